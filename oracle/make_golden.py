@@ -1,0 +1,221 @@
+"""Generate tests/golden/*.npz from the REAL reference (run in the build container only).
+
+    python -m oracle.make_golden            # writes tests/golden/, asserts oracle == reference
+
+TEST INFRASTRUCTURE ONLY.  Every fixture's *outputs* come from the unmodified reference classes
+imported from /root/reference (oracle/_ref_import.py); the restatement in oracle/*_ref.py is
+asserted equal to them on the same inputs (bit-exact on this machine).  The GPU box has no
+/root/reference, so the parity tests there use (a) these committed vectors and (b) the pinned
+restatement.  Big tensors (full-size weights, per-sample source noise) are not stored: they are
+regenerated from the seeds recorded in the fixture and verified against the stored SHA-1.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import _ref_import, mel_ref, nsf_hifigan_ref, sampler_ref, wavenet_ref  # noqa: E402
+
+
+def sha1_of(tensors) -> str:
+    h = hashlib.sha1()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def state_sha1(sd) -> str:
+    return sha1_of([sd[k] for k in sorted(sd)])
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def synth_f0(T: int, frame_rate: float = 44100 / 512) -> torch.Tensor:
+    """220*2^(0.3 sin(2 pi 0.7 t)) Hz with frames 100-130 unvoiced (scaled for short T)."""
+    t = torch.arange(T, dtype=torch.float32) / frame_rate
+    f0 = 220.0 * torch.pow(2.0, 0.3 * torch.sin(2 * np.pi * 0.7 * t))
+    a, b = (100, 130) if T > 160 else (T // 3, T // 3 + max(2, T // 8))
+    f0[a:b] = 0.0
+    return f0
+
+
+WN_SMALL = dict(mel_channels=128, d_encoder=256, residual_channels=64, residual_layers=4, dilation_cycle=4,
+                use_linear_bias=True)
+WN_FULL = dict(mel_channels=128, d_encoder=256, residual_channels=512, residual_layers=20, dilation_cycle=4,
+               use_linear_bias=True)  # configs/_base_/archs/diff_svc_v2.py:27-35
+
+
+def build_ref_diffusion(R, wn_cfg, sd, **kw):
+    diff = R["GaussianDiffusion"](denoiser=dict(type="WaveNetDenoiser", **wn_cfg), spec_min=[-5], spec_max=[0], **kw)
+    diff.denoise_fn.load_state_dict(sd, strict=True)
+    return diff.eval()
+
+
+def oracle_denoiser(sd, cfg):
+    return lambda x, t, c, xm, cm: wavenet_ref.wavenet_forward(
+        sd, x, t, c, xm, cm, residual_layers=cfg["residual_layers"], dilation_cycle=cfg["dilation_cycle"])
+
+
+@torch.no_grad()
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    R = _ref_import.load()
+    torch.set_num_threads(os.cpu_count())
+    manifest = {"torch": torch.__version__, "numpy": np.__version__}
+
+    # ---------------------------------------------------------------- WaveNet forward
+    print("wavenet")
+    for tag, cfg, seed, (B, T) in (("small", WN_SMALL, 101, (2, 50)), ("full", WN_FULL, 1234, (2, 96))):
+        kw = {k: v for k, v in cfg.items() if k != "dilation_cycle"}
+        sd = wavenet_ref.seeded_wavenet_state(seed, **kw)
+        net = R["WaveNet"](**cfg).eval()
+        net.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(B, 128, T, generator=g)
+        cond = torch.randn(B, 256, T, generator=g)
+        t = torch.tensor([37.0, 912.5])[:B]
+        masks = torch.zeros(B, T, dtype=torch.bool)
+        masks[1, T - T // 4:] = True
+        eps = net(x, t, cond)
+        eps_masked = net(x, t, cond, x_masks=masks, cond_masks=masks)
+        eps_long = net(x, torch.tensor([400], dtype=torch.long), cond)  # naive/plms pass a [1] long tensor
+        taps = {}
+        mine = wavenet_ref.wavenet_forward(sd, x, t, cond, residual_layers=cfg["residual_layers"],
+                                           dilation_cycle=cfg["dilation_cycle"], taps=taps)
+        assert torch.equal(mine, eps), "oracle WaveNet != reference"
+        assert torch.equal(wavenet_ref.wavenet_forward(sd, x, t, cond, masks, masks, residual_layers=cfg["residual_layers"],
+                                                       dilation_cycle=cfg["dilation_cycle"]), eps_masked)
+        arrays = dict(x=x, cond=cond, t=t, masks=masks, eps=eps, eps_masked=eps_masked, eps_long=eps_long,
+                      x_layer0=taps["x_0"], x_layer_last=taps[f"x_{cfg['residual_layers'] - 1}"],
+                      skip_sum=taps["skip_sum"], seed=np.int64(seed), weights_sha1=np.array(state_sha1(sd)))
+        if tag == "small":
+            arrays.update({"w:" + k: v for k, v in sd.items()})
+        save(f"wavenet_{tag}", **arrays)
+
+    # ---------------------------------------------------------------- samplers (small net, every predictor)
+    print("samplers (small net)")
+    kw = {k: v for k, v in WN_SMALL.items() if k != "dilation_cycle"}
+    sd = wavenet_ref.seeded_wavenet_state(101, **kw)
+    diff = build_ref_diffusion(R, WN_SMALL, sd)
+    den = oracle_denoiser(sd, WN_SMALL)
+    B, T = 2, 40
+    g = torch.Generator().manual_seed(7)
+    feats = torch.randn(B, T, 256, generator=g)
+    masks = torch.zeros(B, T, dtype=torch.bool)
+    masks[1, 30:] = True
+    betas = sampler_ref.beta_schedule()
+    for pred, interval, skip in (("unipc", 50, 0), ("unipc", 10, 0), ("plms", 50, 0), ("naive", 50, 0),
+                                 ("naive", 1, 900), ("unipc", 100, 400), ("plms", 100, 400)):
+        seed = 1000 + interval + skip
+        mel0 = None
+        if skip:
+            mel0 = torch.rand(B, 128, T, generator=g) * -5
+        torch.manual_seed(seed)
+        ref = diff(feats, sampler_interval=interval, noise_predictor=pred, skip_steps=skip, original_mel=mel0,
+                   x_masks=masks, cond_masks=masks)
+        # replay the reference's RNG draw order: randn(shape) [or randn_like for q_sample], then per-step randn_like
+        torch.manual_seed(seed)
+        if skip:
+            xs = sampler_ref.norm_spec(mel0, torch.tensor([-5.0]).view(1, 1, -1), torch.tensor([0.0]).view(1, 1, -1))
+            x_init = sampler_ref.q_sample(xs, 1000 - skip, torch.randn_like(xs), betas)
+        else:
+            x_init = torch.randn(B, 128, T)
+        n = len(range(0, 1000 - skip, interval))
+        step_noise = torch.stack([torch.randn(B, 128, T) for _ in range(n)]) if pred == "naive" else torch.zeros(0)
+        mine = sampler_ref.diffusion_sample(den, feats, x_init=x_init, sampler_interval=interval, predictor=pred,
+                                            step_noise=step_noise, skip_steps=skip, x_masks=masks, cond_masks=masks)
+        assert torch.equal(mine, ref), f"oracle sampler {pred}/{interval}/{skip} != reference"
+        save(f"sampler_small_{pred}_i{interval}_s{skip}", features=feats, masks=masks, x_init=x_init,
+             step_noise=step_noise, mel=ref, interval=np.int64(interval), skip=np.int64(skip))
+
+    # ---------------------------------------------------------------- BASELINE configs[0] and configs[1] (full net)
+    print("samplers (full net): C1 = 5 s / 20-step UniPC, C2 = 10 s / 100-step UniPC")
+    kw = {k: v for k, v in WN_FULL.items() if k != "dilation_cycle"}
+    sd = wavenet_ref.seeded_wavenet_state(1234, **kw)
+    diff = build_ref_diffusion(R, WN_FULL, sd)
+    for tag, T, interval, seed in (("c1", 430, 50, 1234), ("c2", 861, 10, 1235)):
+        g = torch.Generator().manual_seed(seed)
+        feats = torch.randn(1, T, 256, generator=g)
+        torch.manual_seed(seed + 100)
+        ref = diff(feats, sampler_interval=interval)
+        torch.manual_seed(seed + 100)
+        x_init = torch.randn(1, 128, T)
+        if tag == "c1":
+            mine = sampler_ref.diffusion_sample(oracle_denoiser(sd, WN_FULL), feats, x_init=x_init, sampler_interval=interval)
+            assert torch.equal(mine, ref)
+        save(f"sampler_full_{tag}", features=feats, x_init=x_init, mel=ref, interval=np.int64(interval),
+             seed=np.int64(1234), weights_sha1=np.array(state_sha1(sd)))
+
+    # ---------------------------------------------------------------- NSF-HiFiGAN
+    print("nsf-hifigan")
+    for tag, h, seed, T, store_w in (("v1_small", nsf_hifigan_ref.CONFIG_V1, 55, 24, False),
+                                     ("v1_256_small", nsf_hifigan_ref.CONFIG_V1_256, 56, 20, False),
+                                     ("v1_full", nsf_hifigan_ref.CONFIG_V1, 55, 861, False)):
+        gsd = nsf_hifigan_ref.seeded_generator_state(seed, h)
+        gen = R["Generator"](R["AttrDict"](h))
+        gen.remove_weight_norm()
+        gen.eval()
+        gen.load_state_dict(gsd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        mel = torch.randn(1, 128, T, generator=g) * 0.5 - 2.0
+        f0 = synth_f0(T, h["sampling_rate"] / h["hop_size"])[None]
+        L = T * h["hop_size"]
+        torch.manual_seed(seed + 2)
+        ref = gen(mel, f0)
+        torch.manual_seed(seed + 2)
+        rand_ini = torch.rand(1, 9)
+        rand_ini[:, 0] = 0
+        src_noise = torch.randn(1, L, 9)
+        taps = {}
+        mine = nsf_hifigan_ref.generator_forward(gsd, h, mel, f0, rand_ini, src_noise, taps)
+        assert torch.equal(mine, ref), f"oracle generator {tag} != reference"
+        arrays = dict(mel=mel, f0=f0, rand_ini=rand_ini, wav=ref, har_source=taps["har_source"] if T < 100 else torch.zeros(0),
+                      stage0=taps["stage_0"] if T < 100 else torch.zeros(0),
+                      seed=np.int64(seed), noise_seed=np.int64(seed + 2), weights_sha1=np.array(state_sha1(gsd)),
+                      src_noise_sha1=np.array(sha1_of([src_noise])), config=np.array(json.dumps(h)))
+        if T < 100:
+            arrays["src_noise"] = src_noise
+        save(f"nsf_{tag}", **arrays)
+
+    # ---------------------------------------------------------------- STFT / mel
+    print("mel")
+    pam = R["PitchAdjustableMelSpectrogram"]()
+    g = torch.Generator().manual_seed(77)
+    n = 44100
+    tt = torch.arange(n) / 44100.0
+    wav = (0.4 * torch.sin(2 * np.pi * 220 * tt) + 0.2 * torch.sin(2 * np.pi * 1760 * tt + 1.0)
+           + 0.05 * torch.randn(n, generator=g))[None]
+    arrays = dict(wav=wav)
+    for ks, sp in ((0, 1.0), (3, 1.0), (-5, 1.0), (12, 1.0), (0, 1.5)):
+        ref = pam(wav, key_shift=ks, speed=sp)
+        assert torch.equal(mel_ref.mel_spectrogram(wav, key_shift=ks, speed=sp), ref)
+        arrays[f"mel_ks{ks}_sp{sp}"] = ref
+    arrays["logmel_log10"] = mel_ref.wav2spec(wav, use_natural_log=False)
+    save("mel", **arrays)
+
+    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
