@@ -1,0 +1,11 @@
+"""fish_diffusion_amd -- the MI355X-native hot path of fish-diffusion's SVC/SVS inference
+(WaveNet denoiser + sampler loop + STFT/mel + NSF-HiFiGAN) behind the reference's registry API.
+See DESIGN.md / INTEGRATION.md.  HIP only: no CPU, no PyTorch-eager fallback."""
+from .registry import DENOISERS, DIFFUSIONS, VOCODERS, install  # noqa: F401
+from .wavenet import WaveNet  # noqa: F401
+from .diffusion import GaussianDiffusion  # noqa: F401
+from .nsf_hifigan import NsfHifiGAN, Generator  # noqa: F401
+from .mel import PitchAdjustableMelSpectrogram  # noqa: F401
+
+__all__ = ["DENOISERS", "DIFFUSIONS", "VOCODERS", "install", "WaveNet", "GaussianDiffusion", "NsfHifiGAN", "Generator",
+           "PitchAdjustableMelSpectrogram"]

@@ -1,0 +1,63 @@
+"""Build libfishdx.so (HIP, gfx950 only) in-tree with hipcc.
+
+    python -m fish_diffusion_amd._build [--force]
+
+The shared library is a build artefact (git-ignored) that travels to the GPU box with the repo
+snapshot; there is no JIT and no CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libfishdx.so")
+SOURCES = ["core.hip", "wavenet.hip", "nsf.hip", "mel.hip"]
+HEADERS = ["common.hip.h", "convgemm.hip.h", "elementwise.hip.h", "nsf_kernels.hip.h", "../../include/fishdx.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = []
+
+    def compile_one(src):
+        obj = src[:-4] + ".o"
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,146 @@
+// common.hip.h -- context, error plumbing and device-buffer helpers shared by the translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fishdx.h"
+#include "convgemm.hip.h"
+
+namespace fdx {
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// Row pitch (floats) of a padded activation row holding T valid columns: kHalo zeros, T values, zeros up to a
+// multiple of `cols` (tile overhang) plus kHalo more.  Always a multiple of 32 floats (128 B).
+inline int padded_ld(int T, int cols = 256) { return kHalo + round_up(T, cols) + kHalo; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  // grow-only; returns hipSuccess.  Contents are zeroed whenever `zero` is set (geometry change).
+  hipError_t ensure(size_t bytes, bool zero, hipStream_t s) {
+    if (bytes > cap) {
+      release();
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) { p = nullptr; return e; }
+      cap = bytes;
+    }
+    if (zero && bytes) return hipMemsetAsync(p, 0, bytes, s);
+    return hipSuccess;
+  }
+  float* f() const { return reinterpret_cast<float*>(p); }
+};
+
+// One packed conv/GEMM weight: offsets (in floats) into the arena.
+struct PackedW {
+  size_t w_off = 0;     // fragment-ordered weights
+  size_t b_off = 0;     // bias (logical row order), always present (zeros when the layer has none)
+  int n_mtiles = 0, RB = 2, cin8 = 0, taps = 1;
+  int rows = 0;         // logical rows (bias length)
+};
+
+struct WavenetLayout {
+  PackedW in_proj, mlp0, mlp2, dproj, cond, skip_proj, out_proj;
+  std::vector<PackedW> conv, outp;   // per layer
+  std::vector<int> dil;
+  size_t total_floats = 0;
+};
+
+struct NsfStage {
+  PackedW ups;            // polyphase transposed conv; rows = stride*Cout
+  int ups_shift0 = 0;     // tap j reads input column q + ups_shift0 + j
+  size_t nc_w = 0, nc_b = 0; int nc_k = 1, nc_stride = 1, nc_pad = 0;   // noise conv (VALU kernel), raw layout
+  int cin = 0, cout = 0, stride = 1, ksize = 1;
+  std::vector<PackedW> c1, c2;   // [n_resblock_kernels * n_dil]; c2 empty for ResBlock2
+};
+struct NsfLayout {
+  size_t src_w = 0, src_b = 0;        // m_source.l_linear
+  PackedW conv_pre;
+  std::vector<NsfStage> stages;
+  size_t post_w = 0, post_b = 0; int post_c = 0;   // conv_post (VALU kernel), raw [1][C][7]
+  size_t total_floats = 0;
+};
+
+struct ProfEvents {
+  bool on = false;
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+  double flops_per_launch = 0;
+};
+
+}  // namespace fdx
+
+struct fdx_ctx {
+  int device = 0;
+  std::string err;
+
+  // ---- wavenet
+  bool wn_ok = false;
+  fdx_wavenet_desc wd{};
+  fdx::WavenetLayout wl;
+  const float* wn_arena = nullptr;
+  int B = 0, T = 0, ld = 0;            // prepared geometry
+  bool prepared = false;
+  fdx::DevBuf xin, X, Y, Z, SK, H, EPS, P, condp;
+  fdx::DevBuf tdev, E, Hm, S0, S;      // step-embedding pipeline; ldn below
+  int n_emb = 0, ldn = 0;
+  // ---- sampler state (padded [B][M][ld])
+  fdx::DevBuf sx, sxt, sbase, sm[2], shist[4], seps2, snoise;
+  std::vector<float> ts_host;
+
+  // ---- nsf
+  bool nsf_ok = false;
+  fdx_nsf_desc nd{};
+  fdx::NsfLayout nl;
+  const float* nsf_arena = nullptr;
+  int vB = 0, vT = 0;
+  fdx::DevBuf vmel, vpre, vf0up, vrad, vscan, vhar, vnoise;
+  std::vector<fdx::DevBuf> vU, vR, vTm, vXS;   // per stage
+  fdx::DevBuf scan_part;
+
+  // ---- mel
+  bool mel_ok = false;
+  fdx_mel_desc md{};
+  fdx::DevBuf mel_basis_packed, dft_packed, frames, spec;
+  float dft_key = 1e30f; int dft_nfft = 0, dft_win = 0;   // cache key of dft_packed
+
+  // ---- debug / profiling
+  fdx::DevBuf dbg_w, dbg_x, dbg_b;
+  fdx::ProfEvents prof;
+};
+
+namespace fdx {
+
+extern thread_local std::string g_last_error;   // defined in core.hip
+
+inline int fail(fdx_ctx* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  g_last_error = buf;
+  return code;
+}
+
+#define FDX_HIP(h, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fdx::fail(h, FDX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+inline hipStream_t as_stream(fdx_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace fdx

@@ -1,0 +1,121 @@
+// core.hip -- handle lifetime, error reporting, profiling hooks and the kernel-level test hook.
+#include "common.hip.h"
+
+using namespace fdx;
+
+namespace fdx { thread_local std::string g_last_error; }
+
+extern "C" int fdx_version(void) { return 100; }
+
+extern "C" int fdx_device_available(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n > 0 ? 1 : 0;
+}
+
+extern "C" int fdx_create(int device, fdx_handle* out) {
+  if (!out) return fail(nullptr, FDX_E_ARG, "fdx_create: null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(nullptr, FDX_E_HIP, "fdx_create: no HIP device visible (%s) -- the HIP path has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(nullptr, FDX_E_ARG, "fdx_create: device %d out of range [0,%d)", device, n);
+  hipDeviceProp_t prop;
+  FDX_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, FDX_E_HIP, "fdx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                prop.gcnArchName);
+  FDX_HIP(nullptr, hipSetDevice(device));
+  fdx_ctx* h = new (std::nothrow) fdx_ctx();
+  if (!h) return fail(nullptr, FDX_E_NOMEM, "out of host memory");
+  h->device = device;
+  *out = h;
+  return FDX_OK;
+}
+
+extern "C" int fdx_destroy(fdx_handle h) {
+  if (!h) return FDX_OK;
+  (void)hipSetDevice(h->device);
+  for (auto e : h->prof.start) (void)hipEventDestroy(e);
+  for (auto e : h->prof.stop) (void)hipEventDestroy(e);
+  delete h;
+  return FDX_OK;
+}
+
+extern "C" const char* fdx_last_error(fdx_handle h) {
+  if (h) return h->err.c_str();
+  return g_last_error.c_str();
+}
+
+extern "C" int fdx_prof_enable(fdx_handle h, int on) {
+  if (!h) return FDX_E_ARG;
+  h->prof.on = on != 0;
+  h->prof.used = 0;
+  return FDX_OK;
+}
+
+extern "C" int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch) {
+  if (!h) return FDX_E_ARG;
+  double tot = 0;
+  for (size_t i = 0; i < h->prof.used; ++i) {
+    FDX_HIP(h, hipEventSynchronize(h->prof.stop[i]));
+    float ms = 0;
+    FDX_HIP(h, hipEventElapsedTime(&ms, h->prof.start[i], h->prof.stop[i]));
+    tot += ms;
+  }
+  if (n_launches) *n_launches = (int)h->prof.used;
+  if (total_ms) *total_ms = tot;
+  if (flops_per_launch) *flops_per_launch = h->prof.flops_per_launch;
+  h->prof.used = 0;
+  return FDX_OK;
+}
+
+// y = conv1d(act(x), w, bias, dilation, "same" padding) through the MFMA kernel family -- test hook.
+extern "C" int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, int T, const float* host_w,
+                                const float* host_bias, int Cout, int k, int dilation, float in_slope, int mode, float* y,
+                                fdx_stream st) {
+  if (!h || !x || !host_w || !y) return FDX_E_ARG;
+  if (B <= 0 || Cin <= 0 || T <= 0 || Cout <= 0 || k <= 0 || !(k & 1) || dilation <= 0)
+    return fail(h, FDX_E_ARG, "fdx_debug_conv1d: bad geometry");
+  if ((k - 1) / 2 * dilation > kHalo) return fail(h, FDX_E_ARG, "fdx_debug_conv1d: receptive field exceeds the %d-column halo", kHalo);
+  if (mode != 0 && mode != 1) return fail(h, FDX_E_ARG, "fdx_debug_conv1d: mode must be 0 or 1");
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const int cin8 = (Cin + 7) / 8, cinp = cin8 * 8;
+  const int n_mtiles = (Cout + 63) / 64;
+  const size_t wf = packed_floats(n_mtiles, 2, cin8, k);
+  std::vector<float> packed(wf), bias(round_up(Cout, 64), 0.f);
+  pack_convgemm(packed.data(), n_mtiles, 2, cin8, k, [&](int mt, int rb, int i, int c, int tap) -> float {
+    const int row = mt * 64 + rb * 32 + i;
+    if (row >= Cout || c >= Cin) return 0.f;
+    return host_w[((size_t)row * Cin + c) * k + tap];
+  });
+  if (host_bias) memcpy(bias.data(), host_bias, Cout * sizeof(float));
+  const int ld = padded_ld(T, 256);
+  FDX_HIP(h, h->dbg_w.ensure(wf * 4, false, s));
+  FDX_HIP(h, h->dbg_b.ensure(bias.size() * 4, false, s));
+  FDX_HIP(h, h->dbg_x.ensure((size_t)B * cinp * ld * 4, true, s));
+  FDX_HIP(h, hipMemcpyAsync(h->dbg_w.p, packed.data(), wf * 4, hipMemcpyHostToDevice, s));
+  FDX_HIP(h, hipMemcpyAsync(h->dbg_b.p, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, s));
+  FDX_HIP(h, hipStreamSynchronize(s));   // host vectors die at return (test hook only)
+  for (int b = 0; b < B; ++b)   // item b: rows (b*cinp + c) of the zeroed, padded buffer
+    FDX_HIP(h, hipMemcpy2DAsync(h->dbg_x.f() + (size_t)b * cinp * ld + kHalo, (size_t)ld * 4, x + (size_t)b * Cin * T,
+                                (size_t)T * 4, (size_t)T * 4, (size_t)Cin, hipMemcpyDeviceToDevice, s));
+  EpiBias e{};
+  e.out = y; e.o_bs = (long)Cout * T; e.ldo = T; e.bias = h->dbg_b.f(); e.M = Cout; e.act = ACT_NONE;
+  ConvGeom g{B, T, cin8, k, -(k - 1) / 2 * dilation, dilation, n_mtiles};
+  const float4* Wp = reinterpret_cast<const float4*>(h->dbg_w.p);
+  const float* X = h->dbg_x.f() + kHalo;
+  hipError_t err;
+  if (mode == 0) {
+    err = in_slope == 1.f ? launch_convgemm<2, true, false, EpiBias>(g, Wp, X, (long)cinp * ld, ld, 1.f, e, s)
+                          : launch_convgemm<2, true, true, EpiBias>(g, Wp, X, (long)cinp * ld, ld, in_slope, e, s);
+  } else {
+    err = in_slope == 1.f ? launch_convgemm<2, false, false, EpiBias>(g, Wp, X, (long)cinp * ld, ld, 1.f, e, s)
+                          : launch_convgemm<2, false, true, EpiBias>(g, Wp, X, (long)cinp * ld, ld, in_slope, e, s);
+  }
+  FDX_HIP(h, err);
+  return FDX_OK;
+}

@@ -1,0 +1,438 @@
+// wavenet.hip -- WaveNet-residual denoiser + the sampler loop that drives it.
+//
+// Reference behaviour restated (not translated) from fish_diffusion/modules/wavenet.py:106-120,194-236 and
+// archs/diffsinger/diffusions/{diffusion.py:234-311, noise_predictor.py, uni_pc.py:583-818}.
+//
+// Per denoiser call (B items, T frames, C residual channels, L layers) the device runs
+//   1 x  in_proj      GEMM  [C x M]      epilogue: +bias, ReLU, mask, and Y = X + s_0        (wavenet.py:211-218)
+//   L x  conv+gate    CONV  [2C x 3C]    epilogue: + hoisted conditioner slab, sigmoid*tanh   (:107-115)
+//   L x  out_proj     GEMM  [2C x C]     epilogue: X=(X+res)/sqrt2, Y=X+s_{l+1}, SK(+)=skip   (:117-120,228)
+//   1 x  skip_proj    GEMM  [C x C]      epilogue: +bias, ReLU                                 (:229-230)
+//   1 x  out_proj     GEMM  [M x C]      epilogue: +bias, mask                                 (:231-234)
+// Step-invariant work is hoisted: the L conditioner projections run once per utterance batch
+// (fdx_wavenet_prepare) and the step-embedding MLP + L diffusion projections run once per sampler run for
+// all timesteps at once.
+#include "common.hip.h"
+#include "elementwise.hip.h"
+
+#include <cmath>
+
+using namespace fdx;
+
+
+// ================================================================================================ layout
+static int wn_validate(const fdx_wavenet_desc* d) {
+  if (!d) return fail(nullptr, FDX_E_ARG, "null wavenet desc");
+  if (d->residual_channels <= 0 || d->residual_channels % 32)
+    return fail(nullptr, FDX_E_ARG, "residual_channels must be a positive multiple of 32, got %d", d->residual_channels);
+  if (d->mel_channels <= 0 || d->mel_channels % 8) return fail(nullptr, FDX_E_ARG, "mel_channels must be a multiple of 8");
+  if (d->d_encoder <= 0 || d->d_encoder % 8) return fail(nullptr, FDX_E_ARG, "d_encoder must be a multiple of 8");
+  if (d->residual_layers <= 0) return fail(nullptr, FDX_E_ARG, "residual_layers must be positive");
+  if (d->dilation_cycle < 0 || d->dilation_cycle > 5)
+    return fail(nullptr, FDX_E_ARG, "dilation_cycle %d unsupported (max dilation 16 must fit the %d-column halo)", d->dilation_cycle, kHalo);
+  return FDX_OK;
+}
+
+static PackedW plan_w(size_t& cur, int rows, int cin, int taps, bool paired) {
+  PackedW p;
+  p.RB = 2;
+  p.rows = rows;
+  p.cin8 = (cin + 7) / 8;
+  p.taps = taps;
+  p.n_mtiles = paired ? (rows / 2 + 31) / 32 : (rows + 63) / 64;
+  p.w_off = cur;
+  cur += packed_floats(p.n_mtiles, p.RB, p.cin8, p.taps);
+  p.b_off = cur;
+  cur += (size_t)round_up(rows, 64);
+  return p;
+}
+
+static void wn_layout(const fdx_wavenet_desc& d, WavenetLayout& l) {
+  const int C = d.residual_channels, L = d.residual_layers;
+  size_t cur = 0;
+  l.in_proj = plan_w(cur, C, d.mel_channels, 1, false);
+  l.mlp0 = plan_w(cur, 4 * C, C, 1, false);
+  l.mlp2 = plan_w(cur, C, 4 * C, 1, false);
+  l.dproj = plan_w(cur, L * C, C, 1, false);
+  l.cond = plan_w(cur, L * 2 * C, d.d_encoder, 1, false);
+  l.conv.clear(); l.outp.clear(); l.dil.clear();
+  for (int i = 0; i < L; ++i) {
+    l.conv.push_back(plan_w(cur, 2 * C, C, 3, true));
+    l.outp.push_back(plan_w(cur, 2 * C, C, 1, false));
+    l.dil.push_back(d.dilation_cycle ? 1 << (i % d.dilation_cycle) : 1);
+  }
+  l.skip_proj = plan_w(cur, C, C, 1, false);
+  l.out_proj = plan_w(cur, d.mel_channels, C, 1, false);
+  l.total_floats = cur;
+}
+
+extern "C" int fdx_wavenet_num_weights(const fdx_wavenet_desc* d) {
+  if (wn_validate(d)) return FDX_E_ARG;
+  const int lb = d->use_linear_bias ? 1 : 0;
+  return 2 + 2 * (1 + lb) + d->residual_layers * (6 + 1 + lb) + 4;
+}
+
+extern "C" int fdx_wavenet_packed_bytes(const fdx_wavenet_desc* d, size_t* bytes) {
+  if (wn_validate(d) || !bytes) return FDX_E_ARG;
+  WavenetLayout l;
+  wn_layout(*d, l);
+  *bytes = l.total_floats * sizeof(float);
+  return FDX_OK;
+}
+
+// plain (unpaired) conv/linear weight [rows][cin][taps] -> fragment order; rows/cin beyond the tensor are 0
+static void pack_plain(float* arena, const PackedW& p, const float* w, int rows, int cin, const float* bias) {
+  pack_convgemm(arena + p.w_off, p.n_mtiles, p.RB, p.cin8, p.taps, [&](int mt, int rb, int i, int c, int tap) -> float {
+    const int row = mt * 64 + rb * 32 + i;
+    if (row >= rows || c >= cin) return 0.f;
+    return w[((size_t)row * cin + c) * p.taps + tap];
+  });
+  for (int r = 0; r < round_up(rows, 64); ++r) arena[p.b_off + r] = (bias && r < rows) ? bias[r] : 0.f;
+}
+
+extern "C" int fdx_wavenet_pack(const fdx_wavenet_desc* d, const float* const* w, int n, void* out, size_t bytes) {
+  if (wn_validate(d)) return FDX_E_ARG;
+  if (!w || !out) return fail(nullptr, FDX_E_ARG, "null pointer");
+  if (n != fdx_wavenet_num_weights(d))
+    return fail(nullptr, FDX_E_ARG, "expected %d weight tensors, got %d", fdx_wavenet_num_weights(d), n);
+  WavenetLayout l;
+  wn_layout(*d, l);
+  if (bytes != l.total_floats * sizeof(float)) return fail(nullptr, FDX_E_ARG, "packed size mismatch");
+  float* A = static_cast<float*>(out);
+  memset(A, 0, bytes);
+  const int C = d->residual_channels, L = d->residual_layers, E = d->d_encoder, M = d->mel_channels;
+  const int lb = d->use_linear_bias ? 1 : 0;
+  int k = 0;
+  pack_plain(A, l.in_proj, w[k], C, M, w[k + 1]); k += 2;
+  pack_plain(A, l.mlp0, w[k], 4 * C, C, lb ? w[k + 1] : nullptr); k += 1 + lb;
+  pack_plain(A, l.mlp2, w[k], C, 4 * C, lb ? w[k + 1] : nullptr); k += 1 + lb;
+  std::vector<const float*> dpw(L), dpb(L), cpw(L);
+  for (int i = 0; i < L; ++i) {
+    const float* conv_w = w[k]; const float* conv_b = w[k + 1]; k += 2;
+    dpw[i] = w[k]; dpb[i] = lb ? w[k + 1] : nullptr; k += 1 + lb;
+    cpw[i] = w[k]; const float* cp_b = w[k + 1]; k += 2;
+    const float* op_w = w[k]; const float* op_b = w[k + 1]; k += 2;
+    // dilated conv, gate/filter paired: tile mt holds gate rows 32mt.. (rb 0) and filter rows C+32mt.. (rb 1)
+    const PackedW& pc = l.conv[i];
+    pack_convgemm(A + pc.w_off, pc.n_mtiles, 2, pc.cin8, 3, [&](int mt, int rb, int r, int c, int tap) -> float {
+      const int ch = mt * 32 + r;
+      if (ch >= C || c >= C) return 0.f;
+      return conv_w[((size_t)(rb * C + ch) * C + c) * 3 + tap];
+    });
+    // the hoisted conditioner slab also absorbs the conv bias: y = (conv + b_conv) + (cond + b_cond), wavenet.py:112
+    for (int r = 0; r < 2 * C; ++r) A[l.cond.b_off + (size_t)i * 2 * C + r] = cp_b[r] + conv_b[r];
+    pack_plain(A, l.outp[i], op_w, 2 * C, C, op_b);
+  }
+  {  // diffusion projections of all layers = one [L*C x C] GEMM; conditioner projections = one [L*2C x E] GEMM
+    const PackedW& p = l.dproj;
+    pack_convgemm(A + p.w_off, p.n_mtiles, 2, p.cin8, 1, [&](int mt, int rb, int r, int c, int) -> float {
+      const int row = mt * 64 + rb * 32 + r;
+      if (row >= L * C || c >= C) return 0.f;
+      return dpw[row / C][(size_t)(row % C) * C + c];
+    });
+    for (int r = 0; r < L * C; ++r) A[p.b_off + r] = dpb[r / C] ? dpb[r / C][r % C] : 0.f;
+    const PackedW& q = l.cond;
+    pack_convgemm(A + q.w_off, q.n_mtiles, 2, q.cin8, 1, [&](int mt, int rb, int r, int c, int) -> float {
+      const int row = mt * 64 + rb * 32 + r;
+      if (row >= L * 2 * C || c >= E) return 0.f;
+      return cpw[row / (2 * C)][(size_t)(row % (2 * C)) * E + c];
+    });
+  }
+  pack_plain(A, l.skip_proj, w[k], C, C, w[k + 1]); k += 2;
+  pack_plain(A, l.out_proj, w[k], M, C, w[k + 1]); k += 2;
+  return FDX_OK;
+}
+
+extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const void* dev, size_t bytes) {
+  if (!h) return FDX_E_ARG;
+  if (wn_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
+  WavenetLayout l;
+  wn_layout(*d, l);
+  if (!dev || bytes != l.total_floats * sizeof(float)) return fail(h, FDX_E_ARG, "packed arena size mismatch");
+  h->wd = *d;
+  h->wl = l;
+  h->wn_arena = static_cast<const float*>(dev);
+  h->wn_ok = true;
+  h->prepared = false;
+  return FDX_OK;
+}
+
+// ================================================================================================ launch helpers
+template <bool SPLITK, bool LRELU, class Epi>
+static hipError_t run_gemm(const float* arena, const PackedW& p, int B, int T, const float* X, long x_bs, int ldx,
+                           int shift0, int dshift, float slope, const Epi& e, hipStream_t s) {
+  ConvGeom g{B, T, p.cin8, p.taps, shift0, dshift, p.n_mtiles};
+  return launch_convgemm<2, SPLITK, LRELU, Epi>(g, reinterpret_cast<const float4*>(arena + p.w_off), X, x_bs, ldx, slope, e, s);
+}
+
+static EpiBias epi_bias(float* out, long o_bs, int ldo, const float* bias, int M, int act) {
+  EpiBias e{};
+  e.out = out; e.o_bs = o_bs; e.ldo = ldo; e.bias = bias; e.M = M; e.act = act;
+  return e;
+}
+
+// ================================================================================================ prepare
+static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
+  const auto& d = h->wd;
+  const int C = d.residual_channels, L = d.residual_layers, M = d.mel_channels, E = d.d_encoder;
+  const int ld = padded_ld(T, 64);
+  const bool geom = (B != h->B || T != h->T);
+  h->B = B; h->T = T; h->ld = ld;
+  auto sz = [&](int ch) { return (size_t)B * ch * ld * sizeof(float); };
+  // every buffer that is read with column shifts must have zero halos => re-zero on geometry change
+  FDX_HIP(h, h->xin.ensure(sz(M), geom, s));
+  FDX_HIP(h, h->X.ensure(sz(C), geom, s));
+  FDX_HIP(h, h->Y.ensure(sz(C), geom, s));
+  FDX_HIP(h, h->Z.ensure(sz(C), geom, s));
+  FDX_HIP(h, h->SK.ensure(sz(C), geom, s));
+  FDX_HIP(h, h->H.ensure(sz(C), geom, s));
+  FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
+  FDX_HIP(h, h->condp.ensure(sz(E), geom, s));
+  FDX_HIP(h, h->P.ensure(sz(L * 2 * C), geom, s));
+  return FDX_OK;
+}
+
+extern "C" int fdx_wavenet_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask, fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  if (!h->wn_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_prepare: no weights attached");
+  if (!cond || B <= 0 || T <= 0) return fail(h, FDX_E_ARG, "fdx_wavenet_prepare: bad cond/B/T");
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  if (int rc = wn_alloc(h, B, T, s)) return rc;
+  const auto& d = h->wd;
+  const int C = d.residual_channels, L = d.residual_layers, E = d.d_encoder, ld = h->ld;
+  // conditioner.masked_fill(cond_masks) (wavenet.py:220-221) while staging into the padded layout
+  hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, h->condp.f() + kHalo, (long)E * ld, ld, cond,
+                     (long)E * T, T, E, T, 1.f, cond_mask);
+  // P[b][l*2C + r][t] = Wc_l[r] . cond[b][:, t] + bc_l[r] + bconv_l[r]   -- all layers in one GEMM
+  EpiBias e = epi_bias(h->P.f() + kHalo, (long)L * 2 * C * ld, ld, h->wn_arena + h->wl.cond.b_off, L * 2 * C, ACT_NONE);
+  FDX_HIP(h, (run_gemm<true, false>(h->wn_arena, h->wl.cond, B, T, h->condp.f() + kHalo, (long)E * ld, ld, 0, 0, 1.f, e, s)));
+  h->prepared = true;
+  return FDX_OK;
+}
+
+// ================================================================================================ step embeddings
+// S[(l*C + c)][j] = diffusion_projection_l(mlp(embedding(t_j)))[c] for j < n   (wavenet.py:214-215,107)
+static int wn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s) {
+  const auto& d = h->wd;
+  const int C = d.residual_channels, L = d.residual_layers;
+  const int ldn = padded_ld(n, 64);
+  const bool geom = ldn != h->ldn;
+  h->ldn = ldn; h->n_emb = n;
+  FDX_HIP(h, h->E.ensure((size_t)C * ldn * 4, geom, s));
+  FDX_HIP(h, h->Hm.ensure((size_t)4 * C * ldn * 4, geom, s));
+  FDX_HIP(h, h->S0.ensure((size_t)C * ldn * 4, geom, s));
+  FDX_HIP(h, h->S.ensure((size_t)L * C * ldn * 4, geom, s));
+  const float* A = h->wn_arena;
+  hipLaunchKernelGGL(k_step_embed, ew_grid(n, C), dim3(kEwBlock), 0, s, h->E.f() + kHalo, ldn, t_dev, n, C);
+  EpiBias e0 = epi_bias(h->Hm.f() + kHalo, 0, ldn, A + h->wl.mlp0.b_off, 4 * C, ACT_MISH);
+  FDX_HIP(h, (run_gemm<true, false>(A, h->wl.mlp0, 1, n, h->E.f() + kHalo, 0, ldn, 0, 0, 1.f, e0, s)));
+  EpiBias e1 = epi_bias(h->S0.f() + kHalo, 0, ldn, A + h->wl.mlp2.b_off, C, ACT_NONE);
+  FDX_HIP(h, (run_gemm<true, false>(A, h->wl.mlp2, 1, n, h->Hm.f() + kHalo, 0, ldn, 0, 0, 1.f, e1, s)));
+  EpiBias e2 = epi_bias(h->S.f() + kHalo, 0, ldn, A + h->wl.dproj.b_off, L * C, ACT_NONE);
+  FDX_HIP(h, (run_gemm<true, false>(A, h->wl.dproj, 1, n, h->S0.f() + kHalo, 0, ldn, 0, 0, 1.f, e2, s)));
+  return FDX_OK;
+}
+
+// ================================================================================================ forward
+// xin: padded [B][M][ld] (valid data at +kHalo).  Step projections are read from column `col0 + b*sb_bs` of S.
+// eps_out: [B][M] rows with pitch ldo / item stride o_bs (padded EPS buffer or the caller's tensor).
+static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out,
+                           long o_bs, int ldo, hipStream_t s) {
+  const auto& d = h->wd;
+  const auto& l = h->wl;
+  const int C = d.residual_channels, L = d.residual_layers, M = d.mel_channels;
+  const int B = h->B, T = h->T, ld = h->ld, ldn = h->ldn;
+  const float* A = h->wn_arena;
+  const long bsC = (long)C * ld;
+  float* X = h->X.f() + kHalo; float* Y = h->Y.f() + kHalo; float* Z = h->Z.f() + kHalo;
+  float* SK = h->SK.f() + kHalo; float* H = h->H.f() + kHalo;
+  const float* S = h->S.f() + kHalo + col0;
+
+  {  // input projection + ReLU + mask; Y = X + s_0
+    EpiBias e = epi_bias(X, bsC, ld, A + l.in_proj.b_off, C, ACT_RELU);
+    e.mask = mask; e.mask_ld = T;
+    e.out2 = Y; e.o2_bs = bsC; e.ldo2 = ld; e.sb = S; e.sb_ld = ldn; e.sb_bs = sb_bs;
+    FDX_HIP(h, (run_gemm<true, false>(A, l.in_proj, B, T, xin, (long)M * ld, ld, 0, 0, 1.f, e, s)));
+  }
+  const float sqrtL = (float)std::sqrt((double)L);
+  for (int i = 0; i < L; ++i) {
+    const int dil = l.dil[i];
+    EpiGate g{};
+    g.out = Z; g.o_bs = bsC; g.ldo = ld;
+    g.P = h->P.f() + kHalo + (size_t)i * 2 * C * ld; g.p_bs = (long)L * 2 * C * ld; g.ldp = ld; g.C = C;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (h->prof.on) {
+      auto& pe = h->prof;
+      if (pe.used == pe.start.size()) {
+        hipEvent_t a, b;
+        FDX_HIP(h, hipEventCreate(&a)); FDX_HIP(h, hipEventCreate(&b));
+        pe.start.push_back(a); pe.stop.push_back(b);
+      }
+      ev0 = pe.start[pe.used]; ev1 = pe.stop[pe.used]; pe.used++;
+      pe.flops_per_launch = 2.0 * (2.0 * C) * (3.0 * C) * (double)B * T;
+      FDX_HIP(h, hipEventRecord(ev0, s));
+    }
+    FDX_HIP(h, (run_gemm<true, false>(A, l.conv[i], B, T, Y, bsC, ld, -dil, dil, 1.f, g, s)));
+    if (ev1) FDX_HIP(h, hipEventRecord(ev1, s));
+
+    EpiResSkip r{};
+    r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
+    r.Y = (i + 1 < L) ? Y : nullptr;
+    r.sb = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn; r.sb_ld = ldn; r.sb_bs = sb_bs;
+    r.skip_mode = (L == 1) ? 3 : (i == 0 ? 0 : (i + 1 == L ? 2 : 1));
+    r.inv_div = sqrtL;
+    FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s)));
+  }
+  {
+    EpiBias e = epi_bias(H, bsC, ld, A + l.skip_proj.b_off, C, ACT_RELU);
+    FDX_HIP(h, (run_gemm<true, false>(A, l.skip_proj, B, T, SK, bsC, ld, 0, 0, 1.f, e, s)));
+  }
+  {
+    EpiBias e = epi_bias(eps_out, o_bs, ldo, A + l.out_proj.b_off, M, ACT_NONE);
+    e.mask = mask; e.mask_ld = T;
+    FDX_HIP(h, (run_gemm<true, false>(A, l.out_proj, B, T, H, bsC, ld, 0, 0, 1.f, e, s)));
+  }
+  return FDX_OK;
+}
+
+extern "C" int fdx_wavenet_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask,
+                                   float* eps, fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  if (!h->wn_ok || !h->prepared) return fail(h, FDX_E_STATE, "fdx_wavenet_forward: call attach + prepare first");
+  if (!x || !t || !eps) return fail(h, FDX_E_ARG, "fdx_wavenet_forward: null pointer");
+  if (n_t != 1 && n_t != h->B) return fail(h, FDX_E_ARG, "diffusion_step must have 1 or B=%d entries, got %d", h->B, n_t);
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const int M = h->wd.mel_channels, B = h->B, T = h->T, ld = h->ld;
+  if (int rc = wn_embed(h, t, n_t, s)) return rc;
+  hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * M), dim3(kEwBlock), 0, s, h->xin.f() + kHalo, (long)M * ld, ld, x,
+                     (long)M * T, T, M, T, 1.f, (const uint8_t*)nullptr);
+  return wn_forward_core(h, h->xin.f() + kHalo, 0, n_t == 1 ? 0 : 1, x_mask, eps, (long)M * T, T, s);
+}
+
+// ================================================================================================ sampler
+static void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_randn, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, out, n, seed, offset);
+}
+
+extern "C" int fdx_randn(fdx_handle h, float* out, size_t n, uint64_t seed, uint64_t offset, fdx_stream st) {
+  if (!h || !out) return FDX_E_ARG;
+  FDX_HIP(h, hipSetDevice(h->device));
+  if (n) launch_randn(out, n, seed, offset, as_stream(st));
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
+
+extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_rows, float* x, const float* step_noise,
+                               uint64_t seed, const uint8_t* x_mask, fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  if (!h->wn_ok || !h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run: call attach + prepare first");
+  if (!tab || n_rows <= 0 || !x) return fail(h, FDX_E_ARG, "fdx_sampler_run: bad table / x");
+  if (kind != FDX_SAMPLER_NAIVE && kind != FDX_SAMPLER_UNIPC && kind != FDX_SAMPLER_PLMS)
+    return fail(h, FDX_E_NOIMPL, "Unknown noise predictor: %d", kind);
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const int M = h->wd.mel_channels, B = h->B, T = h->T, ld = h->ld;
+  const long bs = (long)M * ld;
+  const size_t bytes = (size_t)B * M * ld * sizeof(float);
+  const dim3 grid = ew_grid(T, B * M), blk(kEwBlock);
+
+  // ---- timesteps of every model evaluation, embedded in one batch
+  std::vector<float>& ts = h->ts_host;   // context-owned: outlives the (pageable, staged) async copy
+  ts.clear();
+  for (int r = 0; r < n_rows; ++r) ts.push_back(tab[(size_t)r * FDX_ROW]);
+  if (kind == FDX_SAMPLER_PLMS) ts.push_back(tab[1]);   // t_prev of the first step (diffusion.py:285)
+  FDX_HIP(h, h->tdev.ensure(ts.size() * 4, false, s));
+  FDX_HIP(h, hipMemcpyAsync(h->tdev.p, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, s));
+  if (int rc = wn_embed(h, h->tdev.f(), (int)ts.size(), s)) return rc;
+
+  FDX_HIP(h, h->sx.ensure(bytes, true, s));
+  float* sx = h->sx.f() + kHalo;
+  float* eps = h->EPS.f() + kHalo;
+  hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, sx, bs, ld, x, (long)M * T, T, M, T, 1.f, (const uint8_t*)nullptr);
+  auto model = [&](const float* xin, int col, bool masked) {
+    return wn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s);
+  };
+
+  if (kind == FDX_SAMPLER_UNIPC) {
+    FDX_HIP(h, h->sxt.ensure(bytes, true, s));
+    FDX_HIP(h, h->sbase.ensure(bytes, true, s));
+    for (auto& b : h->sm) FDX_HIP(h, b.ensure(bytes, true, s));
+    FDX_HIP(h, h->seps2.ensure(bytes, true, s));
+    float* xt = h->sxt.f() + kHalo; float* xb = h->sbase.f() + kHalo;
+    float* m0 = h->sm[0].f() + kHalo; float* m1 = h->sm[1].f() + kHalo; float* mt = h->seps2.f() + kHalo;
+    if (int rc = model(sx, 0, true)) return rc;
+    hipLaunchKernelGGL(k_x0_pred, grid, blk, 0, s, m0, sx, eps, bs, ld, M, T, tab[1], tab[2]);
+    for (int r = 1; r < n_rows; ++r) {
+      const float* row = tab + (size_t)r * FDX_ROW;
+      const float sigma = row[1], alpha = row[2], c_x = row[3], c_m = row[4], aB = row[5], rk = row[6];
+      const int order = (int)row[7], corr = (int)row[8];
+      hipLaunchKernelGGL(k_unipc_pre, grid, blk, 0, s, xb, xt, sx, m0, m1, bs, ld, M, T, c_x, c_m, aB, rk, order);
+      if (corr) {
+        if (int rc = model(xt, r, true)) return rc;
+        hipLaunchKernelGGL(k_unipc_post, grid, blk, 0, s, sx, mt, xb, xt, eps, m0, m1, bs, ld, M, T, sigma, alpha, aB, rk,
+                           order, row[9], row[10]);
+        float* tmp = m1; m1 = m0; m0 = mt; mt = tmp;   // history shift (uni_pc.py:797-804)
+      } else {
+        FDX_HIP(h, hipMemcpyAsync(h->sx.p, h->sxt.p, bytes, hipMemcpyDeviceToDevice, s));
+      }
+    }
+  } else if (kind == FDX_SAMPLER_NAIVE) {
+    const size_t n_el = (size_t)B * M * T;
+    if (!step_noise) FDX_HIP(h, h->snoise.ensure(n_el * 4, false, s));
+    for (int r = 0; r < n_rows; ++r) {
+      const float* row = tab + (size_t)r * FDX_ROW;
+      if (int rc = model(sx, r, true)) return rc;
+      const float* nz = step_noise ? step_noise + (size_t)r * n_el : h->snoise.f();
+      if (!step_noise) launch_randn(h->snoise.f(), n_el, seed, (uint64_t)r * ((n_el + 3) / 4), s);
+      hipLaunchKernelGGL(k_naive_step, grid, blk, 0, s, sx, eps, nz, (long)M * T, T, bs, ld, M, T, row[1], row[2], row[3],
+                         row[4], row[5]);
+    }
+  } else {  // PLMS
+    FDX_HIP(h, h->sxt.ensure(bytes, true, s));
+    FDX_HIP(h, h->seps2.ensure(bytes, true, s));
+    for (auto& b : h->shist) FDX_HIP(h, b.ensure(bytes, true, s));
+    float* xp = h->sxt.f() + kHalo; float* prime = h->seps2.f() + kHalo;
+    // hist[0] = newest stored eps (noise_list[-1]) ... hist[2] = noise_list[-3]; `cur` takes this step's eps
+    float* hist[3] = {h->shist[0].f() + kHalo, h->shist[1].f() + kHalo, h->shist[2].f() + kHalo};
+    float* cur = h->shist[3].f() + kHalo;
+    int n_hist = 0;
+    for (int r = 0; r < n_rows; ++r) {
+      const float* row = tab + (size_t)r * FDX_ROW;
+      const float A = row[2], P = row[3], Q = row[4];
+      if (int rc = model(sx, r, true)) return rc;
+      FDX_HIP(h, hipMemcpyAsync(cur - kHalo, h->EPS.p, bytes, hipMemcpyDeviceToDevice, s));
+      if (n_hist == 0) {
+        hipLaunchKernelGGL(k_plms_pred, grid, blk, 0, s, xp, sx, cur, bs, ld, M, T, A, P, Q);
+        if (int rc = model(xp, n_rows, false)) return rc;   // second call without masks (diffusion.py:285)
+        hipLaunchKernelGGL(k_plms_blend, grid, blk, 0, s, prime, cur, eps, eps, eps, bs, ld, M, T, 0);
+      } else {
+        hipLaunchKernelGGL(k_plms_blend, grid, blk, 0, s, prime, cur, hist[0], hist[1], hist[2], bs, ld, M, T, n_hist);
+      }
+      hipLaunchKernelGGL(k_plms_pred, grid, blk, 0, s, sx, sx, prime, bs, ld, M, T, A, P, Q);
+      float* freed = hist[2];
+      hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = cur; cur = freed;
+      if (n_hist < 3) ++n_hist;
+    }
+  }
+  hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, x, (long)M * T, T, sx, bs, ld, M, T, 1.f, (const uint8_t*)nullptr);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
+
+extern "C" int fdx_denorm_spec(fdx_handle h, const float* x, int B, int M, int T, const float* spec_min,
+                               const float* spec_max, int n_spec, float* mel, fdx_stream st) {
+  if (!h || !x || !mel || !spec_min || !spec_max) return FDX_E_ARG;
+  if (n_spec != 1 && n_spec != M) return fail(h, FDX_E_ARG, "spec_min and spec_max must be either of length 1 or mel_channels");
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  FDX_HIP(h, h->dbg_b.ensure(2 * (size_t)n_spec * 4, false, s));
+  FDX_HIP(h, hipMemcpyAsync(h->dbg_b.p, spec_min, n_spec * 4, hipMemcpyHostToDevice, s));
+  FDX_HIP(h, hipMemcpyAsync(h->dbg_b.f() + n_spec, spec_max, n_spec * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_denorm_transpose, dim3((T + 31) / 32, (M + 31) / 32, B), dim3(256), 0, s, mel, x, M, T,
+                     h->dbg_b.f(), h->dbg_b.f() + n_spec, n_spec);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}

@@ -1,0 +1,206 @@
+/*
+ * fishdx.h -- C ABI of libfishdx.so: the MI355X (gfx950) native hot path of fish-diffusion's
+ * SVC/SVS inference: WaveNet-residual denoiser, noise-schedule sampler loop, STFT/mel front end
+ * and NSF-HiFiGAN vocoder.
+ *
+ * Every entry point replaces one Python-level interface of the reference (cited as file:line,
+ * relative to the fish-diffusion v2.2.0 tree).  The reference has no native code, so what a
+ * maintainer binds is a ctypes stub inside the registered nn.Module -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  "dev" pointers are HIP device memory owned by the
+ *     caller (torch tensors' data_ptr()); "host" pointers are ordinary host memory.
+ *   - every function returns 0 on success, <0 on error; fdx_last_error() gives the message.
+ *     No exception crosses the ABI; the Python wrappers map codes to the reference's exception types.
+ *   - kernels are enqueued on the caller's stream (hipStream_t passed as void*); the library never
+ *     synchronises the device inside *_forward / *_run.  Buffers grow only in *_prepare / first call
+ *     with a new geometry.
+ *   - all arithmetic is fp32 (f32-in/f32-acc MFMA), activations are [B][C][T] with T contiguous.
+ *   - a handle is NOT re-entrant: one in-flight call per handle (the Python wrapper holds a lock;
+ *     the reference's flask_api.py:86 can call forward from several threads).
+ */
+#ifndef FISHDX_H_
+#define FISHDX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fdx_ctx* fdx_handle;
+typedef void* fdx_stream; /* hipStream_t */
+
+enum {
+  FDX_OK = 0,
+  FDX_E_ARG = -1,     /* bad argument / geometry (maps to ValueError / AssertionError) */
+  FDX_E_STATE = -2,   /* call order (weights not attached, prepare not called)  (RuntimeError) */
+  FDX_E_HIP = -3,     /* HIP runtime error (RuntimeError) */
+  FDX_E_NOIMPL = -4,  /* unsupported variant (NotImplementedError) */
+  FDX_E_NOMEM = -5
+};
+
+int fdx_version(void);
+/* 1 if a HIP device is visible to this process, else 0 (never fails). */
+int fdx_device_available(void);
+int fdx_create(int device, fdx_handle* out);
+int fdx_destroy(fdx_handle h);
+/* h may be NULL: returns the last error of a failed fdx_create / pure-host call on this thread. */
+const char* fdx_last_error(fdx_handle h);
+
+/* ------------------------------------------------------------------------------------------------
+ * WaveNet denoiser  -- replaces fish_diffusion/modules/wavenet.py:151-236 (WaveNet.__init__/forward),
+ * registered as DENOISERS "WaveNetDenoiser" at archs/diffsinger/diffusions/builder.py:10.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int mel_channels;      /* 128 */
+  int d_encoder;         /* 256 */
+  int residual_channels; /* 512; multiple of 32 */
+  int residual_layers;   /* 20 */
+  int dilation_cycle;    /* 4, or 0 for "None" (all dilations 1) -- wavenet.py:181 */
+  int use_linear_bias;   /* wavenet.py:161 */
+} fdx_wavenet_desc;
+
+/* Canonical tensor order expected by fdx_wavenet_pack = the reference's state_dict order
+ * (wavenet.py:168-191): input_projection.conv.{weight,bias}, mlp.0.linear.{weight[,bias]},
+ * mlp.2.linear.{weight[,bias]}, then per layer conv_layer.conv.{weight,bias},
+ * diffusion_projection.linear.{weight[,bias]}, conditioner_projection.conv.{weight,bias},
+ * output_projection.conv.{weight,bias}; then skip_projection.conv.{weight,bias},
+ * output_projection.conv.{weight,bias}.  Conv1d weights [Cout][Cin][k], Linear [out][in]. */
+int fdx_wavenet_num_weights(const fdx_wavenet_desc* d);
+int fdx_wavenet_packed_bytes(const fdx_wavenet_desc* d, size_t* bytes);
+/* Pure host: repack reference-layout fp32 tensors into the MFMA-fragment-ordered arena. */
+int fdx_wavenet_pack(const fdx_wavenet_desc* d, const float* const* host_weights, int n_weights,
+                     void* host_packed, size_t bytes);
+/* Attach a packed arena that already lives in device memory (owned by the caller; it must outlive
+ * the handle or the next attach).  Rank 0 packs + uploads, the other ranks receive the same bytes
+ * by one RCCL broadcast and attach them -- see fish_diffusion_amd/dist.py. */
+int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const void* dev_packed, size_t bytes);
+
+/* Step-invariant work for one batch of utterances (conditioner slabs for all layers, wavenet.py:108).
+ * cond: dev [B][d_encoder][T]; cond_mask: dev [B][T] bytes (1 = masked, wavenet.py:220-221) or NULL. */
+int fdx_wavenet_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask,
+                        fdx_stream s);
+/* eps = WaveNet(x, t, cond).  x, eps: dev [B][mel_channels][T]; t: dev [n_t] floats with n_t == B or 1
+ * (the samplers pass one timestep for the whole batch, noise_predictor.py:12-13);
+ * x_mask: dev [B][T] bytes or NULL (wavenet.py:217-218,233-234). */
+int fdx_wavenet_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask,
+                        float* eps, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler loop -- replaces GaussianDiffusion.forward's loop, diffusion.py:234-311, and the three
+ * predictors (noise_predictor.py:19-222, uni_pc.py:583-818).  The per-step scalars are computed by
+ * the host (fish_diffusion_amd/schedule.py mirrors the reference's fp32 arithmetic) and passed as a
+ * table of FDX_ROW floats per row; the tensor math runs on the device with no host round trip.
+ * ---------------------------------------------------------------------------------------------- */
+enum { FDX_SAMPLER_NAIVE = 0, FDX_SAMPLER_UNIPC = 1, FDX_SAMPLER_PLMS = 2 };
+#define FDX_ROW 16
+/* Row layouts (unused columns 0):
+ *  UNIPC row 0      : {t_input, sigma_t, alpha_t}                                  (initial model call)
+ *  UNIPC row r>=1   : {t_input, sigma_t, alpha_t, c_x = sigma_t/sigma_prev, c_m = alpha_t*h_phi_1,
+ *                      aB = alpha_t*B_h, rk, order(1|2), use_corrector(0|1), rho_c0, rho_c1}
+ *  NAIVE row        : {t, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, noise_scale}
+ *  PLMS  row        : {t, t_prev, A = a_prev - a_t, P, Q}   (noise_predictor.py:118-131)
+ */
+/* x: dev [B][M][T], in = x_T (initial noise or q_sample'd mel), out = x_0 (normalised mel).
+ * step_noise: NAIVE only, dev [n_rows][B][M][T] standard normals, or NULL => device Philox(seed).
+ * x_mask as in fdx_wavenet_forward.  fdx_wavenet_prepare must have been called for this batch. */
+int fdx_sampler_run(fdx_handle h, int kind, const float* host_table, int n_rows, float* x,
+                    const float* step_noise, uint64_t seed, const uint8_t* x_mask, fdx_stream s);
+/* norm_spec / denorm_spec + the [B,M,T] <-> [B,T,M] transposes, diffusion.py:315-319,217.
+ * spec_min/max: host arrays of n_spec (1 or M) floats.  denorm: x [B][M][T] -> mel [B][T][M]. */
+int fdx_denorm_spec(fdx_handle h, const float* x, int B, int M, int T, const float* spec_min,
+                    const float* spec_max, int n_spec, float* mel, fdx_stream s);
+/* Standard-normal fill with the library's Philox4x32-10 generator (perf mode's stand-in for
+ * torch.randn at diffusion.py:222). */
+int fdx_randn(fdx_handle h, float* out, size_t n, uint64_t seed, uint64_t offset, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * NSF-HiFiGAN generator -- replaces modules/vocoders/nsf_hifigan/models.py:353-448 (Generator),
+ * :27-158 (ResBlock1/2), :161-350 (SineGen, SourceModuleHnNSF) and the scalar glue of
+ * NsfHifiGAN.spec2wav, nsf_hifigan.py:72-85.
+ * ---------------------------------------------------------------------------------------------- */
+#define FDX_MAX_STAGES 8
+#define FDX_MAX_RESK 4
+#define FDX_MAX_DIL 4
+typedef struct {
+  int num_mels;                 /* 128 */
+  int upsample_initial_channel; /* 512 */
+  int n_stages;
+  int upsample_rates[FDX_MAX_STAGES];
+  int upsample_kernel_sizes[FDX_MAX_STAGES];
+  int n_resblock_kernels;       /* 3 */
+  int resblock_kernel_sizes[FDX_MAX_RESK];
+  int n_dilations;              /* 3 for ResBlock1, 2 for ResBlock2 */
+  int resblock_dilations[FDX_MAX_RESK][FDX_MAX_DIL];
+  int resblock_type;            /* 1 | 2  (json "resblock") */
+  int sampling_rate;            /* 44100 */
+  int hop_size;                 /* prod(upsample_rates) */
+  int harmonic_num;             /* 8 (models.py:360) */
+} fdx_nsf_desc;
+
+/* Canonical order (weight-norm already folded, nsf_hifigan.py:51-52): m_source.l_linear.{weight,bias},
+ * conv_pre.{weight,bias}, then per stage i: ups.i.{weight,bias}, noise_convs.i.{weight,bias};
+ * then per resblock n (stage-major): ResBlock1: per j: convs1.j.{weight,bias}, convs2.j.{weight,bias};
+ * ResBlock2: per j: convs.j.{weight,bias}; finally conv_post.{weight,bias}.
+ * Conv1d [Cout][Cin][k]; ConvTranspose1d [Cin][Cout][k]. */
+int fdx_nsf_num_weights(const fdx_nsf_desc* d);
+int fdx_nsf_packed_bytes(const fdx_nsf_desc* d, size_t* bytes);
+int fdx_nsf_pack(const fdx_nsf_desc* d, const float* const* host_weights, int n_weights,
+                 void* host_packed, size_t bytes);
+int fdx_nsf_attach(fdx_handle h, const fdx_nsf_desc* d, const void* dev_packed, size_t bytes);
+/* mel: dev [B][num_mels][T]; f0: dev [B][T] (Hz, 0 = unvoiced); mel_scale: 2.30259 when the mel is
+ * log10 (nsf_hifigan.py:79-80) else 1.  rand_ini: dev [B][harmonic_num+1] in [0,1) (column 0 is forced
+ * to 0 as models.py:213) or NULL; src_noise: dev [B][T*hop][harmonic_num+1] standard normals or NULL;
+ * NULL => device Philox(seed).  wav: dev [B][T*hop]. */
+int fdx_nsf_forward(fdx_handle h, const float* mel, const float* f0, int B, int T, float mel_scale,
+                    const float* rand_ini, const float* src_noise, uint64_t seed, float* wav,
+                    fdx_stream s);
+/* Test hook: harmonic source only (models.py:411-416) -> har: dev [B][T*hop]. */
+int fdx_nsf_source(fdx_handle h, const float* f0, int B, int T, const float* rand_ini,
+                   const float* src_noise, uint64_t seed, float* har, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * STFT / mel -- replaces utils/pitch_adjustable_mel.py:33-96 (PitchAdjustableMelSpectrogram.__call__),
+ * utils/audio.py:11-18 (dynamic_range_compression) and the tail of NsfHifiGAN.wav2spec,
+ * nsf_hifigan.py:101-107.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int sample_rate; /* 44100 */
+  int n_fft;       /* 2048 */
+  int win_size;    /* 2048 */
+  int hop;         /* 512 */
+  int n_mels;      /* 128 */
+  float f_min;     /* 40 */
+  float f_max;     /* 16000 */
+} fdx_mel_desc;
+int fdx_mel_config(fdx_handle h, const fdx_mel_desc* d);
+/* number of frames the reference produces for N samples (center=False after the reflect pad). */
+int fdx_mel_num_frames(const fdx_mel_desc* d, int N, float key_shift, float speed, int* T);
+/* Pure host: the slaney mel filterbank [n_mels][1+n_fft/2] (librosa.filters.mel semantics). */
+int fdx_mel_filterbank(const fdx_mel_desc* d, float* host_out);
+enum { FDX_MEL_LINEAR = 0, FDX_MEL_LN = 1, FDX_MEL_LOG10 = 2 };
+/* wav: dev [B][N]; mel: dev [B][n_mels][T] with T = fdx_mel_num_frames(...). */
+int fdx_mel_forward(fdx_handle h, const float* wav, int B, int N, float key_shift, float speed,
+                    int log_mode, float* mel, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-level test / profiling hooks (used by tests/ and bench.py only)
+ * ---------------------------------------------------------------------------------------------- */
+/* y = conv1d(act_in(x), w) + bias with "same" zero padding: x dev [B][Cin][T], w HOST [Cout][Cin][k],
+ * bias HOST [Cout] or NULL, y dev [B][Cout][T].  in_slope: leaky-relu slope applied to x (1 = none).
+ * mode: 0 = 4-wave split-K tiles (denoiser regime), 1 = one tile per wave (vocoder regime). */
+int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, int T, const float* host_w,
+                     const float* host_bias, int Cout, int k, int dilation, float in_slope, int mode,
+                     float* y, fdx_stream s);
+/* Per-kernel timing: when enabled, every launch of the dominant kernel (the dilated-conv + gate
+ * kernel of the residual block) is bracketed by HIP events on its own stream.  fdx_prof_read returns
+ * the number of launches recorded and their total duration (synchronises those events). */
+int fdx_prof_enable(fdx_handle h, int on);
+int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISHDX_H_ */

@@ -1,0 +1,275 @@
+"""CPU: host-side logic of the product -- C-ABI surface, loud failure without a GPU, weight packing (checked by a
+numpy emulation of the MFMA kernel's lane-level index math), scalar sampler tables, filterbank, registry."""
+import ctypes as C
+import json
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import ROOT, WN_SMALL, emulate_convgemm, wavenet_sd
+
+
+@pytest.fixture(scope="module")
+def lib(lib_built):
+    from fish_diffusion_amd import _lib
+    return _lib
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    header = open(f"{ROOT}/include/fishdx.h").read()
+    declared = set(re.findall(r"\b(fdx_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fdx_ctx"}
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    l = lib.lib()
+    for name in declared:
+        assert hasattr(l, name)
+    assert l.fdx_version() >= 100
+
+
+def test_fails_loudly_without_gpu(lib):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.lib().fdx_create(0, C.byref(h))
+    assert rc == -3 and b"no HIP device" in lib.lib().fdx_last_error(None)
+    from fish_diffusion_amd import WaveNet
+    net = WaveNet(**WN_SMALL)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net(torch.zeros(1, 128, 8), torch.zeros(1), torch.zeros(1, 256, 8))
+
+
+def test_bad_configs_raise_like_the_reference(lib):
+    from fish_diffusion_amd import DENOISERS, DIFFUSIONS, GaussianDiffusion
+    with pytest.raises(ValueError):
+        DENOISERS.build(dict(type="WaveNetDenoiser", residual_channels=100))
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5], spec_max=None)
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5, -4], spec_max=[0, 0])
+    d = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5], spec_max=[0]))
+    assert d.noise_predictor == "unipc" and d.num_timesteps == 1000 and d.mel_bins == 128
+    d1 = GaussianDiffusion(dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5], spec_max=[0], sampler_interval=1)
+    assert d1.noise_predictor == "naive"
+    with pytest.raises(KeyError):
+        DENOISERS.build(dict(type="NoSuchDenoiser"))
+
+
+def test_state_dict_keys_match_reference_contract(lib):
+    from fish_diffusion_amd import GaussianDiffusion, WaveNet
+    from oracle import wavenet_ref
+    net = WaveNet(**WN_SMALL)
+    want = [k for k, _ in wavenet_ref.wavenet_param_shapes(128, 256, 64, 4, True)]
+    assert list(net.state_dict().keys()) == want
+    sd = wavenet_sd(WN_SMALL, 1)
+    assert net.load_state_dict(sd, strict=True)
+    d = GaussianDiffusion(dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5], spec_max=[0])
+    keys = set(d.state_dict().keys())
+    for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "spec_min", "spec_max",
+              "naive_noise_predictor.posterior_mean_coef1", "plms_noise_predictor.alphas_cumprod",
+              "denoise_fn.residual_layers.3.output_projection.conv.weight"):
+        assert k in keys, k
+    # no-bias variant (v1 arch)
+    assert "mlp.0.linear.bias" not in WaveNet(128, 256, 64, 2, use_linear_bias=False).state_dict()
+
+
+# ------------------------------------------------------------------ packing, via the numpy kernel emulation
+def _wn_offsets(C_, L, M, E):
+    """Mirror of wn_layout (fish_diffusion_amd/csrc/wavenet.hip): arena section offsets in floats."""
+    def plan(cur, rows, cin, taps, paired):
+        mt = (rows // 2 + 31) // 32 if paired else (rows + 63) // 64
+        w = mt * ((cin + 7) // 8) * taps * 2 * 64 * 4
+        return dict(w=cur, b=cur + w, mt=mt, cin8=(cin + 7) // 8, taps=taps), cur + w + (rows + 63) // 64 * 64
+    cur, out = 0, {}
+    for name, rows, cin in (("in_proj", C_, M), ("mlp0", 4 * C_, C_), ("mlp2", C_, 4 * C_), ("dproj", L * C_, C_), ("cond", L * 2 * C_, E)):
+        out[name], cur = plan(cur, rows, cin, 1, False)
+    for i in range(L):
+        out[f"conv{i}"], cur = plan(cur, 2 * C_, C_, 3, True)
+        out[f"outp{i}"], cur = plan(cur, 2 * C_, C_, 1, False)
+    out["skip_proj"], cur = plan(cur, C_, C_, 1, False)
+    out["out_proj"], cur = plan(cur, M, C_, 1, False)
+    out["total"] = cur
+    return out
+
+
+def test_wavenet_packing_matches_kernel_index_math(lib):
+    from fish_diffusion_amd import WaveNet
+    net = WaveNet(**WN_SMALL)
+    sd = wavenet_sd(WN_SMALL, 3)
+    net.load_state_dict(sd)
+    arena = lib.pack_on_host(net._desc, net._params(), "wavenet")
+    off = _wn_offsets(64, 4, 128, 256)
+    assert arena.size == off["total"]
+    T, halo = 40, 32
+    ld = halo + 64 + halo
+    g = torch.Generator().manual_seed(0)
+    # ---- paired dilated conv of layer 1 (dilation 2): gate rows in rb 0, filter rows in rb 1
+    y = torch.randn(64, T, generator=g)
+    X = np.zeros((64, ld), np.float32)
+    X[:, halo:halo + T] = y.numpy()
+    o = off["conv1"]
+    acc = emulate_convgemm(arena[o["w"]:o["b"]], X, n_mtiles=o["mt"], RB=2, cin8=o["cin8"], taps=3, shift0=-2, dshift=2, T=T)
+    ref = F.conv1d(y[None], sd["residual_layers.1.conv_layer.conv.weight"], None, padding=2, dilation=2)[0].numpy()
+    for mt in range(o["mt"]):
+        np.testing.assert_allclose(acc[(mt, 0)], ref[mt * 32:mt * 32 + 32], rtol=1e-4, atol=1e-5)          # gate
+        np.testing.assert_allclose(acc[(mt, 1)], ref[64 + mt * 32:64 + mt * 32 + 32], rtol=1e-4, atol=1e-5)  # filter
+    # ---- concatenated diffusion projection: row l*C + c
+    s = torch.randn(64, 5, generator=g)
+    X = np.zeros((64, ld), np.float32)
+    X[:, halo:halo + 5] = s.numpy()
+    o = off["dproj"]
+    acc = emulate_convgemm(arena[o["w"]:o["b"]], X, n_mtiles=o["mt"], RB=2, cin8=o["cin8"], taps=1, shift0=0, dshift=0, T=5)
+    got = np.concatenate([np.concatenate([acc[(mt, 0)], acc[(mt, 1)]]) for mt in range(o["mt"])])
+    ref = torch.cat([sd[f"residual_layers.{i}.diffusion_projection.linear.weight"] @ s for i in range(4)]).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+    bias = arena[o["b"]:o["b"] + 256]
+    np.testing.assert_array_equal(bias, torch.cat([sd[f"residual_layers.{i}.diffusion_projection.linear.bias"] for i in range(4)]).numpy())
+    # ---- conditioner slab bias absorbs the conv bias
+    o = off["cond"]
+    want = torch.cat([sd[f"residual_layers.{i}.conditioner_projection.conv.bias"] + sd[f"residual_layers.{i}.conv_layer.conv.bias"]
+                      for i in range(4)]).numpy()
+    np.testing.assert_allclose(arena[o["b"]:o["b"] + 512], want, rtol=0, atol=1e-7)
+
+
+def test_polyphase_transposed_conv_packing(lib):
+    """ups.0 of a tiny generator, emulated, equals F.conv_transpose1d (k=16,u=8,p=4 and k=8,u=2,p=3 geometries)."""
+    from fish_diffusion_amd.nsf_hifigan import Generator
+    from oracle import nsf_hifigan_ref
+    h = dict(nsf_hifigan_ref.CONFIG_V1, upsample_initial_channel=64, upsample_rates=[8, 2], upsample_kernel_sizes=[16, 8],
+             hop_size=16, resblock_kernel_sizes=[3], resblock_dilation_sizes=[[1, 3, 5]])
+    gen = Generator(h)
+    sd = nsf_hifigan_ref.seeded_generator_state(9, h)
+    gen.load_folded_state(sd)
+    arena = lib.pack_on_host(gen._desc, gen.folded_weights(), "nsf")
+    cur = 64 + 64  # src_w, src_b
+    cur += 1 * (128 // 8) * 7 * 2 * 64 * 4 + 64  # conv_pre: rows 64 -> 1 m-tile (RB 2), cin8 16, taps 7; bias 64
+    T, halo = 12, 32
+    g = torch.Generator().manual_seed(1)
+    for i, (cin, cout, k, u, taps, dhi) in enumerate([(64, 32, 16, 8, 3, 1), (32, 16, 8, 2, 5, 2)]):
+        rows = u * cout
+        RB = 1 if rows <= 32 else 2
+        mt = (rows + 32 * RB - 1) // (32 * RB)
+        wfl = mt * (cin // 8) * taps * RB * 64 * 4
+        x = torch.randn(cin, T, generator=g)
+        X = np.zeros((cin, halo + 64 + halo), np.float32)
+        X[:, halo:halo + T] = x.numpy()
+        acc = emulate_convgemm(arena[cur:cur + wfl], X, n_mtiles=mt, RB=RB, cin8=cin // 8, taps=taps, shift0=-dhi, dshift=1, T=T)
+        ref = F.conv_transpose1d(x[None], sd[f"ups.{i}.weight"], None, stride=u, padding=(k - u) // 2)[0].numpy()
+        got = np.zeros_like(ref)
+        for m in range(mt):
+            for rb in range(RB):
+                blk = acc[(m, rb)]
+                for r in range(32):
+                    row = m * 32 * RB + rb * 32 + r
+                    if row < rows:
+                        got[row % cout, (row // cout)::u] = blk[r]
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+        nk = 2 * 2 if i == 0 else 1
+        cur += wfl + (rows + 63) // 64 * 64 + (cout * nk + 63) // 64 * 64 + (cout + 63) // 64 * 64
+
+
+# ------------------------------------------------------------------ scalar tables
+@pytest.mark.parametrize("interval", [50, 10])
+def test_unipc_table_matches_oracle_arithmetic(interval):
+    """Drive the oracle UniPC with a linear 'denoiser' and replay it from the table: identical x_0."""
+    from fish_diffusion_amd import schedule
+    from oracle import sampler_ref
+    betas = sampler_ref.beta_schedule()
+    steps = 1000 // interval
+    kind, tab = schedule.sampler_table("unipc", interval=interval)
+    assert tab.shape == (steps + 1, 16) and kind == 1
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 6, generator=g)
+    W = torch.randn(4, 4, generator=g) * 0.3
+
+    def eps_model(x, t):
+        return torch.einsum("ij,bjt->bit", W, x) * (1 + 1e-3 * t.view(-1, 1, 1))
+    want = sampler_ref.unipc_sample(eps_model, x0, betas, steps)
+    # replay with the table (same formulas as the device kernels)
+    x = x0.clone()
+    def model(xx, row):
+        return eps_model(xx, torch.tensor([row[0]]))
+    r0 = tab[0]
+    m0 = (x - r0[1] * model(x, r0)) / r0[2]
+    m1 = None
+    for r in range(1, steps + 1):
+        t_in, sig, al, c_x, c_m, aB, rk, order, corr, rho0, rho1 = [torch.tensor(v) for v in tab[r, :11]]
+        xb = c_x * x - c_m * m0
+        xt = xb - aB * (0.5 * ((m1 - m0) / rk)) if order == 2 else xb
+        if corr:
+            mt = (xt - sig * model(xt, tab[r])) / al
+            c = rho0 * ((m1 - m0) / rk) + rho1 * (mt - m0) if order == 2 else rho1 * (mt - m0)
+            x = xb - aB * c
+            m1, m0 = m0, mt
+        else:
+            x = xt
+    assert torch.equal(x, want)
+
+
+def test_naive_and_plms_tables():
+    from fish_diffusion_amd import schedule
+    from oracle import sampler_ref
+    betas = sampler_ref.beta_schedule()
+    kind, tab = schedule.sampler_table("naive", interval=50, skip_steps=400)
+    chunks = schedule.timestep_chunks(1000, 400, 50)
+    assert kind == 0 and [int(t) for t in tab[:, 0]] == chunks == list(range(0, 600, 50))[::-1]
+    tb = sampler_ref.NaiveTables(betas)
+    x, e, n = torch.randn(3), torch.randn(3), torch.randn(3)
+    for r, t in enumerate(chunks):
+        _, sr, srm1, c1, c2, sc = [torch.tensor(v) for v in tab[r, :6]]
+        got = c1 * torch.clamp(sr * x - srm1 * e, -1, 1) + c2 * x + sc * n
+        assert torch.equal(got, sampler_ref.naive_step(tb, x, t, e, n))
+    kind, tab = schedule.sampler_table("plms", interval=100)
+    ac = sampler_ref.f32(np.cumprod(1.0 - betas))
+    for r, t in enumerate(schedule.timestep_chunks(1000, 0, 100)):
+        _, tp, A, P, Q = [torch.tensor(v) for v in tab[r, :5]]
+        assert int(tp) == max(t - 100, 0)
+        assert torch.equal(x + A * (P * x - Q * e), sampler_ref.plms_x_pred(ac, x, e, t, int(tp)))
+    with pytest.raises(NotImplementedError):
+        schedule.sampler_table("euler")
+    with pytest.raises(NotImplementedError):
+        schedule.make_betas("sigmoid")
+    assert np.array_equal(schedule.make_betas("cosine"), sampler_ref.beta_schedule("cosine"))
+
+
+def test_mel_filterbank_and_frame_count(lib):
+    from fish_diffusion_amd import PitchAdjustableMelSpectrogram
+    from oracle import mel_ref
+    m = PitchAdjustableMelSpectrogram()
+    fb = m.filterbank().numpy()
+    ref = mel_ref.slaney_mel_filterbank(sr=44100, n_fft=2048, n_mels=128, fmin=40, fmax=16000)
+    np.testing.assert_allclose(fb, ref, rtol=2e-6, atol=1e-9)
+    for ks, sp, n in ((0, 1.0, 44100), (3, 1.0, 44100), (-5, 1.0, 30000), (12, 1.0, 44100), (0, 1.5, 44100), (0, 1.0, 441000)):
+        n_fft, win, hop, pad = mel_ref.stft_geometry(2048, 2048, 512, ks, sp)
+        want = 1 + (n + 2 * pad - n_fft) // hop
+        assert m.num_frames(n, ks, sp) == want
+    with pytest.raises(ValueError):
+        m.num_frames(100)
+
+
+def test_generator_checkpoint_contract(lib, tmp_path):
+    """Reference checkpoints are in weight-norm form under `generator.*` or {"generator": sd} (nsf_hifigan.py:38-52)."""
+    from fish_diffusion_amd import NsfHifiGAN
+    from fish_diffusion_amd.nsf_hifigan import Generator, generator_param_table
+    from oracle import nsf_hifigan_ref
+    h = dict(nsf_hifigan_ref.CONFIG_V1, upsample_initial_channel=256)
+    gen = Generator(h)
+    keys = set(gen.state_dict().keys())
+    assert "conv_pre.weight_g" in keys and "ups.0.weight_v" in keys and "resblocks.14.convs2.2.weight_g" in keys
+    assert "noise_convs.0.weight" in keys and "m_source.l_linear.weight" in keys and "conv_post.weight_g" in keys
+    sd = {k: v.clone() for k, v in gen.state_dict().items()}
+    (tmp_path / "config.json").write_text(json.dumps(h))
+    torch.save({"generator": sd}, tmp_path / "model")
+    voc = NsfHifiGAN(str(tmp_path / "model"), sampling_rate=44100, mel_channels=128)
+    assert "conv_pre.weight" in voc.model.state_dict() and "conv_pre.weight_g" not in voc.model.state_dict()
+    folded = nsf_hifigan_ref.fold_weight_norm(sd)
+    for (key, _, _), w in zip(generator_param_table(h), voc.model.folded_weights()):
+        assert torch.allclose(w, folded[key], atol=1e-7), key
+    torch.save({"state_dict": {"generator." + k: v for k, v in sd.items()}}, tmp_path / "model2")
+    NsfHifiGAN(str(tmp_path / "model2"), config_file=str(tmp_path / "config.json"))
+    with pytest.raises(ValueError, match="Incorrect value"):
+        NsfHifiGAN(str(tmp_path / "model"), sampling_rate=48000)
+    voc.freeze()
+    assert not any(p.requires_grad for p in voc.parameters())

@@ -1,0 +1,100 @@
+"""CPU: the oracle restatement reproduces the golden vectors generated from the REAL reference
+(oracle/make_golden.py).  Tolerances are a few ulps: a different host CPU may pick different MKL-DNN kernels."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mel_ref, nsf_hifigan_ref, sampler_ref, wavenet_ref
+from tests.helpers import WN_FULL, WN_SMALL, load, rel_err, abs_err, sha1_state, wavenet_sd
+
+torch.set_num_threads(8)
+
+
+def _den(sd, cfg):
+    return lambda x, t, c, xm, cm: wavenet_ref.wavenet_forward(sd, x, t, c, xm, cm, residual_layers=cfg["residual_layers"],
+                                                               dilation_cycle=cfg["dilation_cycle"])
+
+
+@pytest.mark.parametrize("tag,cfg", [("small", WN_SMALL), ("full", WN_FULL)])
+def test_wavenet_oracle_matches_reference(tag, cfg):
+    g = load(f"wavenet_{tag}")
+    sd = wavenet_sd(cfg, int(g["seed"]))
+    assert sha1_state(sd) == str(g["weights_sha1"]), "seeded weights drifted (torch RNG changed?)"
+    if tag == "small":
+        for k, v in sd.items():
+            assert torch.equal(v, g["w:" + k])
+    with torch.no_grad():
+        eps = _den(sd, cfg)(g["x"], g["t"], g["cond"], None, None)
+        eps_m = _den(sd, cfg)(g["x"], g["t"], g["cond"], g["masks"].bool(), g["masks"].bool())
+        eps_l = _den(sd, cfg)(g["x"], torch.tensor([400]), g["cond"], None, None)
+    assert rel_err(eps, g["eps"]) < 1e-5
+    assert rel_err(eps_m, g["eps_masked"]) < 1e-5
+    assert rel_err(eps_l, g["eps_long"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["unipc_i50_s0", "unipc_i10_s0", "plms_i50_s0", "naive_i50_s0", "unipc_i100_s400",
+                                  "plms_i100_s400"])
+def test_sampler_oracle_matches_reference(name):
+    g = load(f"sampler_small_{name}")
+    sd = wavenet_sd(WN_SMALL, 101)
+    pred = name.split("_")[0]
+    with torch.no_grad():
+        mel = sampler_ref.diffusion_sample(_den(sd, WN_SMALL), g["features"], x_init=g["x_init"], sampler_interval=int(g["interval"]),
+                                           predictor=pred, step_noise=g["step_noise"], skip_steps=int(g["skip"]),
+                                           x_masks=g["masks"].bool(), cond_masks=g["masks"].bool())
+    assert rel_err(mel, g["mel"]) < 1e-4
+
+
+def test_sampler_oracle_c1_full_net():
+    """BASELINE configs[0]: 5 s utterance, 20-step UniPC, full-size WaveNet, CPU."""
+    g = load("sampler_full_c1")
+    sd = wavenet_sd(WN_FULL, int(g["seed"]))
+    assert sha1_state(sd) == str(g["weights_sha1"])
+    with torch.no_grad():
+        mel = sampler_ref.diffusion_sample(_den(sd, WN_FULL), g["features"], x_init=g["x_init"], sampler_interval=int(g["interval"]))
+    assert rel_err(mel, g["mel"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["v1_small", "v1_256_small"])
+def test_generator_oracle_matches_reference(tag):
+    g = load(f"nsf_{tag}")
+    h = json.loads(str(g["config"]))
+    sd = nsf_hifigan_ref.seeded_generator_state(int(g["seed"]), h)
+    assert sha1_state(sd) == str(g["weights_sha1"])
+    taps = {}
+    with torch.no_grad():
+        wav = nsf_hifigan_ref.generator_forward(sd, h, g["mel"], g["f0"], g["rand_ini"], g["src_noise"], taps)
+    assert abs_err(wav, g["wav"]) < 1e-5
+    assert abs_err(taps["har_source"], g["har_source"]) < 1e-5
+
+
+def test_fold_weight_norm():
+    v = torch.randn(6, 4, 3)
+    gg = torch.rand(6, 1, 1) + 0.5
+    out = nsf_hifigan_ref.fold_weight_norm({"c.weight_g": gg, "c.weight_v": v, "c.bias": torch.zeros(6)})
+    ref = torch._weight_norm(v, gg, 0)
+    assert torch.allclose(out["c.weight"], ref, atol=1e-6) and "c.bias" in out
+
+
+def test_mel_oracle_matches_reference():
+    g = load("mel")
+    for key in [k for k in g if k.startswith("mel_ks")]:
+        ks, sp = key[len("mel_ks"):].split("_sp")
+        out = mel_ref.mel_spectrogram(g["wav"], key_shift=float(ks), speed=float(sp))
+        assert rel_err(out, g[key]) < 1e-5, key
+    assert rel_err(mel_ref.wav2spec(g["wav"], use_natural_log=False), g["logmel_log10"]) < 1e-5
+
+
+def test_discrete_vp_interpolation_properties():
+    ns = sampler_ref.DiscreteVP(sampler_ref.beta_schedule())
+    knots = ns.t_knots
+    # at the knots the interpolant returns the table itself (to 1 ulp); between knots it is monotone decreasing
+    assert torch.allclose(ns.log_mean_coeff(knots), ns.log_alpha, rtol=0, atol=2e-7)
+    ts = torch.linspace(1e-3, 1.0, 4001)
+    la = ns.log_mean_coeff(ts)
+    assert (la[1:] <= la[:-1] + 1e-9).all()
+    # extrapolation below the first knot is linear
+    below = ns.log_mean_coeff(torch.tensor([0.0005]))
+    assert below > ns.log_alpha[0]
