@@ -81,7 +81,7 @@ def seeded_modules(device, seed=1234):
     g = torch.Generator().manual_seed(seed + 1)
     state = {}
     for key, shape, _ in generator_param_table(NSF_V1):
-        if key.endswith("bias"):
+        if key.endswith("bias") or len(shape) < 3:
             state[key] = torch.randn(shape, generator=g) * 0.01
         else:
             fan_in = shape[1] * shape[2] if "ups." not in key else shape[0] * shape[2] / max(1, NSF_V1["upsample_rates"][int(key.split(".")[1])])
@@ -105,12 +105,25 @@ def one_step(diff, voc, feats, f0, interval):
     return wav
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box is a
+    256-thread EPYC with a 16-CPU quota: 256 torch threads there oversubscribe 16x and run ~5x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(diff, voc, T, seconds, n_steps, sample_steps):
     """The oracle (restatement of the reference PyTorch path, same torch CPU ops) on this box's host cores.
     Bounded sample: `sample_steps` of the `n_steps` UniPC steps at full length + the full vocoder pass; the rest of
     the sampler is extrapolated linearly (every step is the same denoiser call)."""
     from oracle import nsf_hifigan_ref, sampler_ref, wavenet_ref
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in diff.denoise_fn.state_dict().items()}
     gsd = {k: v.detach().cpu() for k, v in voc.model.state_dict().items()}

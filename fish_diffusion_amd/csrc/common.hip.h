@@ -91,7 +91,8 @@ struct fdx_ctx {
   const float* wn_arena = nullptr;
   int B = 0, T = 0, ld = 0;            // prepared geometry
   bool prepared = false;
-  fdx::DevBuf xin, X, Y, Z, SK, H, EPS, P, condp;
+  fdx::DevBuf xin, X, Y, Z, SK, H, EPS, P, condp, condraw, P2;
+  bool cond_masked = false; int condraw_ld = 0;
   fdx::DevBuf tdev, E, Hm, S0, S;      // step-embedding pipeline; ldn below
   int n_emb = 0, ldn = 0;
   // ---- sampler state (padded [B][M][ld])

@@ -192,6 +192,15 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   return FDX_OK;
 }
 
+// P[b][l*2C + r][t] = Wc_l[r] . cond[b][:, t] + bc_l[r] + bconv_l[r]   -- all layers in one GEMM (wavenet.py:108,112)
+static int wn_cond_slab(fdx_ctx* h, const float* condp, float* P, hipStream_t s) {
+  const auto& d = h->wd;
+  const int C = d.residual_channels, L = d.residual_layers, E = d.d_encoder, ld = h->ld;
+  EpiBias e = epi_bias(P + kHalo, (long)L * 2 * C * ld, ld, h->wn_arena + h->wl.cond.b_off, L * 2 * C, ACT_NONE);
+  FDX_HIP(h, (run_gemm<true, false>(h->wn_arena, h->wl.cond, h->B, h->T, condp + kHalo, (long)E * ld, ld, 0, 0, 1.f, e, s)));
+  return FDX_OK;
+}
+
 extern "C" int fdx_wavenet_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask, fdx_stream st) {
   if (!h) return FDX_E_ARG;
   if (!h->wn_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_prepare: no weights attached");
@@ -200,13 +209,20 @@ extern "C" int fdx_wavenet_prepare(fdx_handle h, const float* cond, int B, int T
   FDX_HIP(h, hipSetDevice(h->device));
   if (int rc = wn_alloc(h, B, T, s)) return rc;
   const auto& d = h->wd;
-  const int C = d.residual_channels, L = d.residual_layers, E = d.d_encoder, ld = h->ld;
+  const int E = d.d_encoder, ld = h->ld;
   // conditioner.masked_fill(cond_masks) (wavenet.py:220-221) while staging into the padded layout
   hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, h->condp.f() + kHalo, (long)E * ld, ld, cond,
                      (long)E * T, T, E, T, 1.f, cond_mask);
-  // P[b][l*2C + r][t] = Wc_l[r] . cond[b][:, t] + bc_l[r] + bconv_l[r]   -- all layers in one GEMM
-  EpiBias e = epi_bias(h->P.f() + kHalo, (long)L * 2 * C * ld, ld, h->wn_arena + h->wl.cond.b_off, L * 2 * C, ACT_NONE);
-  FDX_HIP(h, (run_gemm<true, false>(h->wn_arena, h->wl.cond, B, T, h->condp.f() + kHalo, (long)E * ld, ld, 0, 0, 1.f, e, s)));
+  if (int rc = wn_cond_slab(h, h->condp.f(), h->P.f(), s)) return rc;
+  // PLMS evaluates the denoiser once WITHOUT masks (diffusion.py:285): keep the unmasked conditioner for that call
+  h->cond_masked = cond_mask != nullptr;
+  if (h->cond_masked) {
+    const bool geom = h->condraw.cap < (size_t)B * E * ld * sizeof(float) || h->condraw_ld != ld;
+    FDX_HIP(h, h->condraw.ensure((size_t)B * E * ld * sizeof(float), geom, s));
+    h->condraw_ld = ld;
+    hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, h->condraw.f() + kHalo, (long)E * ld, ld, cond,
+                       (long)E * T, T, E, T, 1.f, (const uint8_t*)nullptr);
+  }
   h->prepared = true;
   return FDX_OK;
 }
@@ -238,7 +254,7 @@ static int wn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s) {
 // xin: padded [B][M][ld] (valid data at +kHalo).  Step projections are read from column `col0 + b*sb_bs` of S.
 // eps_out: [B][M] rows with pitch ldo / item stride o_bs (padded EPS buffer or the caller's tensor).
 static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out,
-                           long o_bs, int ldo, hipStream_t s) {
+                           long o_bs, int ldo, hipStream_t s, const float* Pslab = nullptr) {
   const auto& d = h->wd;
   const auto& l = h->wl;
   const int C = d.residual_channels, L = d.residual_layers, M = d.mel_channels;
@@ -260,7 +276,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     const int dil = l.dil[i];
     EpiGate g{};
     g.out = Z; g.o_bs = bsC; g.ldo = ld;
-    g.P = h->P.f() + kHalo + (size_t)i * 2 * C * ld; g.p_bs = (long)L * 2 * C * ld; g.ldp = ld; g.C = C;
+    g.P = (Pslab ? Pslab : h->P.f()) + kHalo + (size_t)i * 2 * C * ld; g.p_bs = (long)L * 2 * C * ld; g.ldp = ld; g.C = C;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (h->prof.on) {
       auto& pe = h->prof;
@@ -353,7 +369,15 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   float* eps = h->EPS.f() + kHalo;
   hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, sx, bs, ld, x, (long)M * T, T, M, T, 1.f, (const uint8_t*)nullptr);
   auto model = [&](const float* xin, int col, bool masked) {
-    return wn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s);
+    const float* P = nullptr;
+    if (!masked && h->cond_masked) {   // the one unmasked call of PLMS: conditioner slab of the unmasked conditioner
+      const auto& d = h->wd;
+      if (h->P2.ensure((size_t)B * d.residual_layers * 2 * d.residual_channels * ld * sizeof(float), false, s) != hipSuccess)
+        return fail(h, FDX_E_NOMEM, "out of device memory for the unmasked conditioner slab");
+      if (int rc = wn_cond_slab(h, h->condraw.f(), h->P2.f(), s)) return rc;
+      P = h->P2.f();
+    }
+    return wn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, P);
   };
 
   if (kind == FDX_SAMPLER_UNIPC) {
