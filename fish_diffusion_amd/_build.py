@@ -34,6 +34,16 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def build_trace(verbose: bool = True) -> str:
+    """Instrumented build (tools/ktrace.py): libfishdx_trace.so with -DFDX_KTRACE, one shot, no object cache."""
+    out = os.path.join(CSRC, "libfishdx_trace.so")
+    cmd = [_hipcc(), *FLAGS, "-DFDX_KTRACE", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -60,4 +70,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_trace() if "--trace" in sys.argv else build(force="--force" in sys.argv))

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfishdx.so")
+LIB_PATH = os.environ.get("FDX_LIB_PATH") or os.path.join(_HERE, "csrc", "libfishdx.so")  # env override: trace build
 
 FDX_ROW = 16
 SAMPLER_NAIVE, SAMPLER_UNIPC, SAMPLER_PLMS = 0, 1, 2

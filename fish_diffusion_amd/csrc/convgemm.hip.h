@@ -44,11 +44,41 @@ struct ConvArgs {
   int n_tiles_n;                  // B * tiles_per_item
   int n_mtiles;
   float in_slope;                 // leaky-relu slope applied to the B operand (LRELU instantiations)
+#ifdef FDX_KTRACE
+  unsigned long long* trace;      // [block][wave][8] shader-clock stamps of this launch, or null (tools/ktrace.py)
+#endif
 };
 
+#ifdef FDX_KTRACE
+#define FDX_STAMP(k) do { if (a.trace && lane == 0) a.trace[((long)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+struct TraceState { unsigned long long* buf = nullptr; int max_launches = 0, n = 0, blocks_cap = 0; };
+inline TraceState g_trace;
+#else
+#define FDX_STAMP(k) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------ epilogues
-// Each epilogue sees (item b, logical row, column t, value).  `kPaired` epilogues get the values of row
-// and row + "pair distance" (same lane, accumulators rb=0 / rb=1): gate/filter, re/im.
+// Column mapping: lane li of MFMA column block nb (0/1) owns output column t0 + 2*li + nb, i.e. every lane owns an
+// ADJACENT column pair (t, t+1), t even.  B operands are fetched as 8-byte pairs and every epilogue moves pairs.
+//
+// An epilogue has two halves so that its global reads can be issued BEFORE the K loop and land behind it:
+//   Pre  load (b, row, t, two)               -- global loads only (conditioner slab, residual, skip, bias ...)
+//   void store(b, row, t, two, v[, w], pre)  -- arithmetic + stores.  `two` = column t+1 is valid too.
+// `kPaired` epilogues get the values of row and row + "pair distance" (accumulators rb=0 / rb=1): gate/filter, re/im.
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };   // dword-aligned pair: global ld/st at any even/odd float
+
+// pair loads are unconditional: every source read this way is one of the library's own padded rows (>= kHalo floats of
+// slack right of column T-1), never a caller tensor.
+__device__ __forceinline__ f2 ld2(const float* p, bool /*two*/) {
+  const f2u v = *reinterpret_cast<const f2u*>(p);
+  return f2{v.x, v.y};
+}
+__device__ __forceinline__ void st2(float* p, f2 v, bool two) {
+  if (two) { f2u u; u.x = v.x; u.y = v.y; *reinterpret_cast<f2u*>(p) = u; }
+  else p[0] = v.x;
+}
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2 };
 
@@ -66,14 +96,27 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
   const uint8_t* mask; int mask_ld;   // [B][mask_ld] bytes, 1 = masked
   float* out2; long o2_bs; int ldo2;  // optional second output
   const float* sb; int sb_ld, sb_bs;  // out2 = v + sb[row*sb_ld + b*sb_bs]
-  __device__ __forceinline__ void operator()(int b, int row, int t, float v) const {
-    if (row >= M) return;
-    if (bias) v += bias[row];
+  struct Pre { float bias, sb; bool m0, m1; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p{0.f, 0.f, false, false};
+    if (row >= M) return p;
+    if (bias) p.bias = bias[row];
+    if (out2) p.sb = sb[(long)row * sb_ld + b * sb_bs];
+    if (mask) { p.m0 = mask[(long)b * mask_ld + t] != 0; p.m1 = two && mask[(long)b * mask_ld + t + 1] != 0; }
+    return p;
+  }
+  __device__ __forceinline__ float act1(float v, float bv, bool masked) const {
+    if (bias) v += bv;
     if (act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (act == ACT_MISH) v = mish_f(v);
-    if (mask && mask[(long)b * mask_ld + t]) v = 0.f;
-    out[b * o_bs + (long)row * ldo + t] = v;
-    if (out2) out2[b * o2_bs + (long)row * ldo2 + t] = v + sb[(long)row * sb_ld + b * sb_bs];
+    return masked ? 0.f : v;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
+    if (row >= M) return;
+    v.x = act1(v.x, p.bias, p.m0);
+    v.y = act1(v.y, p.bias, p.m1);
+    st2(out + b * o_bs + (long)row * ldo + t, v, two);
+    if (out2) st2(out2 + b * o2_bs + (long)row * ldo2 + t, f2{v.x + p.sb, v.y + p.sb}, two);
   }
 };
 
@@ -82,13 +125,32 @@ struct EpiGate {  // wavenet.py:112-115: y = conv + conditioner (bias folded int
   float* out; long o_bs; int ldo;
   const float* P; long p_bs; int ldp;  // [B][2C][ldp]: conditioner slab (+ conv bias + conditioner bias)
   int C;
-  __device__ __forceinline__ void operator()(int b, int row, int t, float g, float f) const {
+  struct Pre { f2 pg, pf; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p{f2{0.f, 0.f}, f2{0.f, 0.f}};
+    if (row >= C) return p;
+    const float* q = P + b * p_bs + t;
+    p.pg = ld2(q + (long)row * ldp, two);
+    p.pf = ld2(q + (long)(row + C) * ldp, two);
+    return p;
+  }
+  // sigmoid(g) * tanh(f) on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each):
+  //   sigmoid(g) = 1 / (1 + e^-g),  tanh(f) = 1 - 2 / (e^2f + 1)  (saturates cleanly: e^2f = inf -> 1, 0 -> -1).
+  // Absolute error ~1e-7 on a value in [-1, 1] -- fp32 round-off class, two orders below what the reference's own
+  // CPU backends differ by; the end-to-end parity tests (1e-3 rel on mel after 100 steps) hold it.
+  // Near 0 the exp form of tanh loses RELATIVE accuracy (1 - (1 - f)), so |f| < 0.15 takes the odd Taylor polynomial
+  // f (1 - f^2/3 + 2f^4/15 - 17f^6/315)  (next term 62/2835 f^8 < 6e-9 there); both are evaluated, one is selected.
+  __device__ __forceinline__ static float gate1(float g, float f) {
+    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-g));
+    const float th_e = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * f) + 1.f);
+    const float f2_ = f * f;
+    const float th_p = f * (1.f + f2_ * (-0.33333334f + f2_ * (0.13333334f + f2_ * -0.053968254f)));
+    return sg * (fabsf(f) < 0.15f ? th_p : th_e);
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 g, f2 f, const Pre& p) const {
     if (row >= C) return;
-    const float* p = P + b * p_bs + t;
-    g += p[(long)row * ldp];
-    f += p[(long)(row + C) * ldp];
-    float sg = 1.f / (1.f + expf(-g));
-    out[b * o_bs + (long)row * ldo + t] = sg * tanhf(f);
+    g += p.pg; f += p.pf;
+    st2(out + b * o_bs + (long)row * ldo + t, f2{gate1(g.x, f.x), gate1(g.y, f.y)}, two);
   }
 };
 
@@ -99,20 +161,33 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
   const float* sb; int sb_ld, sb_bs;                  // next layer's diffusion projection, [C][sb_ld]
   int C, skip_mode;                                   // 0 first (=), 1 middle (+=), 2 last ((+=)/sqrt(L)); 3 = first and last
   float inv_div;                                      // sqrt(n_layers)
-  __device__ __forceinline__ void operator()(int b, int row, int t, float v) const {
-    if (row >= 2 * C) return;
-    v += bias[row];
+  struct Pre { f2 old; float bias, sb; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p{f2{0.f, 0.f}, 0.f, 0.f};
+    if (row >= 2 * C) return p;
+    p.bias = bias[row];
     if (row < C) {
-      long o = b * bs + (long)row * ld + t;
-      float xn = (X[o] + v) / 1.41421356237309504880f;
-      X[o] = xn;
-      if (Y) Y[o] = xn + sb[(long)row * sb_ld + b * sb_bs];
+      p.old = ld2(X + b * bs + (long)row * ld + t, two);
+      if (Y) p.sb = sb[(long)row * sb_ld + b * sb_bs];
+    } else if (skip_mode == 1 || skip_mode == 2) {
+      p.old = ld2(SK + b * bs + (long)(row - C) * ld + t, two);
+    }
+    return p;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
+    if (row >= 2 * C) return;
+    v += p.bias;
+    if (row < C) {
+      const long o = b * bs + (long)row * ld + t;
+      const f2 xn = (p.old + v) / 1.41421356237309504880f;
+      st2(X + o, xn, two);
+      if (Y) st2(Y + o, xn + p.sb, two);
     } else {
-      long o = b * bs + (long)(row - C) * ld + t;
-      float s = v;
-      if (skip_mode == 1 || skip_mode == 2) s = SK[o] + v;
+      const long o = b * bs + (long)(row - C) * ld + t;
+      f2 s = v;
+      if (skip_mode == 1 || skip_mode == 2) s = p.old + v;
       if (skip_mode >= 2) s = s / inv_div;
-      SK[o] = s;
+      st2(SK + o, s, two);
     }
   }
 };
@@ -123,14 +198,23 @@ struct EpiResblock {  // models.py:103-110 conv2: x = xt + x; plus the MRF mean 
   const float* bias; int M;
   int mode;     // 0: out = v    1: out += v    2: out = (out + v) / div
   float div;
-  __device__ __forceinline__ void operator()(int b, int row, int t, float v) const {
+  struct Pre { f2 res, old; float bias; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p{f2{0.f, 0.f}, f2{0.f, 0.f}, 0.f};
+    if (row >= M) return p;
+    const long o = b * bs + (long)row * ld + t;
+    p.bias = bias[row];
+    if (resid) p.res = ld2(resid + o, two);
+    if (mode != 0) p.old = ld2(out + o, two);
+    return p;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
     if (row >= M) return;
-    long o = b * bs + (long)row * ld + t;
-    v += bias[row];
-    if (resid) v += resid[o];
-    if (mode == 1) v = out[o] + v;
-    else if (mode == 2) v = (out[o] + v) / div;
-    out[o] = v;
+    v += p.bias;
+    if (resid) v += p.res;
+    if (mode == 1) v = p.old + v;
+    else if (mode == 2) v = (p.old + v) / div;
+    st2(out + b * bs + (long)row * ld + t, v, two);
   }
 };
 
@@ -138,13 +222,19 @@ struct EpiUps {  // polyphase ConvTranspose1d (models.py:421): logical row = pha
   static constexpr bool kPaired = false;
   float* out; long o_bs; int ldo;
   const float* bias; int Cout, stride, Lout;
-  __device__ __forceinline__ void operator()(int b, int row, int t, float v) const {
-    int ph = row / Cout;
+  struct Pre { float bias; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    const int ph = row / Cout;
+    return Pre{ph < stride ? bias[row - ph * Cout] : 0.f};
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
+    const int ph = row / Cout;
     if (ph >= stride) return;
-    int co = row - ph * Cout;
-    int n = t * stride + ph;
-    if (n >= Lout) return;
-    out[b * o_bs + (long)co * ldo + n] = v + bias[co];
+    const int co = row - ph * Cout;
+    float* o = out + b * o_bs + (long)co * ldo;
+    const int n = t * stride + ph;
+    if (n < Lout) o[n] = v.x + p.bias;
+    if (two && n + stride < Lout) o[n + stride] = v.y + p.bias;
   }
 };
 
@@ -153,27 +243,36 @@ struct EpiMag {  // pitch_adjustable_mel.py:83-92: sqrt(re^2 + im^2 + 1e-9) [* w
   float* out; long o_bs; int ldo;
   int n_bins, n_rows;   // rows in [n_bins, n_rows) are written as 0 (zero-padded bins)
   float mul, div;       // 0 => no rescale
-  __device__ __forceinline__ void operator()(int b, int row, int t, float re, float im) const {
+  struct Pre {};
+  __device__ __forceinline__ Pre load(int, int, int, bool) const { return Pre{}; }
+  __device__ __forceinline__ float mag1(float re, float im) const {
+    float v = sqrtf(re * re + im * im + 1e-9f);
+    if (mul != 0.f) v = v * mul / div;
+    return v;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 re, f2 im, const Pre&) const {
     if (row >= n_rows) return;
-    float v = 0.f;
-    if (row < n_bins) {
-      v = sqrtf(re * re + im * im + 1e-9f);
-      if (mul != 0.f) v = v * mul / div;
-    }
-    out[b * o_bs + (long)row * ldo + t] = v;
+    f2 v{0.f, 0.f};
+    if (row < n_bins) v = f2{mag1(re.x, im.x), mag1(re.y, im.y)};
+    st2(out + b * o_bs + (long)row * ldo + t, v, two);
   }
 };
 
 struct EpiLogMel {  // audio.py:11-18 + nsf_hifigan.py:104-105
   static constexpr bool kPaired = false;
   float* out; long o_bs; int ldo; int M, log_mode;
-  __device__ __forceinline__ void operator()(int b, int row, int t, float v) const {
-    if (row >= M) return;
+  struct Pre {};
+  __device__ __forceinline__ Pre load(int, int, int, bool) const { return Pre{}; }
+  __device__ __forceinline__ float log1(float v) const {
     if (log_mode != 0) {
       v = logf(fmaxf(v, 1e-5f));
       if (log_mode == 2) v = 0.434294f * v;
     }
-    out[b * o_bs + (long)row * ldo + t] = v;
+    return v;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre&) const {
+    if (row >= M) return;
+    st2(out + b * o_bs + (long)row * ldo + t, f2{log1(v.x), log1(v.y)}, two);
   }
 };
 
@@ -184,13 +283,14 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 template <int RB, bool SPLITK, bool LRELU, class Epi>
 __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
   static_assert(!Epi::kPaired || RB == 2, "paired epilogues need both row blocks");
-  constexpr int NB = 2;                       // two 32-column blocks per wave tile
+  constexpr int NB = 2;                       // two 32-column MFMA blocks per wave tile (interleaved columns)
   constexpr int Q = RB * NB * 16;             // accumulator registers per lane
   __shared__ float red[SPLITK ? 4 * Q * kWave : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, li = lane & 31;
+  FDX_STAMP(0);
 
   // ---- XCD-aware logical tile id (block b runs on XCD b % 8; give each XCD a contiguous chunk)
   const int G = gridDim.x, bid = blockIdx.x;
@@ -202,6 +302,9 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
   const int tile_in_item = nt - item * a.tiles_per_item;
   constexpr int COLS = SPLITK ? 64 : 256;
   const int t0 = tile_in_item * COLS + (SPLITK ? 0 : wave * 64);
+  const int tc = t0 + 2 * li;                 // this lane's column pair (tc, tc+1)
+  const bool col_ok = tc < a.T, col_two = tc + 1 < a.T;
+  const int row_base = mt * (Epi::kPaired ? 32 : 32 * RB);
 
   int it_begin = 0, it_end = a.n_it;
   if (SPLITK) {
@@ -209,6 +312,24 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
     it_begin = wave * per;
     it_end = min(a.n_it, it_begin + per);
   }
+
+  // ---- split-K: the epilogue sites of this wave are static -> their global reads are issued right after the pipeline's
+  // first operand loads (so they do not delay the K loop's start) and land behind the K loop.
+  // paired: wave w finishes accumulator rows r = 4w..4w+3 (gate & filter); RB=2: rb = w>>1, r = 8(w&1)..+7; RB=1: r = 4w..+3
+  constexpr int NS = SPLITK ? (Epi::kPaired ? 4 : (RB == 2 ? 8 : 4)) : 1;
+  typename Epi::Pre pre[NS];
+  auto prefetch_epilogue = [&]() {
+    if constexpr (SPLITK) {
+      if (col_ok) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int rb = (!Epi::kPaired && RB == 2) ? (wave >> 1) : 0;
+          const int r = (Epi::kPaired || RB == 1) ? wave * 4 + i : (wave & 1) * 8 + i;
+          pre[i] = epi.load(item, row_base + rb * 32 + acc_row(r, half), tc, col_two);
+        }
+      }
+    }
+  };
 
   f32x16 acc[RB][NB];
 #pragma unroll
@@ -220,121 +341,170 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
 
   const bool active = SPLITK ? true : (t0 < a.T);   // whole-wave overhang tiles skip the K loop
   if (active && it_begin < it_end) {
-    const float4* Ap = a.Wp + ((long)mt * a.n_it + it_begin) * (RB * 64) + lane;
-    const float* Xw = a.X + item * a.x_bstride + (long)(half * 4) * a.ldx + t0 + li;
-    int cb = it_begin / a.taps;
-    int tap = it_begin - cb * a.taps;
+    struct Stage { float4 a[RB]; f2 b[4]; };
+    // Wave-uniform bases (SGPR pairs) + 32-bit byte cursors (SGPR) + per-lane 32-bit byte offsets (VGPR).  The cursors
+    // saturate at the wave's last K iteration, so the pipeline's run-ahead loads are unconditional and never leave
+    // this wave's K range (the over-run re-reads the last iteration: L1 hits, values unused).
+    const int n = it_end - it_begin;
+    const int cb0 = it_begin / a.taps, tap0 = it_begin - cb0 * a.taps;
+    const char* Abase = reinterpret_cast<const char*>(a.Wp + ((long)mt * a.n_it + it_begin) * (RB * 64));
+    const char* Xbase = reinterpret_cast<const char*>(a.X + item * a.x_bstride + a.shift0 + t0);
+    const unsigned rs = (unsigned)a.ldx * 4u;                  // bytes between channels
+    const unsigned d_tap = (unsigned)a.dshift * 4u;            // next tap, same channel block
+    const unsigned d_wrap = 8u * rs - (unsigned)(a.taps - 1) * d_tap;   // first tap of the next channel block
+    const int itl = it_end - 1, cbl = itl / a.taps, tapl = itl - cbl * a.taps;
+    const unsigned a_last = (unsigned)(n - 1) * (RB * 1024u);
+    const unsigned x_last = (unsigned)cbl * 8u * rs + (unsigned)tapl * d_tap;
+    unsigned a_off = 0, x_off = (unsigned)cb0 * 8u * rs + (unsigned)tap0 * d_tap;
+    int tap = tap0;
+    const unsigned a_lane = lane * 16u;
+    unsigned x_lane[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x_lane[j] = (unsigned)(half * 4 + j) * rs + (unsigned)li * 8u;
 
-    float4 a_cur[RB], a_nxt[RB];
-    float b_cur[4][NB], b_nxt[4][NB];
-
-    auto load = [&](float4(&av)[RB], float(&bv)[4][NB], int cbi, int tapi, const float4* ap) {
+    auto load = [&](Stage& s) {
+#if !defined(FDX_EXP_NOA)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) av[rb] = ap[rb * 64];
-      const float* xp = Xw + (long)(cbi * 8) * a.ldx + (a.shift0 + tapi * a.dshift);
+      for (int rb = 0; rb < RB; ++rb) s.a[rb] = *reinterpret_cast<const float4*>(Abase + (a_off + a_lane + rb * 1024u));
+#endif
+#if !defined(FDX_EXP_NOB)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[j][nb] = xp[(long)j * a.ldx + nb * 32];
+      for (int j = 0; j < 4; ++j) {
+        const f2u v = *reinterpret_cast<const f2u*>(Xbase + (x_off + x_lane[j]));
+        s.b[j] = f2{v.x, v.y};
+      }
+#endif
+      const bool wrap = tap + 1 == a.taps;
+      a_off = min(a_off + RB * 1024u, a_last);
+      x_off = min(x_off + (wrap ? d_wrap : d_tap), x_last);
+      tap = wrap ? 0 : tap + 1;
     };
-
-    load(a_cur, b_cur, cb, tap, Ap);
-    // Make the prologue loads land before the loop: otherwise hipcc's waitcnt pass merges "pending
-    // prologue load" into the loop header state and puts vmcnt waits for the NEXT tile's loads in front
-    // of the current tile's MFMAs (measured in the .s: vmcnt(7..0) ladder inside the MFMA block).
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-      asm volatile("" : "+v"(a_cur[rb].x), "+v"(a_cur[rb].y), "+v"(a_cur[rb].z), "+v"(a_cur[rb].w));
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(b_cur[j][nb]));
-    for (int it = it_begin; it < it_end; ++it) {
-      Ap += RB * 64;
-      if (++tap == a.taps) { tap = 0; ++cb; }
-      if (it + 1 < it_end) load(a_nxt, b_nxt, cb, tap, Ap);
+    auto compute = [&](Stage& s) {
       if (LRELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            float v = b_cur[j][nb];
-            b_cur[j][nb] = v > 0.f ? v : v * a.in_slope;
-          }
+        for (int j = 0; j < 4; ++j) {
+          s.b[j].x = s.b[j].x > 0.f ? s.b[j].x : s.b[j].x * a.in_slope;
+          s.b[j].y = s.b[j].y > 0.f ? s.b[j].y : s.b[j].y * a.in_slope;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-          const float av = j == 0 ? a_cur[rb].x : j == 1 ? a_cur[rb].y : j == 2 ? a_cur[rb].z : a_cur[rb].w;
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[j][nb], acc[rb][nb], 0, 0, 0);
+          const float av = j == 0 ? s.a[rb].x : j == 1 ? s.a[rb].y : j == 2 ? s.a[rb].z : s.a[rb].w;
+          acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[j].x, acc[rb][0], 0, 0, 0);
+          acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[j].y, acc[rb][1], 0, 0, 0);
         }
       }
+    };
+    // One pipeline slot = "issue the loads of stage L, run the MFMAs of stage C".  The loads and the cursor arithmetic
+    // are spread between the first MFMAs (a wave issues in order: anything placed in one lump between two MFMA groups
+    // leaves the matrix pipe idle for as long as it takes to issue).
+    auto slot = [&](Stage& L, Stage& C) {
+      load(L);
+      compute(C);
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) a_cur[rb] = a_nxt[rb];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b_cur[j][nb] = b_nxt[j][nb];
-    }
-  }
+      for (int k = 0; k < 2 + 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // a few VALU / SALU
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, RB * 8 - 6, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
 
-  const int row_base = mt * (Epi::kPaired ? 32 : 32 * RB);
+    // Software pipeline over a D-stage register ring: the operands of iteration i+D-1 are requested while iteration i
+    // runs.  Both operand streams arrive from beyond the XCD's L2 on first touch (weights from HBM / Infinity Cache,
+    // activations from the L2 of whichever XCD wrote them), and all workgroups sharing a line run in lockstep, so the
+    // latency to cover is the ~2-4 k cycle fabric latency, not an L2 hit: D-1 = 5 slots of 1024 MFMA cycles.
+    // No conditional loads and no register copies: the only waits are counted vmcnt(D-1 stages in flight).
+    constexpr int D = SPLITK ? 6 : 4;
+    Stage st[D];
+    FDX_STAMP(1);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load(st[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_epilogue();
+    __builtin_amdgcn_sched_barrier(0);
+    int done = 0;
+    for (; done + D <= n; done += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (done + d < n) compute(st[d]);
+  } else {
+    prefetch_epilogue();
+  }
+  FDX_STAMP(2);
 
   if (SPLITK) {
-    // ---- cross-wave K reduction through LDS, fixed summation order (deterministic)
+    // ---- cross-wave K reduction through LDS, fixed summation order ((w0+w1)+w2)+w3 (deterministic).
+    // Layout red[wave][r][lane][rb*NB+nb]: a lane's RB*NB values of accumulator row r are one 16-byte (RB=2) or
+    // 8-byte (RB=1) LDS word -> ds_write_b128 / ds_read_b128, conflict-free (consecutive lanes, consecutive words).
+    constexpr int V = RB * NB;
+    typedef float fV __attribute__((ext_vector_type(V)));
+    fV* redv = reinterpret_cast<fV*>(red);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int r = 0; r < 16; ++r) {
+      fV v;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          red[(wave * Q + (rb * NB + nb) * 16 + r) * kWave + lane] = acc[rb][nb][r];
+        for (int nb = 0; nb < NB; ++nb) v[rb * NB + nb] = acc[rb][nb][r];
+      redv[(wave * 16 + r) * kWave + lane] = v;
+    }
+    FDX_STAMP(3);
     __syncthreads();
-    auto rsum = [&](int q) {
-      return ((red[(0 * Q + q) * kWave + lane] + red[(1 * Q + q) * kWave + lane]) +
-              red[(2 * Q + q) * kWave + lane]) + red[(3 * Q + q) * kWave + lane];
-    };
-    if constexpr (Epi::kPaired) {
-      const int nb = wave >> 1, r0 = (wave & 1) * 8;
-      const int t = t0 + nb * 32 + li;
+    FDX_STAMP(4);
+    if (!col_ok) return;
+    if constexpr (Epi::kPaired || RB == 1) {
+      fV sum[NS];
 #pragma unroll
-      for (int r = r0; r < r0 + 8; ++r) {
-        float g = rsum((0 * NB + nb) * 16 + r), f = rsum((1 * NB + nb) * 16 + r);
-        if (t < a.T) epi(item, row_base + acc_row(r, half), t, g, f);
+      for (int i = 0; i < NS; ++i) {
+        const int r = wave * 4 + i;
+        sum[i] = ((redv[(0 * 16 + r) * kWave + lane] + redv[(1 * 16 + r) * kWave + lane]) +
+                  redv[(2 * 16 + r) * kWave + lane]) + redv[(3 * 16 + r) * kWave + lane];
       }
-    } else if constexpr (RB == 2) {
-      const int rb = wave >> 1, nb = wave & 1;
-      const int t = t0 + nb * 32 + li;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = rsum((rb * NB + nb) * 16 + r);
-        if (t < a.T) epi(item, row_base + rb * 32 + acc_row(r, half), t, v);
+      for (int i = 0; i < NS; ++i) {
+        const int r = wave * 4 + i;
+        if constexpr (Epi::kPaired)
+          epi.store(item, row_base + acc_row(r, half), tc, col_two, f2{sum[i][0], sum[i][1]}, f2{sum[i][2], sum[i][3]}, pre[i]);
+        else
+          epi.store(item, row_base + acc_row(r, half), tc, col_two, f2{sum[i][0], sum[i][1]}, pre[i]);
       }
     } else {
-      const int nb = wave >> 1, r0 = (wave & 1) * 8;
-      const int t = t0 + nb * 32 + li;
+      const int rb = wave >> 1;
+      const f2* red2 = reinterpret_cast<const f2*>(red);   // [wave][r][lane][rb] pairs
+      f2 sum[NS];
 #pragma unroll
-      for (int r = r0; r < r0 + 8; ++r) {
-        float v = rsum(nb * 16 + r);
-        if (t < a.T) epi(item, row_base + acc_row(r, half), t, v);
+      for (int i = 0; i < NS; ++i) {
+        const int r = (wave & 1) * 8 + i;
+        sum[i] = ((red2[((0 * 16 + r) * kWave + lane) * 2 + rb] + red2[((1 * 16 + r) * kWave + lane) * 2 + rb]) +
+                  red2[((2 * 16 + r) * kWave + lane) * 2 + rb]) + red2[((3 * 16 + r) * kWave + lane) * 2 + rb];
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int r = (wave & 1) * 8 + i;
+        epi.store(item, row_base + rb * 32 + acc_row(r, half), tc, col_two, sum[i], pre[i]);
       }
     }
+    FDX_STAMP(5);
   } else {
-    if (!active) return;
+    if (!active || !col_ok) return;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int t = t0 + nb * 32 + li;
-      if (t >= a.T) continue;
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (Epi::kPaired) {
+        const int row = row_base + acc_row(r, half);
+        epi.store(item, row, tc, col_two, f2{acc[0][0][r], acc[0][1][r]}, f2{acc[1][0][r], acc[1][1][r]},
+                  epi.load(item, row, tc, col_two));
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if constexpr (Epi::kPaired) {
-          epi(item, row_base + acc_row(r, half), t, acc[0][nb][r], acc[1][nb][r]);
-        } else {
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) epi(item, row_base + rb * 32 + acc_row(r, half), t, acc[rb][nb][r]);
+        for (int rb = 0; rb < RB; ++rb) {
+          const int row = row_base + rb * 32 + acc_row(r, half);
+          epi.store(item, row, tc, col_two, f2{acc[rb][0][r], acc[rb][1][r]}, epi.load(item, row, tc, col_two));
         }
       }
     }
@@ -363,6 +533,11 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   a.in_slope = in_slope;
   const int grid = a.n_tiles_n * a.n_mtiles;
   if (grid <= 0) return hipSuccess;
+#ifdef FDX_KTRACE
+  a.trace = nullptr;
+  if (g_trace.buf && g_trace.n < g_trace.max_launches && grid <= g_trace.blocks_cap)
+    a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
+#endif
   hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi>), dim3(grid), dim3(256), 0, s, a, epi);
   return hipGetLastError();
 }

@@ -119,3 +119,12 @@ extern "C" int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, in
   FDX_HIP(h, err);
   return FDX_OK;
 }
+
+#ifdef FDX_KTRACE
+// Trace build only (python -m fish_diffusion_amd._build --trace): the next `max_launches` conv/GEMM launches with at most
+// `blocks_cap` workgroups write 8 shader-clock stamps per wave into buf[launch][blocks_cap][4][8] (u64, device memory).
+extern "C" int fdx_debug_trace(unsigned long long* dev_buf, int max_launches, int blocks_cap) {
+  g_trace.buf = dev_buf; g_trace.max_launches = max_launches; g_trace.blocks_cap = blocks_cap; g_trace.n = 0;
+  return FDX_OK;
+}
+#endif

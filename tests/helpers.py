@@ -85,7 +85,7 @@ def emulate_convgemm(packed, X, *, n_mtiles, RB, cin8, taps, shift0, dshift, T, 
                 for j in range(4):
                     ch = cb * 8 + half * 4 + j
                     for nb in range(2):
-                        col = halo + t0 + nb * 32 + li + shift0 + tap * dshift
+                        col = halo + t0 + 2 * li + nb + shift0 + tap * dshift   # lane li owns the column pair (2li, 2li+1)
                         b = X[ch, col]
                         for rb in range(RB):
                             a = P[mt, it, rb, :, j]
@@ -95,7 +95,7 @@ def emulate_convgemm(packed, X, *, n_mtiles, RB, cin8, taps, shift0, dshift, T, 
                     for r in range(16):
                         for h in range(2):
                             row = (r & 3) + 8 * (r >> 2) + 4 * h
-                            tiles[0][rb][row, t0 + nb * 32:t0 + nb * 32 + 32] = acc[rb, nb, r, h * 32:(h + 1) * 32]
+                            tiles[0][rb][row, t0 + nb:t0 + 64:2] = acc[rb, nb, r, h * 32:(h + 1) * 32]
         for rb in range(RB):
             out[(mt, rb)] = tiles[0][rb][:, :T]
     return out

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where does a conv/GEMM launch spend its time?  Runs one WaveNet forward (T=861, full net) on the instrumented
+library (`python -m fish_diffusion_amd._build --trace`, FDX_LIB_PATH=.../libfishdx_trace.so) and prints, per launch,
+the per-wave shader-clock intervals:  start->loads issued, K loop, LDS write, barrier wait, epilogue."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FDX_LIB_PATH", os.path.join(ROOT, "fish_diffusion_amd", "csrc", "libfishdx_trace.so"))
+from fish_diffusion_amd import DENOISERS, _lib  # noqa: E402
+
+dev = torch.device("cuda", 0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+T = 861
+net = DENOISERS.build(dict(type="WaveNetDenoiser", mel_channels=128, d_encoder=256, residual_channels=512, residual_layers=20,
+                           dilation_cycle=4, use_linear_bias=True)).to(dev)
+x, cond, t = torch.randn(B, 128, T, device=dev), torch.randn(B, 256, T, device=dev), torch.tensor([500.0], device=dev)
+for _ in range(3):
+    net(x, t, cond)
+torch.cuda.synchronize()
+CAP, NL = 256 * B, 64
+buf = torch.zeros(NL * CAP * 32, dtype=torch.int64, device=dev)
+lib = _lib.lib()
+lib.fdx_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.fdx_debug_trace(C.c_void_p(buf.data_ptr()), NL, CAP)
+net(x, t, cond)
+torch.cuda.synchronize()
+lib.fdx_debug_trace(None, 0, 0)
+tr = buf.cpu().numpy().reshape(NL, CAP, 4, 8)
+names = ["setup+prefetch", "K loop", "LDS write", "barrier wait", "epilogue"]
+print(f"{'launch':>6} {'waves':>6} {'span':>8} | " + " ".join(f"{n:>14}" for n in names) + " | total/wave   (shader cycles, mean over waves; span = last end - first start)")
+for l in range(NL):
+    w = tr[l].reshape(-1, 8)
+    w = w[w[:, 0] != 0]
+    if not len(w):
+        continue
+    d = np.diff(w[:, :6].astype(np.int64), axis=1)
+    span = int(w[:, 5].max() - w[:, 0].min())
+    print(f"{l:>6} {len(w):>6} {span:>8} | " + " ".join(f"{d[:, i].mean():>14.0f}" for i in range(5)) + f" | {d.sum(1).mean():>10.0f}")
