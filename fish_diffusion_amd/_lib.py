@@ -68,6 +68,7 @@ _SIGS = {
                                    C.c_int, _P, _P]),
     "fdx_prof_enable": (C.c_int, [_P, C.c_int]),
     "fdx_prof_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fdx_prof_calibrate": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -73,6 +73,8 @@ struct NsfLayout {
 
 struct ProfEvents {
   bool on = false;
+  int stride = 1;          // record every stride-th launch of the dominant kernel
+  long seen = 0;
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
   double flops_per_launch = 0;

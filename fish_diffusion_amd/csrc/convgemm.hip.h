@@ -23,6 +23,7 @@
 //  * XCD-aware block order: consecutive logical tiles (same weight rows) land on the same XCD's L2.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace fdx {
@@ -80,6 +81,13 @@ __device__ __forceinline__ void st2(float* p, f2 v, bool two) {
   else p[0] = v.x;
 }
 
+// Pair store into one of the library's own padded rows: unconditional 8-byte store; when column t+1 == T it receives 0,
+// which is what the zero halo right of the row must hold anyway (keeps the epilogue free of per-lane branches).
+__device__ __forceinline__ void st2p(float* p, f2 v, bool two) {
+  f2u u; u.x = v.x; u.y = two ? v.y : 0.f;
+  *reinterpret_cast<f2u*>(p) = u;
+}
+
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2 };
 
 __device__ __forceinline__ float mish_f(float x) {
@@ -96,6 +104,7 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
   const uint8_t* mask; int mask_ld;   // [B][mask_ld] bytes, 1 = masked
   float* out2; long o2_bs; int ldo2;  // optional second output
   const float* sb; int sb_ld, sb_bs;  // out2 = v + sb[row*sb_ld + b*sb_bs]
+  int tight;                          // 1: `out` is a caller tensor with no padding (row pitch may equal T); out2 is always padded
   struct Pre { float bias, sb; bool m0, m1; };
   __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
     Pre p{0.f, 0.f, false, false};
@@ -115,8 +124,9 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
     if (row >= M) return;
     v.x = act1(v.x, p.bias, p.m0);
     v.y = act1(v.y, p.bias, p.m1);
-    st2(out + b * o_bs + (long)row * ldo + t, v, two);
-    if (out2) st2(out2 + b * o2_bs + (long)row * ldo2 + t, f2{v.x + p.sb, v.y + p.sb}, two);
+    if (tight) st2(out + b * o_bs + (long)row * ldo + t, v, two);
+    else st2p(out + b * o_bs + (long)row * ldo + t, v, two);
+    if (out2) st2p(out2 + b * o2_bs + (long)row * ldo2 + t, f2{v.x + p.sb, v.y + p.sb}, two);
   }
 };
 
@@ -150,7 +160,7 @@ struct EpiGate {  // wavenet.py:112-115: y = conv + conditioner (bias folded int
   __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 g, f2 f, const Pre& p) const {
     if (row >= C) return;
     g += p.pg; f += p.pf;
-    st2(out + b * o_bs + (long)row * ldo + t, f2{gate1(g.x, f.x), gate1(g.y, f.y)}, two);
+    st2p(out + b * o_bs + (long)row * ldo + t, f2{gate1(g.x, f.x), gate1(g.y, f.y)}, two);
   }
 };
 
@@ -162,11 +172,13 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
   int C, skip_mode;                                   // 0 first (=), 1 middle (+=), 2 last ((+=)/sqrt(L)); 3 = first and last
   float inv_div;                                      // sqrt(n_layers)
   struct Pre { f2 old; float bias, sb; };
+  // A 32-row accumulator block lies entirely on one side of C (C % 32 == 0), so "residual or skip half?" is decided
+  // on a wave-uniform value (scalar branch) instead of per lane.
+  __device__ __forceinline__ bool is_res(int row) const { return __builtin_amdgcn_readfirstlane(row) < C; }
   __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
     Pre p{f2{0.f, 0.f}, 0.f, 0.f};
-    if (row >= 2 * C) return p;
     p.bias = bias[row];
-    if (row < C) {
+    if (is_res(row)) {
       p.old = ld2(X + b * bs + (long)row * ld + t, two);
       if (Y) p.sb = sb[(long)row * sb_ld + b * sb_bs];
     } else if (skip_mode == 1 || skip_mode == 2) {
@@ -175,19 +187,18 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
     return p;
   }
   __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
-    if (row >= 2 * C) return;
     v += p.bias;
-    if (row < C) {
+    if (is_res(row)) {
       const long o = b * bs + (long)row * ld + t;
       const f2 xn = (p.old + v) / 1.41421356237309504880f;
-      st2(X + o, xn, two);
-      if (Y) st2(Y + o, xn + p.sb, two);
+      st2p(X + o, xn, two);
+      if (Y) st2p(Y + o, xn + p.sb, two);
     } else {
       const long o = b * bs + (long)(row - C) * ld + t;
       f2 s = v;
       if (skip_mode == 1 || skip_mode == 2) s = p.old + v;
       if (skip_mode >= 2) s = s / inv_div;
-      st2(SK + o, s, two);
+      st2p(SK + o, s, two);
     }
   }
 };
@@ -214,7 +225,7 @@ struct EpiResblock {  // models.py:103-110 conv2: x = xt + x; plus the MRF mean 
     if (resid) v += p.res;
     if (mode == 1) v = p.old + v;
     else if (mode == 2) v = (p.old + v) / div;
-    st2(out + b * bs + (long)row * ld + t, v, two);
+    st2p(out + b * bs + (long)row * ld + t, v, two);
   }
 };
 
@@ -254,7 +265,7 @@ struct EpiMag {  // pitch_adjustable_mel.py:83-92: sqrt(re^2 + im^2 + 1e-9) [* w
     if (row >= n_rows) return;
     f2 v{0.f, 0.f};
     if (row < n_bins) v = f2{mag1(re.x, im.x), mag1(re.y, im.y)};
-    st2(out + b * o_bs + (long)row * ldo + t, v, two);
+    st2p(out + b * o_bs + (long)row * ldo + t, v, two);
   }
 };
 
@@ -363,17 +374,13 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
     for (int j = 0; j < 4; ++j) x_lane[j] = (unsigned)(half * 4 + j) * rs + (unsigned)li * 8u;
 
     auto load = [&](Stage& s) {
-#if !defined(FDX_EXP_NOA)
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) s.a[rb] = *reinterpret_cast<const float4*>(Abase + (a_off + a_lane + rb * 1024u));
-#endif
-#if !defined(FDX_EXP_NOB)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f2u v = *reinterpret_cast<const f2u*>(Xbase + (x_off + x_lane[j]));
         s.b[j] = f2{v.x, v.y};
       }
-#endif
       const bool wrap = tap + 1 == a.taps;
       a_off = min(a_off + RB * 1024u, a_last);
       x_off = min(x_off + (wrap ? d_wrap : d_tap), x_last);
@@ -404,21 +411,22 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
       load(L);
       compute(C);
 #pragma unroll
-      for (int k = 0; k < 2 + 4; ++k) {
+      for (int k = 0; k < RB + 4; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
         __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // a few VALU / SALU
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, RB * 8 - 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, RB * 8 - (RB + 4), 0);
       __builtin_amdgcn_sched_barrier(0);
     };
 
     // Software pipeline over a D-stage register ring: the operands of iteration i+D-1 are requested while iteration i
     // runs.  Both operand streams arrive from beyond the XCD's L2 on first touch (weights from HBM / Infinity Cache,
     // activations from the L2 of whichever XCD wrote them), and all workgroups sharing a line run in lockstep, so the
-    // latency to cover is the ~2-4 k cycle fabric latency, not an L2 hit: D-1 = 5 slots of 1024 MFMA cycles.
+    // latency to cover is the ~2-4 k cycle fabric latency, not an L2 hit: D-1 = 3 slots of 1024 MFMA cycles (D = 3, 4
+    // and 6 measure within 2 % of each other; the residual ~12 % gap to the no-load MFMA rate is not latency).
     // No conditional loads and no register copies: the only waits are counted vmcnt(D-1 stages in flight).
-    constexpr int D = SPLITK ? 6 : 4;
+    constexpr int D = 4;
     Stage st[D];
     FDX_STAMP(1);
 #pragma unroll
@@ -521,7 +529,8 @@ struct ConvGeom {   // everything the launcher needs besides pointers
 
 template <int RB, bool SPLITK, bool LRELU, class Epi>
 inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx,
-                                  float in_slope, const Epi& epi, hipStream_t s) {
+                                  float in_slope, const Epi& epi, hipStream_t s, hipEvent_t ev_start = nullptr,
+                                  hipEvent_t ev_stop = nullptr) {
   ConvArgs a;
   a.Wp = Wp; a.X = X; a.x_bstride = x_bstride; a.ldx = ldx;
   a.n_it = g.cin8 * g.taps; a.taps = g.taps; a.shift0 = g.shift0; a.dshift = g.dshift;
@@ -538,7 +547,10 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   if (g_trace.buf && g_trace.n < g_trace.max_launches && grid <= g_trace.blocks_cap)
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
-  hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi>), dim3(grid), dim3(256), 0, s, a, epi);
+  if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, a, epi);
+  else
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi>), dim3(grid), dim3(256), 0, s, a, epi);
   return hipGetLastError();
 }
 

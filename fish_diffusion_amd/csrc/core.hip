@@ -1,6 +1,8 @@
 // core.hip -- handle lifetime, error reporting, profiling hooks and the kernel-level test hook.
 #include "common.hip.h"
 
+#include <algorithm>
+
 using namespace fdx;
 
 namespace fdx { thread_local std::string g_last_error; }
@@ -52,6 +54,8 @@ extern "C" const char* fdx_last_error(fdx_handle h) {
 extern "C" int fdx_prof_enable(fdx_handle h, int on) {
   if (!h) return FDX_E_ARG;
   h->prof.on = on != 0;
+  h->prof.stride = on > 1 ? on : 1;   // on = N > 1: sample every N-th launch (keeps the probe effect out of `value`)
+  h->prof.seen = 0;
   h->prof.used = 0;
   return FDX_OK;
 }
@@ -69,6 +73,23 @@ extern "C" int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, do
   if (total_ms) *total_ms = tot;
   if (flops_per_launch) *flops_per_launch = h->prof.flops_per_launch;
   h->prof.used = 0;
+  return FDX_OK;
+}
+
+extern "C" int fdx_prof_calibrate(fdx_handle h, fdx_stream st, double* empty_pair_ms) {
+  if (!h || !empty_pair_ms) return FDX_E_ARG;
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  constexpr int N = 65;
+  hipEvent_t a[N], b[N];
+  for (int i = 0; i < N; ++i) { FDX_HIP(h, hipEventCreate(&a[i])); FDX_HIP(h, hipEventCreate(&b[i])); }
+  for (int i = 0; i < N; ++i) { FDX_HIP(h, hipEventRecord(a[i], s)); FDX_HIP(h, hipEventRecord(b[i], s)); }
+  FDX_HIP(h, hipStreamSynchronize(s));
+  std::vector<float> ms(N);
+  for (int i = 0; i < N; ++i) FDX_HIP(h, hipEventElapsedTime(&ms[i], a[i], b[i]));
+  for (int i = 0; i < N; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
+  std::nth_element(ms.begin(), ms.begin() + N / 2, ms.end());
+  *empty_pair_ms = ms[N / 2];
   return FDX_OK;
 }
 
@@ -104,7 +125,7 @@ extern "C" int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, in
     FDX_HIP(h, hipMemcpy2DAsync(h->dbg_x.f() + (size_t)b * cinp * ld + kHalo, (size_t)ld * 4, x + (size_t)b * Cin * T,
                                 (size_t)T * 4, (size_t)T * 4, (size_t)Cin, hipMemcpyDeviceToDevice, s));
   EpiBias e{};
-  e.out = y; e.o_bs = (long)Cout * T; e.ldo = T; e.bias = h->dbg_b.f(); e.M = Cout; e.act = ACT_NONE;
+  e.out = y; e.o_bs = (long)Cout * T; e.ldo = T; e.bias = h->dbg_b.f(); e.M = Cout; e.act = ACT_NONE; e.tight = 1;
   ConvGeom g{B, T, cin8, k, -(k - 1) / 2 * dilation, dilation, n_mtiles};
   const float4* Wp = reinterpret_cast<const float4*>(h->dbg_w.p);
   const float* X = h->dbg_x.f() + kHalo;

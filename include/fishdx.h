@@ -195,10 +195,16 @@ int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, int T, const 
                      const float* host_bias, int Cout, int k, int dilation, float in_slope, int mode,
                      float* y, fdx_stream s);
 /* Per-kernel timing: when enabled, every launch of the dominant kernel (the dilated-conv + gate
- * kernel of the residual block) is bracketed by HIP events on its own stream.  fdx_prof_read returns
- * the number of launches recorded and their total duration (synchronises those events). */
+ * kernel of the residual block) is dispatched with hipExtLaunchKernel's start/stop events, i.e. the
+ * events carry that dispatch's own begin/end timestamps on its stream (the quantity rocprofv3's
+ * kernel trace reports).  fdx_prof_read returns the number of launches recorded and their total
+ * duration (synchronises those events). */
+/* on = 0: off; 1: every launch; N > 1: every N-th launch (sampling keeps the probe effect negligible). */
 int fdx_prof_enable(fdx_handle h, int on);
 int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch);
+/* Median elapsed time (ms) of an EMPTY hipEventRecord start/stop pair on stream s (diagnostic: what
+ * bracketing a launch with plain recorded events would add; fdx_prof_* does not use that method). */
+int fdx_prof_calibrate(fdx_handle h, fdx_stream s, double* empty_pair_ms);
 
 #ifdef __cplusplus
 }
