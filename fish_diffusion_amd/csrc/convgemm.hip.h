@@ -51,7 +51,7 @@ struct ConvArgs {
 };
 
 #ifdef FDX_KTRACE
-#define FDX_STAMP(k) do { if (a.trace && lane == 0) a.trace[((long)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FDX_STAMP(k) do { if (a.trace && lane == 0) a.trace[((long)blockIdx.x * (blockDim.x >> 6) + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 struct TraceState { unsigned long long* buf = nullptr; int max_launches = 0, n = 0, blocks_cap = 0; };
 inline TraceState g_trace;
 #else
@@ -87,6 +87,16 @@ __device__ __forceinline__ void st2p(float* p, f2 v, bool two) {
   f2u u; u.x = v.x; u.y = two ? v.y : 0.f;
   *reinterpret_cast<f2u*>(p) = u;
 }
+
+// x / c for a wave-uniform constant c with rc = RN(1/c): Markstein's sequence q = RN(x*rc); r = x - q*c (exact, fused);
+// q' = RN(q + r*rc) returns the correctly rounded quotient (checked bit-identical to IEEE division on 8e7 random x for
+// c = sqrt(2)) in 3 dependent VALU ops instead of the ~12-op v_div_scale / v_rcp / v_div_fixup expansion.
+__device__ __forceinline__ float div_const(float x, float c, float rc) {
+  const float q = x * rc;
+  const float r = fmaf(-q, c, x);
+  return fmaf(r, rc, q);
+}
+__device__ __forceinline__ f2 div_const(f2 x, float c, float rc) { return f2{div_const(x.x, c, rc), div_const(x.y, c, rc)}; }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2 };
 
@@ -170,7 +180,7 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
   const float* bias;                                  // [2C]
   const float* sb; int sb_ld, sb_bs;                  // next layer's diffusion projection, [C][sb_ld]
   int C, skip_mode;                                   // 0 first (=), 1 middle (+=), 2 last ((+=)/sqrt(L)); 3 = first and last
-  float inv_div;                                      // sqrt(n_layers)
+  float inv_div, r_inv_div;                           // sqrt(n_layers) and RN(1/sqrt(n_layers))
   struct Pre { f2 old; float bias, sb; };
   // A 32-row accumulator block lies entirely on one side of C (C % 32 == 0), so "residual or skip half?" is decided
   // on a wave-uniform value (scalar branch) instead of per lane.
@@ -190,14 +200,14 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
     v += p.bias;
     if (is_res(row)) {
       const long o = b * bs + (long)row * ld + t;
-      const f2 xn = (p.old + v) / 1.41421356237309504880f;
+      const f2 xn = div_const(p.old + v, 1.41421356237309504880f, 0.70710678118654752440f);
       st2p(X + o, xn, two);
       if (Y) st2p(Y + o, xn + p.sb, two);
     } else {
       const long o = b * bs + (long)(row - C) * ld + t;
       f2 s = v;
       if (skip_mode == 1 || skip_mode == 2) s = p.old + v;
-      if (skip_mode >= 2) s = s / inv_div;
+      if (skip_mode >= 2) s = div_const(s, inv_div, r_inv_div);
       st2p(SK + o, s, two);
     }
   }
@@ -291,12 +301,13 @@ struct EpiLogMel {  // audio.py:11-18 + nsf_hifigan.py:104-105
 // Accumulator element r of a 32x32 tile sits at row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31.
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int RB, bool SPLITK, bool LRELU, class Epi>
-__global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
+template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) {
+  static_assert(NW == 4 || (SPLITK && NW == 8), "4 waves per workgroup, or 8 K-splitting waves (2 per SIMD)");
   static_assert(!Epi::kPaired || RB == 2, "paired epilogues need both row blocks");
   constexpr int NB = 2;                       // two 32-column MFMA blocks per wave tile (interleaved columns)
   constexpr int Q = RB * NB * 16;             // accumulator registers per lane
-  __shared__ float red[SPLITK ? 4 * Q * kWave : 1];
+  __shared__ float red[SPLITK ? NW * Q * kWave : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,23 +330,25 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
 
   int it_begin = 0, it_end = a.n_it;
   if (SPLITK) {
-    const int per = (a.n_it + 3) >> 2;
+    const int per = (a.n_it + NW - 1) / NW;
     it_begin = wave * per;
     it_end = min(a.n_it, it_begin + per);
   }
 
   // ---- split-K: the epilogue sites of this wave are static -> their global reads are issued right after the pipeline's
   // first operand loads (so they do not delay the K loop's start) and land behind the K loop.
-  // paired: wave w finishes accumulator rows r = 4w..4w+3 (gate & filter); RB=2: rb = w>>1, r = 8(w&1)..+7; RB=1: r = 4w..+3
-  constexpr int NS = SPLITK ? (Epi::kPaired ? 4 : (RB == 2 ? 8 : 4)) : 1;
+  // The tile's epilogue sites (accumulator row r [x row block rb when unpaired]) are dealt to the NW waves in order:
+  // site s = wave*NS + i; paired / RB=1: r = s; unpaired RB=2: rb = s / 16, r = s % 16.
+  constexpr int NS = SPLITK ? ((Epi::kPaired || RB == 1) ? 16 / NW : 32 / NW) : 1;
   typename Epi::Pre pre[NS];
   auto prefetch_epilogue = [&]() {
     if constexpr (SPLITK) {
       if (col_ok) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-          const int rb = (!Epi::kPaired && RB == 2) ? (wave >> 1) : 0;
-          const int r = (Epi::kPaired || RB == 1) ? wave * 4 + i : (wave & 1) * 8 + i;
+          const int sidx = wave * NS + i;
+          const int rb = (!Epi::kPaired && RB == 2) ? (sidx >> 4) : 0;
+          const int r = sidx & 15;
           pre[i] = epi.load(item, row_base + rb * 32 + acc_row(r, half), tc, col_two);
         }
       }
@@ -471,31 +484,32 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvArgs a, Epi epi) {
       fV sum[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int r = wave * 4 + i;
-        sum[i] = ((redv[(0 * 16 + r) * kWave + lane] + redv[(1 * 16 + r) * kWave + lane]) +
-                  redv[(2 * 16 + r) * kWave + lane]) + redv[(3 * 16 + r) * kWave + lane];
+        const int r = wave * NS + i;
+        sum[i] = redv[(0 * 16 + r) * kWave + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum[i] += redv[(w * 16 + r) * kWave + lane];
       }
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int r = wave * 4 + i;
+        const int r = wave * NS + i;
         if constexpr (Epi::kPaired)
           epi.store(item, row_base + acc_row(r, half), tc, col_two, f2{sum[i][0], sum[i][1]}, f2{sum[i][2], sum[i][3]}, pre[i]);
         else
           epi.store(item, row_base + acc_row(r, half), tc, col_two, f2{sum[i][0], sum[i][1]}, pre[i]);
       }
     } else {
-      const int rb = wave >> 1;
       const f2* red2 = reinterpret_cast<const f2*>(red);   // [wave][r][lane][rb] pairs
       f2 sum[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int r = (wave & 1) * 8 + i;
-        sum[i] = ((red2[((0 * 16 + r) * kWave + lane) * 2 + rb] + red2[((1 * 16 + r) * kWave + lane) * 2 + rb]) +
-                  red2[((2 * 16 + r) * kWave + lane) * 2 + rb]) + red2[((3 * 16 + r) * kWave + lane) * 2 + rb];
+        const int sidx = wave * NS + i, rb = sidx >> 4, r = sidx & 15;
+        sum[i] = red2[((0 * 16 + r) * kWave + lane) * 2 + rb];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum[i] += red2[((w * 16 + r) * kWave + lane) * 2 + rb];
       }
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int r = (wave & 1) * 8 + i;
+        const int sidx = wave * NS + i, rb = sidx >> 4, r = sidx & 15;
         epi.store(item, row_base + rb * 32 + acc_row(r, half), tc, col_two, sum[i], pre[i]);
       }
     }
@@ -527,7 +541,7 @@ struct ConvGeom {   // everything the launcher needs besides pointers
   int n_mtiles;     // row tiles of 32*RB logical rows (32 pairs for paired epilogues)
 };
 
-template <int RB, bool SPLITK, bool LRELU, class Epi>
+template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4>
 inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx,
                                   float in_slope, const Epi& epi, hipStream_t s, hipEvent_t ev_start = nullptr,
                                   hipEvent_t ev_stop = nullptr) {
@@ -548,9 +562,9 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
-    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, a, epi);
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0, a, epi);
   else
-    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi>), dim3(grid), dim3(256), 0, s, a, epi);
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW>), dim3(grid), dim3(NW * 64), 0, s, a, epi);
   return hipGetLastError();
 }
 

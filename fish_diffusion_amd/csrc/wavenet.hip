@@ -158,6 +158,9 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
 }
 
 // ================================================================================================ launch helpers
+// (An 8-wave variant -- 2 K-splitting waves per SIMD, convgemm_kernel<..., NW = 8> -- was measured on the batch-1
+// denoiser: 2 % SLOWER than 4 waves.  The K loop's residual stall is per-CU operand throughput, not latency, so a second
+// wave per SIMD has nothing to hide)
 template <bool SPLITK, bool LRELU, class Epi>
 static hipError_t run_gemm(const float* arena, const PackedW& p, int B, int T, const float* X, long x_bs, int ldx,
                            int shift0, int dshift, float slope, const Epi& e, hipStream_t s, hipEvent_t ev0 = nullptr,
@@ -297,7 +300,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     r.Y = (i + 1 < L) ? Y : nullptr;
     r.sb = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn; r.sb_ld = ldn; r.sb_bs = sb_bs;
     r.skip_mode = (L == 1) ? 3 : (i == 0 ? 0 : (i + 1 == L ? 2 : 1));
-    r.inv_div = sqrtL;
+    r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
     FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s)));
   }
   {

@@ -340,3 +340,99 @@ def test_end_to_end_c1_mel_to_wave(dev):
     print(f"C1 end-to-end wav abs err {err:.3e}")
     assert wav.numel() == T * 512
     assert err < 5e-3   # mel error (<=1e-3 rel of a 5-unit range) amplified by the vocoder; each stage is held to its own bar above
+
+
+# ------------------------------------------------------------------------------------------------ more of SURVEY 8(a)
+def test_wavenet_v1_arch_no_linear_bias_no_dilation_cycle(dev):
+    """diff_svc v1 arch: use_linear_bias=False, dilation_cycle=None (all dilations 1) -- wavenet.py:161,181."""
+    cfg = dict(mel_channels=128, d_encoder=256, residual_channels=96, residual_layers=3, dilation_cycle=None, use_linear_bias=False)
+    sd = wavenet_sd(cfg, 7)
+    assert not any(k.endswith("linear.bias") for k in sd)
+    net = _wavenet(cfg, sd, dev)
+    g = torch.Generator().manual_seed(1)
+    x, cond, t = torch.randn(2, 128, 77, generator=g), torch.randn(2, 256, 77, generator=g), torch.tensor([3.0, 777.0])
+    with torch.no_grad():
+        ref = _oracle_den(sd, cfg)(x, t, cond, None, None)
+    assert rel_err(net(x.to(dev), t.to(dev), cond.to(dev)).cpu(), ref) < 2e-5
+
+
+def test_per_bin_spec_stats_and_cosine_schedule(dev):
+    """spec_min / spec_max of length mel_channels (diffusion.py:106-107) and noise_schedule='cosine' (:18-31)."""
+    from oracle import sampler_ref
+    sd = wavenet_sd(WN_SMALL, 101)
+    g = torch.Generator().manual_seed(2)
+    smin = (-6 + torch.rand(128, generator=g)).tolist()
+    smax = (0.5 * torch.rand(128, generator=g)).tolist()
+    from fish_diffusion_amd import DIFFUSIONS
+    diff = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=smin,
+                                 spec_max=smax, noise_schedule="cosine"))
+    diff.denoise_fn.load_state_dict(sd, strict=True)
+    diff = diff.to(dev).eval()
+    feats, x0 = torch.randn(2, 31, 256, generator=g), torch.randn(2, 128, 31, generator=g)
+    for pred, interval in (("unipc", 100), ("plms", 200), ("naive", 250)):
+        n = len(range(0, 1000, interval))
+        sn = torch.randn(n, 2, 128, 31, generator=g)
+        with torch.no_grad():
+            ref = sampler_ref.diffusion_sample(_oracle_den(sd, WN_SMALL), feats, x_init=x0, sampler_interval=interval, predictor=pred,
+                                               step_noise=sn, noise_schedule="cosine", spec_min=smin, spec_max=smax)
+        mel = diff(feats.to(dev), sampler_interval=interval, noise_predictor=pred, x_init=x0.to(dev),
+                   step_noise=sn.to(dev) if pred == "naive" else None)
+        assert rel_err(mel.cpu(), ref) < MEL_REL, pred
+    with pytest.raises(AssertionError):
+        DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[0.0, 1.0],
+                              spec_max=[1.0, 2.0]))
+
+
+def test_q_sample_and_shallow_diffusion_entry(dev):
+    """diffusion.py:120-127,223-232: q_sample with given noise == oracle; the skip_steps path runs end to end."""
+    from oracle import sampler_ref
+    diff = _diffusion(WN_SMALL, wavenet_sd(WN_SMALL, 101), dev)
+    g = torch.Generator().manual_seed(4)
+    x0, nz = torch.randn(2, 128, 20, generator=g), torch.randn(2, 128, 20, generator=g)
+    ref = sampler_ref.q_sample(x0, 600, nz, sampler_ref.beta_schedule())
+    out = diff.q_sample(x0.to(dev), torch.tensor([600], device=dev), nz.to(dev))
+    assert abs_err(out.cpu(), ref) < 1e-6
+    mel0 = -5 * torch.rand(2, 128, 20, generator=g)
+    torch.manual_seed(0)
+    a = diff(torch.randn(2, 20, 256, generator=g).to(dev), sampler_interval=100, skip_steps=400, original_mel=mel0.to(dev))
+    assert a.shape == (2, 20, 128) and torch.isfinite(a).all()
+
+
+def test_vocoder_wav2spec_roundtrip_interfaces(dev):
+    """NsfHifiGAN.wav2spec (nsf_hifigan.py:91-107) natural-log and log10 variants vs the oracle; spec2wav output length."""
+    from oracle import mel_ref, nsf_hifigan_ref
+    h = nsf_hifigan_ref.CONFIG_V1
+    gsd = nsf_hifigan_ref.seeded_generator_state(55, h)
+    g = load("mel")
+    for nat in (True, False):
+        voc = _vocoder(h, gsd, dev, use_natural_log=nat)
+        out = voc.wav2spec(g["wav"].to(dev))
+        ref = mel_ref.wav2spec(g["wav"], use_natural_log=nat)
+        assert out.shape == ref.shape and abs_err(out.cpu(), ref) < 2e-3   # log of an fp32 magnitude near the 1e-5 clamp
+        out_ks = voc.wav2spec(g["wav"].to(dev), key_shift=3)
+        assert abs_err(out_ks.cpu(), mel_ref.wav2spec(g["wav"], use_natural_log=nat, key_shift=3.0)) < 2e-3
+    voc.model.rng = "philox"
+    wav = voc.spec2wav(out.contiguous(), synth_f0(out.shape[1]).to(dev))
+    assert wav.shape == (out.shape[1] * 512,) and torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
+
+
+def test_ragged_batch_with_masks_equals_individual_runs(dev):
+    """BASELINE configs[3] in miniature: utterances of different lengths padded into one batch with x_masks / cond_masks
+    (diffsinger.py:42-55) must give, on their valid frames, what each utterance gives alone -- for the denoiser call."""
+    cfg = WN_SMALL
+    sd = wavenet_sd(cfg, 101)
+    net = _wavenet(cfg, sd, dev)
+    lens = [130, 97, 64]
+    g = torch.Generator().manual_seed(8)
+    B, T = len(lens), max(lens)
+    x, cond = torch.randn(B, 128, T, generator=g), torch.randn(B, 256, T, generator=g)
+    t = torch.tensor([421.0])
+    masks = torch.zeros(B, T, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        masks[b, n:] = True
+    out = net(x.to(dev), t.to(dev), cond.to(dev), x_masks=masks.to(dev), cond_masks=masks.to(dev)).cpu()
+    with torch.no_grad():
+        ref = _oracle_den(sd, cfg)(x, t, cond, masks, masks)
+    assert rel_err(out, ref) < 2e-5
+    for b, n in enumerate(lens):
+        assert (out[b, :, n:] == 0).all()

@@ -31,7 +31,7 @@ lib.fdx_debug_trace(C.c_void_p(buf.data_ptr()), NL, CAP)
 net(x, t, cond)
 torch.cuda.synchronize()
 lib.fdx_debug_trace(None, 0, 0)
-tr = buf.cpu().numpy().reshape(NL, CAP, 4, 8)
+tr = buf.cpu().numpy().reshape(NL, CAP * 4, 8)  # 4 waves per workgroup
 names = ["setup+prefetch", "K loop", "LDS write", "barrier wait", "epilogue"]
 print(f"{'launch':>6} {'waves':>6} {'span':>8} | " + " ".join(f"{n:>14}" for n in names) + " | total/wave   (shader cycles, mean over waves; span = last end - first start)")
 for l in range(NL):
