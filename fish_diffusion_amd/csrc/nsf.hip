@@ -8,10 +8,14 @@
 //                                                                            residual / MRF-mean fused in the epilogue
 //   wav  = tanh(conv_post(lrelu(x, 0.01)))                                  VALU (1 output channel)
 #include "common.hip.h"
+
+#include <cstdlib>
 #include "elementwise.hip.h"
 #include "nsf_kernels.hip.h"
 
 using namespace fdx;
+
+static long kNoSplitMinWgs = 512;   // FDX_NOSPLIT_MIN_WGS overrides (tuning knob, read once)
 
 // ================================================================================================ layout
 static int nsf_validate(const fdx_nsf_desc* d) {
@@ -186,6 +190,7 @@ extern "C" int fdx_nsf_attach(fdx_handle h, const fdx_nsf_desc* d, const void* d
   NsfLayout l;
   nsf_layout(*d, l);
   if (!dev || bytes != l.total_floats * sizeof(float)) return fail(h, FDX_E_ARG, "packed arena size mismatch");
+  if (const char* e = getenv("FDX_NOSPLIT_MIN_WGS")) kNoSplitMinWgs = atol(e);
   h->nd = *d; h->nl = l; h->nsf_arena = static_cast<const float*>(dev); h->nsf_ok = true;
   h->vB = h->vT = 0;
   return FDX_OK;
@@ -200,8 +205,38 @@ static hipError_t run_conv(const float* arena, const PackedW& p, int B, int T, c
   const float4* Wp = reinterpret_cast<const float4*>(arena + p.w_off);
   const long wg_nosplit = (long)B * ((T + 255) / 256) * p.n_mtiles;
   if (p.RB == 1) return launch_convgemm<1, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
-  if (wg_nosplit >= 512 || p.cin8 * p.taps < 4) return launch_convgemm<2, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
+  if (wg_nosplit >= kNoSplitMinWgs || p.cin8 * p.taps < 4) return launch_convgemm<2, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
   return launch_convgemm<2, true, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
+}
+
+// ================================================================================================ noise convs
+template <int K>
+static void launch_noise_win(float* y, long y_bs, int ldy, const float* har, long har_bs, const float* w, const float* bias, int C,
+                             int L, int stride, int pad, int B, hipStream_t s) {
+  // enough channel groups to give every CU a few workgroups; each group re-reads its K-sample windows
+  const int col_blocks = (L + 255) / 256;
+  int groups = 1;
+  while (groups < C && (long)col_blocks * groups * B < 1024) groups *= 2;
+  const int CG = (C + groups - 1) / groups;
+  hipLaunchKernelGGL(k_noise_conv_add_win<K>, dim3(col_blocks, (C + CG - 1) / CG, B), dim3(256), 0, s, y, y_bs, ldy, har, har_bs, w,
+                     bias, C, CG, L, stride, pad);
+}
+
+static void launch_noise_conv(float* y, long y_bs, int ldy, const float* har, long har_bs, const float* w, const float* bias, int C,
+                              int L, int K, int stride, int pad, int B, hipStream_t s) {
+  switch (K) {
+    case 128: return launch_noise_win<128>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    case 64: return launch_noise_win<64>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    case 32: return launch_noise_win<32>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    case 16: return launch_noise_win<16>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    case 8: return launch_noise_win<8>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    case 4: return launch_noise_win<4>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    case 2: return launch_noise_win<2>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    case 1: return launch_noise_win<1>(y, y_bs, ldy, har, har_bs, w, bias, C, L, stride, pad, B, s);
+    default:   // any other geometry: one thread per (channel, sample), K-loop over memory
+      hipLaunchKernelGGL(k_noise_conv_add, dim3((L + 255) / 256, C, B), dim3(256), 0, s, y, y_bs, ldy, har, har_bs, w, bias, C, L, K,
+                         stride, pad);
+  }
 }
 
 // ================================================================================================ buffers
@@ -339,8 +374,7 @@ extern "C" int fdx_nsf_forward(fdx_handle h, const float* mel, const float* f0, 
       FDX_HIP(h, (run_conv<true>(A, st.ups, B, x_L, x, x_bs, x_ld, st.ups_shift0, 1, 0.1f, e, s)));
     }
     // x = x + noise_convs[i](har_source)
-    hipLaunchKernelGGL(k_noise_conv_add, dim3((g.L + 255) / 256, st.cout, B), dim3(256), 0, s, U, bs, g.ld, har, (long)ldL,
-                       A + st.nc_w, A + st.nc_b, st.cout, g.L, st.nc_k, st.nc_stride, st.nc_pad);
+    launch_noise_conv(U, bs, g.ld, har, (long)ldL, A + st.nc_w, A + st.nc_b, st.cout, g.L, st.nc_k, st.nc_stride, st.nc_pad, B, s);
     for (int j = 0; j < nk; ++j) {
       const int k = d.resblock_kernel_sizes[j];
       const float* cur = U;   // running x of this resblock

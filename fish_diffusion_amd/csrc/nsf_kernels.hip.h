@@ -197,6 +197,34 @@ static __global__ void k_noise_conv_add(float* __restrict__ y, long y_bs, int ld
   y[o] = y[o] + (acc + bias[c]);
 }
 
+// Register-window variant: thread n keeps its K-sample window of the source in VGPRs (loaded once, 16-byte loads) and
+// walks a group of CG channels; the weights are wave-uniform (scalar loads, SGPR operands of the FMAs) and the y
+// read-modify-write is coalesced across the wave.  Same summation order as k_noise_conv_add (k ascending).
+// Stage 0 of config_v1 (C=256, K=128, stride 64): 804 us -> tens of us.
+template <int K>
+static __global__ __launch_bounds__(256) void k_noise_conv_add_win(float* __restrict__ y, long y_bs, int ldy,
+                                                                   const float* __restrict__ har, long har_bs,
+                                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                                   int C, int CG, int Lout, int stride, int pad) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CG;
+  float h[K];
+  const float* hp = har + b * har_bs + (long)min(n, Lout - 1) * stride - pad;   // clamp: overhang lanes read valid memory
+#pragma unroll
+  for (int k = 0; k < K; ++k) h[k] = hp[k];
+  if (n >= Lout) return;
+  const int c1 = min(C, c0 + CG);
+  for (int c = c0; c < c1; ++c) {
+    const float* wp = w + (long)c * K;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc += wp[k] * h[k];
+    const long o = b * y_bs + (long)c * ldy + n;
+    y[o] = y[o] + (acc + bias[c]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ conv_post
 // wav[b][n] = tanh(bias + sum_c sum_k w[c][k] * lrelu(x[b][c][n + k - 3], 0.01))   (models.py:434-436)
 static __global__ void k_conv_post(float* __restrict__ wav, long wav_bs, const float* __restrict__ x, long x_bs, int ldx,
