@@ -18,6 +18,9 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // multiple of `cols` (tile overhang) plus kHalo more.  Always a multiple of 32 floats (128 B).
 inline int padded_ld(int T, int cols = 256) { return kHalo + round_up(T, cols) + kHalo; }
 
+// bumped whenever any DevBuf (re)allocates: cached hipGraphs bake buffer addresses in, so their keys include it
+inline uint64_t g_alloc_generation = 0;
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -34,6 +37,7 @@ struct DevBuf {
       hipError_t e = hipMalloc(&p, bytes);
       if (e != hipSuccess) { p = nullptr; return e; }
       cap = bytes;
+      ++g_alloc_generation;
     }
     if (zero && bytes) return hipMemsetAsync(p, 0, bytes, s);
     return hipSuccess;
@@ -97,8 +101,13 @@ struct fdx_ctx {
   bool cond_masked = false; int condraw_ld = 0;
   fdx::DevBuf tdev, E, Hm, S0, S;      // step-embedding pipeline; ldn below
   int n_emb = 0, ldn = 0;
+  // ---- sampler body as a cached hipGraph (wavenet.hip: fdx_sampler_run)
+  struct GraphEntry { uint64_t key; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;
+  bool use_graphs = true;
   // ---- sampler state (padded [B][M][ld])
-  fdx::DevBuf sx, sxt, sbase, sm[2], shist[4], seps2, snoise;
+  fdx::DevBuf sx, sxt, sbase, sm[2], shist[4], seps2, snoise, maskbuf;
   std::vector<float> ts_host;
 
   // ---- nsf

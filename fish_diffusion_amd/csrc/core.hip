@@ -2,6 +2,7 @@
 #include "common.hip.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 using namespace fdx;
 
@@ -33,6 +34,7 @@ extern "C" int fdx_create(int device, fdx_handle* out) {
   fdx_ctx* h = new (std::nothrow) fdx_ctx();
   if (!h) return fail(nullptr, FDX_E_NOMEM, "out of host memory");
   h->device = device;
+  if (const char* e = getenv("FDX_NO_GRAPH")) h->use_graphs = !(e[0] && e[0] != '0');
   *out = h;
   return FDX_OK;
 }
@@ -40,6 +42,8 @@ extern "C" int fdx_create(int device, fdx_handle* out) {
 extern "C" int fdx_destroy(fdx_handle h) {
   if (!h) return FDX_OK;
   (void)hipSetDevice(h->device);
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   for (auto e : h->prof.start) (void)hipEventDestroy(e);
   for (auto e : h->prof.stop) (void)hipEventDestroy(e);
   delete h;

@@ -345,50 +345,23 @@ extern "C" int fdx_randn(fdx_handle h, float* out, size_t n, uint64_t seed, uint
   return FDX_OK;
 }
 
-extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_rows, float* x, const float* step_noise,
-                               uint64_t seed, const uint8_t* x_mask, fdx_stream st) {
-  if (!h) return FDX_E_ARG;
-  if (!h->wn_ok || !h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run: call attach + prepare first");
-  if (!tab || n_rows <= 0 || !x) return fail(h, FDX_E_ARG, "fdx_sampler_run: bad table / x");
-  if (kind != FDX_SAMPLER_NAIVE && kind != FDX_SAMPLER_UNIPC && kind != FDX_SAMPLER_PLMS)
-    return fail(h, FDX_E_NOIMPL, "Unknown noise predictor: %d", kind);
-  hipStream_t s = as_stream(st);
-  FDX_HIP(h, hipSetDevice(h->device));
+// The sampler body (every denoiser call + update rule of one run) as a stream of launches on `s`.  All buffers exist
+// and every scalar is a kernel argument, so the same code is used to run eagerly and to record a hipGraph.
+static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, const float* step_noise, uint64_t seed,
+                        const uint8_t* x_mask, hipStream_t s) {
   const int M = h->wd.mel_channels, B = h->B, T = h->T, ld = h->ld;
   const long bs = (long)M * ld;
   const size_t bytes = (size_t)B * M * ld * sizeof(float);
   const dim3 grid = ew_grid(T, B * M), blk(kEwBlock);
-
-  // ---- timesteps of every model evaluation, embedded in one batch
-  std::vector<float>& ts = h->ts_host;   // context-owned: outlives the (pageable, staged) async copy
-  ts.clear();
-  for (int r = 0; r < n_rows; ++r) ts.push_back(tab[(size_t)r * FDX_ROW]);
-  if (kind == FDX_SAMPLER_PLMS) ts.push_back(tab[1]);   // t_prev of the first step (diffusion.py:285)
-  FDX_HIP(h, h->tdev.ensure(ts.size() * 4, false, s));
-  FDX_HIP(h, hipMemcpyAsync(h->tdev.p, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, s));
-  if (int rc = wn_embed(h, h->tdev.f(), (int)ts.size(), s)) return rc;
-
-  FDX_HIP(h, h->sx.ensure(bytes, true, s));
   float* sx = h->sx.f() + kHalo;
   float* eps = h->EPS.f() + kHalo;
-  hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, sx, bs, ld, x, (long)M * T, T, M, T, 1.f, (const uint8_t*)nullptr);
   auto model = [&](const float* xin, int col, bool masked) {
-    const float* P = nullptr;
-    if (!masked && h->cond_masked) {   // the one unmasked call of PLMS: conditioner slab of the unmasked conditioner
-      const auto& d = h->wd;
-      if (h->P2.ensure((size_t)B * d.residual_layers * 2 * d.residual_channels * ld * sizeof(float), false, s) != hipSuccess)
-        return fail(h, FDX_E_NOMEM, "out of device memory for the unmasked conditioner slab");
-      if (int rc = wn_cond_slab(h, h->condraw.f(), h->P2.f(), s)) return rc;
-      P = h->P2.f();
-    }
+    // the one unmasked call of PLMS uses the conditioner slab of the UNMASKED conditioner (built in the set-up phase)
+    const float* P = (!masked && h->cond_masked) ? h->P2.f() : nullptr;
     return wn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, P);
   };
 
   if (kind == FDX_SAMPLER_UNIPC) {
-    FDX_HIP(h, h->sxt.ensure(bytes, true, s));
-    FDX_HIP(h, h->sbase.ensure(bytes, true, s));
-    for (auto& b : h->sm) FDX_HIP(h, b.ensure(bytes, true, s));
-    FDX_HIP(h, h->seps2.ensure(bytes, true, s));
     float* xt = h->sxt.f() + kHalo; float* xb = h->sbase.f() + kHalo;
     float* m0 = h->sm[0].f() + kHalo; float* m1 = h->sm[1].f() + kHalo; float* mt = h->seps2.f() + kHalo;
     if (int rc = model(sx, 0, true)) return rc;
@@ -409,7 +382,6 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
     }
   } else if (kind == FDX_SAMPLER_NAIVE) {
     const size_t n_el = (size_t)B * M * T;
-    if (!step_noise) FDX_HIP(h, h->snoise.ensure(n_el * 4, false, s));
     for (int r = 0; r < n_rows; ++r) {
       const float* row = tab + (size_t)r * FDX_ROW;
       if (int rc = model(sx, r, true)) return rc;
@@ -419,9 +391,6 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
                          row[4], row[5]);
     }
   } else {  // PLMS
-    FDX_HIP(h, h->sxt.ensure(bytes, true, s));
-    FDX_HIP(h, h->seps2.ensure(bytes, true, s));
-    for (auto& b : h->shist) FDX_HIP(h, b.ensure(bytes, true, s));
     float* xp = h->sxt.f() + kHalo; float* prime = h->seps2.f() + kHalo;
     // hist[0] = newest stored eps (noise_list[-1]) ... hist[2] = noise_list[-3]; `cur` takes this step's eps
     float* hist[3] = {h->shist[0].f() + kHalo, h->shist[1].f() + kHalo, h->shist[2].f() + kHalo};
@@ -445,7 +414,104 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
       if (n_hist < 3) ++n_hist;
     }
   }
-  hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, x, (long)M * T, T, sx, bs, ld, M, T, 1.f, (const uint8_t*)nullptr);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
+
+static uint64_t fnv1a(const void* p, size_t n, uint64_t hsh = 1469598103934665603ULL) {
+  const unsigned char* c = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; ++i) { hsh ^= c[i]; hsh *= 1099511628211ULL; }
+  return hsh;
+}
+
+extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_rows, float* x, const float* step_noise,
+                               uint64_t seed, const uint8_t* x_mask, fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  if (!h->wn_ok || !h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run: call attach + prepare first");
+  if (!tab || n_rows <= 0 || !x) return fail(h, FDX_E_ARG, "fdx_sampler_run: bad table / x");
+  if (kind != FDX_SAMPLER_NAIVE && kind != FDX_SAMPLER_UNIPC && kind != FDX_SAMPLER_PLMS)
+    return fail(h, FDX_E_NOIMPL, "Unknown noise predictor: %d", kind);
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const auto& d = h->wd;
+  const int M = d.mel_channels, B = h->B, T = h->T, ld = h->ld;
+  const long bs = (long)M * ld;
+  const size_t bytes = (size_t)B * M * ld * sizeof(float);
+  const dim3 grid = ew_grid(T, B * M), blk(kEwBlock);
+
+  // ---------------------------------------------------------------- set-up (eager): buffers, step embeddings, x -> sx
+  // timesteps of every model evaluation, embedded in one batch
+  std::vector<float>& ts = h->ts_host;   // context-owned: outlives the (pageable, staged) async copy
+  ts.clear();
+  for (int r = 0; r < n_rows; ++r) ts.push_back(tab[(size_t)r * FDX_ROW]);
+  if (kind == FDX_SAMPLER_PLMS) ts.push_back(tab[1]);   // t_prev of the first step (diffusion.py:285)
+  FDX_HIP(h, h->tdev.ensure(ts.size() * 4, false, s));
+  FDX_HIP(h, hipMemcpyAsync(h->tdev.p, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, s));
+  if (int rc = wn_embed(h, h->tdev.f(), (int)ts.size(), s)) return rc;
+
+  FDX_HIP(h, h->sx.ensure(bytes, true, s));
+  if (kind == FDX_SAMPLER_UNIPC) {
+    FDX_HIP(h, h->sxt.ensure(bytes, true, s));
+    FDX_HIP(h, h->sbase.ensure(bytes, true, s));
+    for (auto& b : h->sm) FDX_HIP(h, b.ensure(bytes, true, s));
+    FDX_HIP(h, h->seps2.ensure(bytes, true, s));
+  } else if (kind == FDX_SAMPLER_NAIVE) {
+    if (!step_noise) FDX_HIP(h, h->snoise.ensure((size_t)B * M * T * 4, false, s));
+  } else {
+    FDX_HIP(h, h->sxt.ensure(bytes, true, s));
+    FDX_HIP(h, h->seps2.ensure(bytes, true, s));
+    for (auto& b : h->shist) FDX_HIP(h, b.ensure(bytes, true, s));
+    if (h->cond_masked) {   // conditioner slab of the unmasked conditioner for the one unmasked call
+      FDX_HIP(h, h->P2.ensure((size_t)B * d.residual_layers * 2 * d.residual_channels * ld * sizeof(float), false, s));
+      if (int rc = wn_cond_slab(h, h->condraw.f(), h->P2.f(), s)) return rc;
+    }
+  }
+  hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, h->sx.f() + kHalo, bs, ld, x, (long)M * T, T, M, T, 1.f, (const uint8_t*)nullptr);
+  if (x_mask) {   // private copy: a stable address for the recorded graph, whatever tensor the caller passes next time
+    FDX_HIP(h, h->maskbuf.ensure((size_t)B * T, false, s));
+    FDX_HIP(h, hipMemcpyAsync(h->maskbuf.p, x_mask, (size_t)B * T, hipMemcpyDeviceToDevice, s));
+    x_mask = static_cast<const uint8_t*>(h->maskbuf.p);
+  }
+
+  // ---------------------------------------------------------------- body: eager, or one hipGraph launch
+  // ~42 launches per step x 100 steps cost the host ~45 ms per run when issued one by one (half of the GPU time at
+  // 10 s / batch 1, more than the GPU time for short utterances).  The body only depends on (sampler, table, geometry,
+  // buffer addresses), so it is recorded once per such key on a private capture stream and replayed with one
+  // hipGraphLaunch on the caller's stream.  Not graphed: profiling runs (per-dispatch events) and the DDPM sampler (its
+  // per-step noise is either a caller tensor whose address changes or a Philox seed that is a kernel argument).
+  const bool graphable = h->use_graphs && !h->prof.on && kind != FDX_SAMPLER_NAIVE;
+  if (!graphable) {
+    if (int rc = sampler_body(h, kind, tab, n_rows, step_noise, seed, x_mask, s)) return rc;
+  } else {
+    uint64_t key = fnv1a(tab, (size_t)n_rows * FDX_ROW * sizeof(float));
+    const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
+                              (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, g_alloc_generation};
+    key = fnv1a(parts, sizeof parts, key);
+    fdx_ctx::GraphEntry* hit = nullptr;
+    for (auto& g : h->graphs) if (g.key == key) hit = &g;
+    if (!hit) {
+      if (!h->cap_stream) FDX_HIP(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+      hipGraph_t graph = nullptr;
+      FDX_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+      const int rc = sampler_body(h, kind, tab, n_rows, step_noise, seed, x_mask, h->cap_stream);
+      const hipError_t ec = hipStreamEndCapture(h->cap_stream, &graph);
+      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      FDX_HIP(h, ec);
+      hipGraphExec_t exec = nullptr;
+      FDX_HIP(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      if (h->graphs.size() >= 4) {   // small FIFO cache: keys change only with geometry / schedule / reallocation
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        h->graphs.erase(h->graphs.begin());
+      }
+      h->graphs.push_back({key, exec});
+      hit = &h->graphs.back();
+    }
+    FDX_HIP(h, hipGraphLaunch(hit->exec, s));
+  }
+
+  // ---------------------------------------------------------------- finish (eager): sx -> x
+  hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, x, (long)M * T, T, h->sx.f() + kHalo, bs, ld, M, T, 1.f, (const uint8_t*)nullptr);
   FDX_HIP(h, hipGetLastError());
   return FDX_OK;
 }
