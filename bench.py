@@ -99,10 +99,41 @@ def synth_inputs(B, T, device, seed):
     return feats.to(device), f0[None].repeat(B, 1).contiguous().to(device)
 
 
-def one_step(diff, voc, feats, f0, interval):
-    mel = diff(feats, sampler_interval=interval)                       # [B, T, M] (log10-scale mel, diff_svc_v2)
-    wav = voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)      # spec2wav for a batch (nsf_hifigan.py:72-85)
+def one_step(diff, voc, feats, f0, interval, streams=None):
+    """One utterance batch: sampler, then vocoder.  With `streams` = (s_den, s_voc) the two stages are enqueued on
+    separate HIP streams (vocoder waits on an event): consecutive steps are independent utterances, so the vocoder of
+    step k overlaps the sampler of step k+1 and fills the CUs the batch-1 denoiser leaves idle (224 tiles / 256 CUs)."""
+    if streams is None:
+        mel = diff(feats, sampler_interval=interval)                       # [B, T, M] (log10-scale mel, diff_svc_v2)
+        return voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)     # spec2wav for a batch (nsf_hifigan.py:72-85)
+    s_den, s_voc = streams
+    with torch.cuda.stream(s_den):
+        mel = diff(feats, sampler_interval=interval)
+        done = torch.cuda.Event()
+        done.record(s_den)
+    with torch.cuda.stream(s_voc):
+        s_voc.wait_event(done)
+        mel.record_stream(s_voc)
+        wav = voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)
     return wav
+
+
+def pmc_traffic(batch: int, T: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.py ->
+    profiles/*_pmc_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so bench.py cannot collect them
+    itself).  Only valid for the configuration the counters were collected on (batch 1, T = 861)."""
+    if batch != 1 or T != 861:
+        return None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    for k, v in d["kernels"].items():
+        if "EpiGate" in k:
+            return v["hbm_bytes"], os.path.relpath(files[-1], ROOT)
+    return None, None
 
 
 def usable_cores() -> int:
@@ -158,6 +189,9 @@ def main():
     ap.add_argument("--interval", type=int, default=10, help="sampler_interval: 10 => 100 UniPC steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=10)
+    ap.add_argument("--overlap", action="store_true", help="sampler and vocoder on separate HIP streams (vocoder of utterance k "
+                    "overlaps the sampler of k+1).  Measured on MI355X: 96.3 vs 95.0 ms per step -- no gain, the co-running "
+                    "vocoder kernels slow the denoiser's by as much as they hide; off by default.")
     ap.add_argument("--no-prof", action="store_true", help="do not time the dominant kernel with HIP events")
     ap.add_argument("--prof-stride", type=int, default=7, help="time every N-th launch of the dominant kernel (7 is co-prime "
                     "with the 20 layers, so every layer / dilation is sampled)")
@@ -193,17 +227,19 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev)) if args.overlap else None
+    if streams:   # inputs were produced on the default stream
+        for st_ in streams:
+            st_.wait_stream(torch.cuda.current_stream(dev))
     for _ in range(args.warmup):
-        one_step(diff, voc, feats, f0, args.interval)
+        one_step(diff, voc, feats, f0, args.interval, streams)
     sync_barrier()
-    pair_ms = C.c_double(0.0)
     if not args.no_prof:
-        _lib.check(_lib.lib().fdx_prof_calibrate(eng.h, _lib.stream_ptr(dev), C.byref(pair_ms)), eng.h)
         _lib.check(_lib.lib().fdx_prof_enable(eng.h, args.prof_stride), eng.h)
         sync_barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wav = one_step(diff, voc, feats, f0, args.interval)
+        wav = one_step(diff, voc, feats, f0, args.interval, streams)
     sync_barrier()
     dt = time.perf_counter() - t0
     dt = fdist.barrier_max(dt, dev)
@@ -216,9 +252,13 @@ def main():
         if n.value:
             avg_ms = raw_ms = ms.value / n.value   # per-dispatch begin/end stamps (hipExtLaunchKernel events)
             ach = fl.value / (avg_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(args.batch, T)
+            C_, M_ = WN_CFG["residual_channels"], args.batch * T
+            alg_bytes = 4 * (2 * C_ * 3 * C_ + C_ * M_ + 2 * C_ * M_ + C_ * M_)   # weights + Y in + conditioner slab in + Z out
             roofline = {"bound": "mfma", "kernel": "convgemm_kernel<2,splitK,EpiGate> (dilated conv k=3 + gate, residual block)",
                         "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-                        "traffic": None, "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch", "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                        "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch", "avg_launch_us": round(avg_ms * 1e3, 2),
                         "timing": "hipExtLaunchKernel start/stop events on the launch stream, timed region",
                         "flops_per_launch": fl.value}
 
@@ -246,7 +286,9 @@ def main():
         "config": {"workload": f"svc_hubert_soft (diff_svc_v2 WaveNet C=512 x 20 layers) {n_steps}-step UniPC + NSF-HiFiGAN config_v1 (hop 512), "
                                f"batch={args.batch} x {args.seconds:g} s @44.1 kHz (T={T}) per GPU",
                    "batch_per_gpu": args.batch, "frames": T, "sampler": "unipc", "sampler_steps": n_steps,
-                   "parallelism": f"utterance-sharded x{world} (no per-step collective)"},
+                   "parallelism": f"utterance-sharded x{world} (no per-step collective)",
+                   "streams": "sampler and vocoder on separate HIP streams (vocoder of utterance k overlaps sampler of k+1)"
+                              if streams else "single stream"},
         "per_gpu": round(value / world, 3), "x_realtime_per_gpu": round(value / world, 3),
         "stages_ms": {"denoise": round(den_ms, 2), "vocoder": round(voc_ms, 2)},
         "end_to_end": {"tflops": round(e2e_tflops, 3), "frac_of_f32_peak": round(e2e_tflops / PEAK_F32_TFLOPS, 4),

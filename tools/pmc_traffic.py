@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the dominant kernels from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected
+in SEPARATE runs: they do not fit one pass on gfx950's 4 TCC counters).
+
+    python tools/pmc_traffic.py <fetch_db> <write_db> > profiles/rNN_pmc_traffic.json
+
+Units and corrections, per /opt/skills/guides/MI355X_MICROARCH.md section HBM: both counters are in KiB-like units of
+1024 B as reported by rocprofv3; on gfx950 FETCH_SIZE counts 128-byte requests at 64 B, i.e. reports half of the bytes
+of wide coalesced reads -> fetch_bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is used as reported (it matches the
+kernel's algorithmic store volume exactly: 1728 KiB = 512 x 864 x 4 B for the gate kernel)."""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    rows = c.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name",
+                     (counter,)).fetchall()
+    return {k: (n, v) for k, n, v in rows}
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"source": {"fetch_db": sys.argv[1], "write_db": sys.argv[2]},
+           "note": "bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024",
+           "kernels": {}}
+    for k in fetch:
+        if "convgemm" not in k:
+            continue
+        n, f = fetch[k]
+        w = write.get(k, (0, 0.0))[1]
+        out["kernels"][k.replace("void ", "").replace("fdx::", "")] = {
+            "launches": n, "FETCH_SIZE": round(f, 1), "WRITE_SIZE": round(w, 1),
+            "fetch_bytes": int(2 * f * 1024), "write_bytes": int(w * 1024), "hbm_bytes": int(2 * f * 1024 + w * 1024)}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
