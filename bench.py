@@ -223,7 +223,7 @@ def main():
 
     def sync_barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -304,7 +304,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -301,13 +301,16 @@ struct EpiLogMel {  // audio.py:11-18 + nsf_hifigan.py:104-105
 // Accumulator element r of a 32x32 tile sits at row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31.
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4>
+template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4, int MT = 1>
 __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) {
   static_assert(NW == 4 || (SPLITK && NW == 8), "4 waves per workgroup, or 8 K-splitting waves (2 per SIMD)");
   static_assert(!Epi::kPaired || RB == 2, "paired epilogues need both row blocks");
+  static_assert(MT == 1 || (SPLITK && MT == 2), "MT = 2 (two packed m-tiles per workgroup) is a split-K variant");
   constexpr int NB = 2;                       // two 32-column MFMA blocks per wave tile (interleaved columns)
-  constexpr int Q = RB * NB * 16;             // accumulator registers per lane
-  __shared__ float red[SPLITK ? NW * Q * kWave : 1];
+  constexpr int RBX = MT * RB;                // 32-row accumulator blocks per wave: (m-tile mtl, row block rb) = (x / RB, x % RB)
+  constexpr int V = RBX * NB;                 // accumulator values per (lane, accumulator row r)
+  constexpr int ROWS = Epi::kPaired ? 32 : 32 * RB;   // logical rows per packed m-tile
+  __shared__ float red[SPLITK ? NW * V * 16 * kWave : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,15 +321,15 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
   const int G = gridDim.x, bid = blockIdx.x;
   const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
   const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int mt = L / a.n_tiles_n;
-  const int nt = L - mt * a.n_tiles_n;
+  const int mtg = L / a.n_tiles_n;            // group of MT consecutive packed m-tiles
+  const int nt = L - mtg * a.n_tiles_n;
   const int item = nt / a.tiles_per_item;
   const int tile_in_item = nt - item * a.tiles_per_item;
   constexpr int COLS = SPLITK ? 64 : 256;
   const int t0 = tile_in_item * COLS + (SPLITK ? 0 : wave * 64);
   const int tc = t0 + 2 * li;                 // this lane's column pair (tc, tc+1)
   const bool col_ok = tc < a.T, col_two = tc + 1 < a.T;
-  const int row_base = mt * (Epi::kPaired ? 32 : 32 * RB);
+  const int row_base = mtg * MT * ROWS;
 
   int it_begin = 0, it_end = a.n_it;
   if (SPLITK) {
@@ -337,41 +340,43 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
 
   // ---- split-K: the epilogue sites of this wave are static -> their global reads are issued right after the pipeline's
   // first operand loads (so they do not delay the K loop's start) and land behind the K loop.
-  // The tile's epilogue sites (accumulator row r [x row block rb when unpaired]) are dealt to the NW waves in order:
-  // site s = wave*NS + i; paired / RB=1: r = s; unpaired RB=2: rb = s / 16, r = s % 16.
-  constexpr int NS = SPLITK ? ((Epi::kPaired || RB == 1) ? 16 / NW : 32 / NW) : 1;
+  // The tile's sites are dealt to the NW waves in order, site s = wave*NS + i:
+  //   paired / RB=1: m-tile s >> 4, accumulator row r = s & 15;   unpaired RB=2: m-tile s >> 5, row block (s >> 4) & 1, r = s & 15.
+  constexpr int NS = SPLITK ? ((Epi::kPaired || RB == 1) ? MT * 16 / NW : MT * 32 / NW) : 1;
+  auto site_row = [&](int sidx) {             // first logical row of the 32-row block the site lives in, + its row inside
+    const int blk = sidx >> 4, r = sidx & 15;
+    const int mtl = (Epi::kPaired || RB == 1) ? blk : (blk >> 1);
+    const int rb = (Epi::kPaired || RB == 1) ? 0 : (blk & 1);
+    return row_base + mtl * ROWS + rb * 32 + acc_row(r, half);
+  };
   typename Epi::Pre pre[NS];
   auto prefetch_epilogue = [&]() {
     if constexpr (SPLITK) {
       if (col_ok) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-          const int sidx = wave * NS + i;
-          const int rb = (!Epi::kPaired && RB == 2) ? (sidx >> 4) : 0;
-          const int r = sidx & 15;
-          pre[i] = epi.load(item, row_base + rb * 32 + acc_row(r, half), tc, col_two);
-        }
+        for (int i = 0; i < NS; ++i) pre[i] = epi.load(item, site_row(wave * NS + i), tc, col_two);
       }
     }
   };
 
-  f32x16 acc[RB][NB];
+  f32x16 acc[RBX][NB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int x = 0; x < RBX; ++x)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[x][nb][r] = 0.f;
 
   const bool active = SPLITK ? true : (t0 < a.T);   // whole-wave overhang tiles skip the K loop
   if (active && it_begin < it_end) {
-    struct Stage { float4 a[RB]; f2 b[4]; };
+    struct Stage { float4 a[RBX]; f2 b[4]; };
     // Wave-uniform bases (SGPR pairs) + 32-bit byte cursors (SGPR) + per-lane 32-bit byte offsets (VGPR).  The cursors
     // saturate at the wave's last K iteration, so the pipeline's run-ahead loads are unconditional and never leave
     // this wave's K range (the over-run re-reads the last iteration: L1 hits, values unused).
     const int n = it_end - it_begin;
     const int cb0 = it_begin / a.taps, tap0 = it_begin - cb0 * a.taps;
-    const char* Abase = reinterpret_cast<const char*>(a.Wp + ((long)mt * a.n_it + it_begin) * (RB * 64));
+    const char* Abase = reinterpret_cast<const char*>(a.Wp + ((long)mtg * MT * a.n_it + it_begin) * (RB * 64));
+    const unsigned mt_stride = (unsigned)a.n_it * (RB * 1024u);           // bytes between consecutive packed m-tiles
     const char* Xbase = reinterpret_cast<const char*>(a.X + item * a.x_bstride + a.shift0 + t0);
     const unsigned rs = (unsigned)a.ldx * 4u;                  // bytes between channels
     const unsigned d_tap = (unsigned)a.dshift * 4u;            // next tap, same channel block
@@ -388,7 +393,8 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
 
     auto load = [&](Stage& s) {
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) s.a[rb] = *reinterpret_cast<const float4*>(Abase + (a_off + a_lane + rb * 1024u));
+      for (int x = 0; x < RBX; ++x)
+        s.a[x] = *reinterpret_cast<const float4*>(Abase + (a_off + a_lane + (x / RB) * mt_stride + (x % RB) * 1024u));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f2u v = *reinterpret_cast<const f2u*>(Xbase + (x_off + x_lane[j]));
@@ -410,10 +416,10 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-          const float av = j == 0 ? s.a[rb].x : j == 1 ? s.a[rb].y : j == 2 ? s.a[rb].z : s.a[rb].w;
-          acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[j].x, acc[rb][0], 0, 0, 0);
-          acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[j].y, acc[rb][1], 0, 0, 0);
+        for (int x = 0; x < RBX; ++x) {
+          const float av = j == 0 ? s.a[x].x : j == 1 ? s.a[x].y : j == 2 ? s.a[x].z : s.a[x].w;
+          acc[x][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[j].x, acc[x][0], 0, 0, 0);
+          acc[x][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[j].y, acc[x][1], 0, 0, 0);
         }
       }
     };
@@ -424,12 +430,12 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
       load(L);
       compute(C);
 #pragma unroll
-      for (int k = 0; k < RB + 4; ++k) {
+      for (int k = 0; k < RBX + 4; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
         __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // a few VALU / SALU
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, RB * 8 - (RB + 4), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, RBX * 8 - (RBX + 4), 0);
       __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -461,57 +467,49 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
   FDX_STAMP(2);
 
   if (SPLITK) {
-    // ---- cross-wave K reduction through LDS, fixed summation order ((w0+w1)+w2)+w3 (deterministic).
-    // Layout red[wave][r][lane][rb*NB+nb]: a lane's RB*NB values of accumulator row r are one 16-byte (RB=2) or
-    // 8-byte (RB=1) LDS word -> ds_write_b128 / ds_read_b128, conflict-free (consecutive lanes, consecutive words).
-    constexpr int V = RB * NB;
-    typedef float fV __attribute__((ext_vector_type(V)));
-    fV* redv = reinterpret_cast<fV*>(red);
+    // ---- cross-wave K reduction through LDS, fixed summation order w0 + w1 + ... (deterministic).
+    // Layout red[wave][r][lane][x*NB + nb]: a lane's V values of accumulator row r are contiguous -> 16-byte LDS
+    // accesses, conflict-free (consecutive lanes, consecutive words).
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto ridx = [&](int w, int r) { return ((w * 16 + r) * kWave + lane) * V; };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      fV v;
+      if constexpr (V == 2) {
+        *reinterpret_cast<f2*>(red + ridx(wave, r)) = f2{acc[0][0][r], acc[0][1][r]};
+      } else {
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) v[rb * NB + nb] = acc[rb][nb][r];
-      redv[(wave * 16 + r) * kWave + lane] = v;
+        for (int q = 0; q < V / 4; ++q)   // block pair (x = 2q, 2q+1): {x nb0, x nb1, x+1 nb0, x+1 nb1}
+          *reinterpret_cast<f4*>(red + ridx(wave, r) + 4 * q) =
+              f4{acc[2 * q][0][r], acc[2 * q][1][r], acc[2 * q + 1][0][r], acc[2 * q + 1][1][r]};
+      }
     }
     FDX_STAMP(3);
     __syncthreads();
     FDX_STAMP(4);
     if (!col_ok) return;
-    if constexpr (Epi::kPaired || RB == 1) {
-      fV sum[NS];
+    if constexpr (Epi::kPaired) {
+      f4 sum[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int r = wave * NS + i;
-        sum[i] = redv[(0 * 16 + r) * kWave + lane];
+        const int sidx = wave * NS + i, mtl = sidx >> 4, r = sidx & 15;
+        sum[i] = *reinterpret_cast<const f4*>(red + ridx(0, r) + 4 * mtl);
 #pragma unroll
-        for (int w = 1; w < NW; ++w) sum[i] += redv[(w * 16 + r) * kWave + lane];
+        for (int w = 1; w < NW; ++w) sum[i] += *reinterpret_cast<const f4*>(red + ridx(w, r) + 4 * mtl);
       }
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int r = wave * NS + i;
-        if constexpr (Epi::kPaired)
-          epi.store(item, row_base + acc_row(r, half), tc, col_two, f2{sum[i][0], sum[i][1]}, f2{sum[i][2], sum[i][3]}, pre[i]);
-        else
-          epi.store(item, row_base + acc_row(r, half), tc, col_two, f2{sum[i][0], sum[i][1]}, pre[i]);
-      }
+      for (int i = 0; i < NS; ++i)
+        epi.store(item, site_row(wave * NS + i), tc, col_two, f2{sum[i][0], sum[i][1]}, f2{sum[i][2], sum[i][3]}, pre[i]);
     } else {
-      const f2* red2 = reinterpret_cast<const f2*>(red);   // [wave][r][lane][rb] pairs
       f2 sum[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int sidx = wave * NS + i, rb = sidx >> 4, r = sidx & 15;
-        sum[i] = red2[((0 * 16 + r) * kWave + lane) * 2 + rb];
+        const int sidx = wave * NS + i, blk = sidx >> 4, r = sidx & 15;   // blk = accumulator block x
+        sum[i] = *reinterpret_cast<const f2*>(red + ridx(0, r) + 2 * blk);
 #pragma unroll
-        for (int w = 1; w < NW; ++w) sum[i] += red2[((w * 16 + r) * kWave + lane) * 2 + rb];
+        for (int w = 1; w < NW; ++w) sum[i] += *reinterpret_cast<const f2*>(red + ridx(w, r) + 2 * blk);
       }
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int sidx = wave * NS + i, rb = sidx >> 4, r = sidx & 15;
-        epi.store(item, row_base + rb * 32 + acc_row(r, half), tc, col_two, sum[i], pre[i]);
-      }
+      for (int i = 0; i < NS; ++i) epi.store(item, site_row(wave * NS + i), tc, col_two, sum[i], pre[i]);
     }
     FDX_STAMP(5);
   } else {
@@ -541,7 +539,7 @@ struct ConvGeom {   // everything the launcher needs besides pointers
   int n_mtiles;     // row tiles of 32*RB logical rows (32 pairs for paired epilogues)
 };
 
-template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4>
+template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4, int MT = 1>
 inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx,
                                   float in_slope, const Epi& epi, hipStream_t s, hipEvent_t ev_start = nullptr,
                                   hipEvent_t ev_stop = nullptr) {
@@ -554,7 +552,8 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   a.n_tiles_n = g.B * a.tiles_per_item;
   a.n_mtiles = g.n_mtiles;
   a.in_slope = in_slope;
-  const int grid = a.n_tiles_n * a.n_mtiles;
+  if (g.n_mtiles % MT) return hipErrorInvalidValue;
+  const int grid = a.n_tiles_n * (a.n_mtiles / MT);
   if (grid <= 0) return hipSuccess;
 #ifdef FDX_KTRACE
   a.trace = nullptr;
@@ -562,9 +561,9 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
-    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0, a, epi);
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0, a, epi);
   else
-    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW>), dim3(grid), dim3(NW * 64), 0, s, a, epi);
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, a, epi);
   return hipGetLastError();
 }
 

@@ -32,10 +32,12 @@ def env_rank_world() -> Tuple[int, int, int]:
 def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Join the job the launcher describes (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).  No-op for world 1."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("FDX_FORCE_PROCESS_GROUP", "") not in ("", "0")   # exercise the RCCL path on a single GPU
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -74,7 +76,7 @@ def broadcast_arena(desc, kind: str, tensors: Optional[Sequence[torch.Tensor]], 
         arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
     if arena.numel() != nbytes:
         raise RuntimeError(f"{kind} arena is {arena.numel()} bytes, expected {nbytes}")
-    if world > 1:
+    if dist.is_initialized():
         dist.broadcast(arena, src=src)
     return arena
 
