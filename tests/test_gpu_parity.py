@@ -436,3 +436,33 @@ def test_ragged_batch_with_masks_equals_individual_runs(dev):
     assert rel_err(out, ref) < 2e-5
     for b, n in enumerate(lens):
         assert (out[b, :, n:] == 0).all()
+
+
+def test_long_utterance_30s_and_geometry_changes(dev):
+    """The reference slices audio into <= 30 s chunks (utils/audio.py:112-167): T = 2583 frames is the largest geometry the
+    path sees.  Also exercises buffer growth / re-zeroing and the graph cache when the geometry changes between calls."""
+    from oracle import sampler_ref
+    sd = wavenet_sd(WN_SMALL, 101)
+    diff = _diffusion(WN_SMALL, sd, dev)
+    den = _oracle_den(sd, WN_SMALL)
+    g = torch.Generator().manual_seed(30)
+    for T in (2583, 40, 2583, 861):          # grow, shrink, grow again (stale halo / stale graph would show up here)
+        feats, x0 = torch.randn(1, T, 256, generator=g), torch.randn(1, 128, T, generator=g)
+        with torch.no_grad():
+            ref = sampler_ref.diffusion_sample(den, feats, x_init=x0, sampler_interval=200)
+        for _ in range(2):                    # second call replays the recorded graph
+            mel = diff(feats.to(dev), sampler_interval=200, x_init=x0.to(dev))
+            assert rel_err(mel.cpu(), ref) < MEL_REL, T
+
+
+def test_empty_and_mismatched_inputs_raise(dev):
+    from fish_diffusion_amd import PitchAdjustableMelSpectrogram
+    net = _wavenet(WN_SMALL, wavenet_sd(WN_SMALL, 101), dev)
+    with pytest.raises(ValueError):           # zero frames: nothing to launch -- refuse instead of returning garbage
+        net(torch.zeros(1, 128, 0, device=dev), torch.zeros(1, device=dev), torch.zeros(1, 256, 0, device=dev))
+    with pytest.raises(ValueError):           # conditioner / mel length mismatch
+        net(torch.zeros(1, 128, 8, device=dev), torch.zeros(1, device=dev), torch.zeros(1, 256, 9, device=dev))
+    with pytest.raises(ValueError):           # wrong number of timesteps
+        net(torch.zeros(2, 128, 8, device=dev), torch.zeros(3, device=dev), torch.zeros(2, 256, 8, device=dev))
+    with pytest.raises(ValueError):
+        PitchAdjustableMelSpectrogram()(torch.zeros(8, device=dev))   # 1-D audio
