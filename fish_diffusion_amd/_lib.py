@@ -33,6 +33,16 @@ class NsfDesc(C.Structure):
                 ("harmonic_num", C.c_int)]
 
 
+class FeatureTerm(C.Structure):
+    _fields_ = [("kind", C.c_int), ("per_frame", C.c_int), ("preproc", C.c_int), ("_pad", C.c_int), ("values", C.c_void_p),
+                ("w", C.c_void_p), ("b", C.c_void_p), ("p0", C.c_float), ("p1", C.c_float)]
+
+
+TERM_VECTOR, TERM_EMBEDDING, TERM_SCALAR_LINEAR = 0, 1, 2
+PRE_NONE, PRE_PITCH_TO_SCALE = 0, 1
+MAX_FEATURE_TERMS = 6
+
+
 class MelDesc(C.Structure):
     _fields_ = [("sample_rate", C.c_int), ("n_fft", C.c_int), ("win_size", C.c_int), ("hop", C.c_int),
                 ("n_mels", C.c_int), ("f_min", C.c_float), ("f_max", C.c_float)]
@@ -64,6 +74,7 @@ _SIGS = {
     "fdx_mel_num_frames": (C.c_int, [C.POINTER(MelDesc), C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int)]),
     "fdx_mel_filterbank": (C.c_int, [C.POINTER(MelDesc), _P]),
     "fdx_mel_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P]),
+    "fdx_features_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm), C.c_int, _P, _P]),
     "fdx_debug_conv1d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, _P, _P]),
     "fdx_prof_enable": (C.c_int, [_P, C.c_int]),

@@ -186,6 +186,30 @@ int fdx_mel_forward(fdx_handle h, const float* wav, int B, int N, float key_shif
                     int log_mode, float* mel, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Condition front end -- replaces DiffSinger.forward_features,
+ * archs/diffsinger/diffsinger.py:57-134, for the NaiveProjection encoders of the SVC configs
+ * (modules/encoders/naive_projection.py:6-60; preprocessing utils/pitch.py:12-22).
+ *   features[b][t][:] = W_text . contents[b][t][:] + b_text  (+ term_0) (+ term_1) ...   in the order given.
+ * All pointers are device memory in the reference's own layouts (nn.Linear weight [out][in], nn.Embedding
+ * weight [n][E]); nothing is packed.
+ * ---------------------------------------------------------------------------------------------- */
+enum { FDX_TERM_VECTOR = 0,        /* values: float [B][E] (per_frame = 0) or [B][T][E] (per_frame = 1): a float speaker mix */
+       FDX_TERM_EMBEDDING = 1,     /* values: int64 ids [B]; w: table [n][E]                                              */
+       FDX_TERM_SCALAR_LINEAR = 2  /* values: float [B] or [B][T]; adds w[E] * pre(value) + b[E]  (nn.Linear(1, E))       */ };
+enum { FDX_PRE_NONE = 0, FDX_PRE_PITCH_TO_SCALE = 1 /* clamp((f0 - p0) / (p1 - p0), 0, 1), p0 = f0_min, p1 = f0_max */ };
+#define FDX_MAX_FEATURE_TERMS 6
+typedef struct {
+  int kind, per_frame, preproc, _pad;
+  const void* values;
+  const float* w;
+  const float* b;   /* may be NULL */
+  float p0, p1;
+} fdx_feature_term;
+/* contents: dev [B][T][Din]; w_text: dev [E][Din]; b_text: dev [E] or NULL; terms: HOST array; features: dev [B][T][E]. */
+int fdx_features_forward(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
+                         const float* b_text, const fdx_feature_term* terms, int n_terms, float* features, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel-level test / profiling hooks (used by tests/ and bench.py only)
  * ---------------------------------------------------------------------------------------------- */
 /* y = conv1d(act_in(x), w) + bias with "same" zero padding: x dev [B][Cin][T], w HOST [Cout][Cin][k],

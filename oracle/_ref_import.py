@@ -71,6 +71,24 @@ def available() -> bool:
 _loaded = {}
 
 
+def _diffsinger_methods():
+    """`DiffSinger.get_mask_from_lengths` and `DiffSinger.forward_features` compiled from the reference file's own source
+    (fish_diffusion/archs/diffsinger/diffsinger.py:42-134) -- the module itself imports loralib / lightning / wandb /
+    matplotlib at the top and cannot be imported here, the two methods only need torch."""
+    import ast
+    import torch
+    path = os.path.join(REFERENCE_ROOT, "fish_diffusion/archs/diffsinger/diffsinger.py")
+    with open(path) as f:
+        src = f.read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DiffSinger")
+    funcs = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("get_mask_from_lengths", "forward_features")]
+    mod = ast.Module(body=funcs, type_ignores=[])
+    ns = {"torch": torch}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["get_mask_from_lengths"], ns["forward_features"]
+
+
 def load():
     """Return a dict of the reference classes on the hot path."""
     if _loaded:
@@ -98,7 +116,7 @@ def load():
     for pkg in ("fish_diffusion", "fish_diffusion.archs", "fish_diffusion.archs.diffsinger",
                 "fish_diffusion.archs.diffsinger.diffusions", "fish_diffusion.modules",
                 "fish_diffusion.modules.vocoders", "fish_diffusion.modules.vocoders.nsf_hifigan",
-                "fish_diffusion.utils"):
+                "fish_diffusion.modules.encoders", "fish_diffusion.utils"):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = [os.path.join(REFERENCE_ROOT, *pkg.split("."))]
@@ -128,7 +146,15 @@ def load():
     pam = by_path("fish_diffusion.utils.pitch_adjustable_mel",
                   "fish_diffusion/utils/pitch_adjustable_mel.py")
 
+    enc_builder = by_path("fish_diffusion.modules.encoders.builder", "fish_diffusion/modules/encoders/builder.py")
+    naive = by_path("fish_diffusion.modules.encoders.naive_projection", "fish_diffusion/modules/encoders/naive_projection.py")
+    pitch = by_path("fish_diffusion.utils.pitch", "fish_diffusion/utils/pitch.py")
+
     _loaded.update(
+        ENCODERS=enc_builder.ENCODERS,
+        NaiveProjectionEncoder=naive.NaiveProjectionEncoder,
+        pitch_to_scale=pitch.pitch_to_scale,
+        diffsinger_methods=_diffsinger_methods,
         WaveNet=wavenet.WaveNet,
         GaussianDiffusion=diffusion.GaussianDiffusion,
         DENOISERS=diffusion.DENOISERS,

@@ -1,0 +1,84 @@
+"""CPU oracle for the condition front end.  TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+
+Functional restatement (state-dict in, features out) of
+  fish_diffusion/archs/diffsinger/diffsinger.py:42-55 (``get_mask_from_lengths``), :57-134 (``forward_features``)
+for the encoders the SVC configs build (configs/_base_/archs/diff_svc_v2.py:41-58):
+  fish_diffusion/modules/encoders/naive_projection.py:6-60 (Linear / Embedding), utils/pitch.py:12-22 (``pitch_to_scale``).
+Pinned by oracle/make_golden.py against the reference's own ``forward_features`` source (extracted from the file and
+executed unmodified on real ``NaiveProjectionEncoder`` instances; the enclosing module cannot be imported here because
+it pulls lightning / loralib / wandb at import time).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+F0_MIN, F0_MAX = 50.0, 1100.0  # utils/pitch.py:6-7
+
+
+def pitch_to_scale(f0: torch.Tensor, f0_min=F0_MIN, f0_max=F0_MAX) -> torch.Tensor:
+    """utils/pitch.py:12-22."""
+    s = (f0 - f0_min) / (f0_max - f0_min)
+    s = s.clone()
+    s[s < 0] = 0
+    s[s > 1] = 1
+    return s.unsqueeze(-1) if f0.ndim == 2 else s
+
+
+def mask_from_lengths(lengths: torch.Tensor, max_len: Optional[int] = None) -> torch.Tensor:
+    """diffsinger.py:42-55: True = padding."""
+    if max_len is None:
+        max_len = int(lengths.max())
+    ids = torch.arange(0, int(max_len)).unsqueeze(0).expand(lengths.shape[0], -1)
+    return ids >= lengths.unsqueeze(1).expand(-1, int(max_len))
+
+
+def forward_features(sd: SD, contents, speakers=None, pitches=None, pitch_shift=None, energy=None, mel_lens=None,
+                     mel_max_len=None) -> dict:
+    """diffsinger.py:57-134 without the phones2mel gather.  Keys of ``sd`` are the DiffSinger state-dict names:
+    text_encoder.projection.{weight,bias}, speaker_encoder.embedding.weight, {pitch,pitch_shift,energy}_encoder.projection.*"""
+    mel_masks = mask_from_lengths(mel_lens, mel_max_len) if mel_lens is not None else None
+    features = F.linear(contents, sd["text_encoder.projection.weight"], sd["text_encoder.projection.bias"])
+    emb = None
+    if speakers is not None and speakers.ndim in (2, 3) and torch.is_floating_point(speakers):
+        emb = speakers
+    elif speakers is not None and "speaker_encoder.embedding.weight" in sd:
+        emb = F.embedding(speakers, sd["speaker_encoder.embedding.weight"])
+    if emb is not None and emb.ndim == 2:
+        emb = emb[:, None, :]
+    if emb is not None:
+        features = features + emb
+    if "pitch_encoder.projection.weight" in sd:
+        features = features + F.linear(pitch_to_scale(pitches), sd["pitch_encoder.projection.weight"],
+                                       sd["pitch_encoder.projection.bias"])
+    if pitch_shift is not None and "pitch_shift_encoder.projection.weight" in sd:
+        e = F.linear(pitch_shift, sd["pitch_shift_encoder.projection.weight"], sd["pitch_shift_encoder.projection.bias"])
+        features = features + (e[:, None, :] if e.ndim == 2 else e)
+    if energy is not None and "energy_encoder.projection.weight" in sd:
+        e = F.linear(energy, sd["energy_encoder.projection.weight"], sd["energy_encoder.projection.bias"])
+        features = features + (e[:, None, :] if e.ndim == 2 else e)
+    return dict(features=features, x_masks=mel_masks, x_lens=mel_lens, cond_masks=mel_masks)
+
+
+def seeded_frontend_state(seed: int, content_dim=256, hidden=256, n_speakers=10, pitch_shift=False, energy=False) -> SD:
+    """Weights with the reference initialisers' statistics (xavier_uniform_ / N(0, hidden^-0.5), naive_projection.py:48-55);
+    biases get small noise instead of the reference's 0 so the bias paths are exercised."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out_f, in_f):
+        bound = (6.0 / (out_f + in_f)) ** 0.5
+        return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound, (torch.rand(out_f, generator=g) * 2 - 1) * 0.05
+
+    sd = {}
+    sd["text_encoder.projection.weight"], sd["text_encoder.projection.bias"] = lin(hidden, content_dim)
+    sd["speaker_encoder.embedding.weight"] = torch.randn(n_speakers, hidden, generator=g) * hidden ** -0.5
+    sd["pitch_encoder.projection.weight"], sd["pitch_encoder.projection.bias"] = lin(hidden, 1)
+    if pitch_shift:
+        sd["pitch_shift_encoder.projection.weight"], sd["pitch_shift_encoder.projection.bias"] = lin(hidden, 1)
+    if energy:
+        sd["energy_encoder.projection.weight"], sd["energy_encoder.projection.bias"] = lin(hidden, 1)
+    return sd

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
-from oracle import _ref_import, mel_ref, nsf_hifigan_ref, sampler_ref, wavenet_ref  # noqa: E402
+from oracle import _ref_import, features_ref, mel_ref, nsf_hifigan_ref, sampler_ref, wavenet_ref  # noqa: E402
 
 
 def sha1_of(tensors) -> str:
@@ -211,6 +211,52 @@ def main():
         arrays[f"mel_ks{ks}_sp{sp}"] = ref
     arrays["logmel_log10"] = mel_ref.wav2spec(wav, use_natural_log=False)
     save("mel", **arrays)
+
+    # ---------------------------------------------------------------- condition front end
+    print("front end (DiffSinger.forward_features, NaiveProjection encoders)")
+    get_mask, fwd_features = R["diffsinger_methods"]()
+    Enc = R["NaiveProjectionEncoder"]
+
+    class RefFrontEnd(torch.nn.Module):   # carries the encoders; the two methods are the reference's own source
+        forward_features = fwd_features
+
+        def __init__(self, sd):
+            super().__init__()
+            self.get_mask_from_lengths = get_mask.__func__ if hasattr(get_mask, "__func__") else get_mask
+            self.text_encoder = Enc(256, 256)
+            self.speaker_encoder = Enc(10, 256, use_embedding=True)
+            self.pitch_encoder = Enc(1, 256, preprocessing=R["pitch_to_scale"])
+            if "pitch_shift_encoder.projection.weight" in sd:
+                self.pitch_shift_encoder = Enc(1, 256)
+            if "energy_encoder.projection.weight" in sd:
+                self.energy_encoder = Enc(1, 256)
+            self.load_state_dict(sd, strict=True)
+
+    g = torch.Generator().manual_seed(99)
+    B, T = 3, 70
+    contents = torch.randn(B, T, 256, generator=g)
+    f0 = torch.rand(B, T, generator=g) * 1300.0            # includes values below f0_min and above f0_max
+    f0[1, 20:30] = 0.0
+    lens = torch.tensor([70, 51, 64])
+    arrays = dict(contents=contents, f0=f0, lens=lens)
+    sd_a = features_ref.seeded_frontend_state(11)
+    sd_b = features_ref.seeded_frontend_state(12, pitch_shift=True, energy=True)
+    ids = torch.tensor([3, 0, 9])
+    mix = torch.randn(B, 256, generator=g) * 0.1
+    mix_t = torch.randn(B, T, 256, generator=g) * 0.1
+    shift = torch.randn(B, 1, generator=g)
+    energy = torch.rand(B, T, 1, generator=g)
+    cases = {"ids": (sd_a, dict(speakers=ids)), "mix": (sd_a, dict(speakers=mix)), "mix_t": (sd_a, dict(speakers=mix_t)),
+             "full": (sd_b, dict(speakers=ids, pitch_shift=shift, energy=energy))}
+    for tag, (sd, kw) in cases.items():
+        ref = RefFrontEnd(sd).forward_features(kw["speakers"], contents, lens, T, mel_lens=lens, mel_max_len=T, pitches=f0.clone(),
+                                               pitch_shift=kw.get("pitch_shift"), energy=kw.get("energy"))
+        mine = features_ref.forward_features(sd, contents, kw["speakers"], f0, kw.get("pitch_shift"), kw.get("energy"), lens, T)
+        assert torch.equal(mine["features"], ref["features"]) and torch.equal(mine["x_masks"], ref["x_masks"]), tag
+        arrays[f"features_{tag}"] = ref["features"]
+    arrays.update(ids=ids, mix=mix, mix_t=mix_t, shift=shift, energy=energy, masks=ref["x_masks"],
+                  sha1_a=np.array(state_sha1(sd_a)), sha1_b=np.array(state_sha1(sd_b)))
+    save("frontend", **arrays)
 
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)

@@ -466,3 +466,57 @@ def test_empty_and_mismatched_inputs_raise(dev):
         net(torch.zeros(2, 128, 8, device=dev), torch.zeros(3, device=dev), torch.zeros(2, 256, 8, device=dev))
     with pytest.raises(ValueError):
         PitchAdjustableMelSpectrogram()(torch.zeros(8, device=dev))   # 1-D audio
+
+
+# ------------------------------------------------------------------------------------------------ condition front end (8f row 1)
+def _frontend(dev, sd, **extra):
+    from fish_diffusion_amd import DiffSinger, pitch_to_scale
+    cfg = dict(text_encoder=dict(type="NaiveProjectionEncoder", input_size=256, output_size=256),
+               speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=256, use_embedding=True),
+               pitch_encoder=dict(type="NaiveProjectionEncoder", input_size=1, output_size=256, preprocessing=pitch_to_scale),
+               diffusion=dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5], spec_max=[0]),
+               **extra)
+    m = DiffSinger(cfg)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("diffusion.") for k in missing)
+    return m.to(dev).eval()
+
+
+def test_forward_features_matches_reference_golden(dev):
+    from oracle import features_ref
+    g = load("frontend")
+    sd_a, sd_b = features_ref.seeded_frontend_state(11), features_ref.seeded_frontend_state(12, pitch_shift=True, energy=True)
+    lin1 = dict(type="NaiveProjectionEncoder", input_size=1, output_size=256)
+    ma, mb = _frontend(dev, sd_a), _frontend(dev, sd_b, pitch_shift_encoder=lin1, energy_encoder=lin1)
+    T = g["contents"].shape[1]
+    lens = torch.as_tensor(g["lens"]).to(dev)
+    ids = torch.as_tensor(g["ids"]).to(dev)
+    c, f0 = g["contents"].to(dev), g["f0"].to(dev)
+    for tag, m, spk, kw in (("ids", ma, ids, {}), ("mix", ma, g["mix"].to(dev), {}), ("mix_t", ma, g["mix_t"].to(dev), {}),
+                            ("full", mb, ids, dict(pitch_shift=g["shift"].to(dev), energy=g["energy"].to(dev)))):
+        out = m.forward_features(spk, c, lens, T, mel_lens=lens, mel_max_len=T, pitches=f0, **kw)
+        assert out["features"].shape == g[f"features_{tag}"].shape
+        assert rel_err(out["features"].cpu(), g[f"features_{tag}"]) < 1e-5, tag
+        assert torch.equal(out["x_masks"].cpu(), g["masks"].bool()) and out["cond_masks"] is out["x_masks"]
+    with pytest.raises(IndexError):
+        ma.forward_features(torch.tensor([10, 0, 0], device=dev), c, lens, T, pitches=f0)
+    with pytest.raises(NotImplementedError):
+        ma.forward_features(ids, c, lens, T, pitches=f0, phones2mel=torch.zeros(3, T, dtype=torch.long, device=dev))
+
+
+def test_svc_inference_chain_features_to_mel(dev):
+    """tools/diffusion/inference.py:131-159 as one call: forward_features -> diffusion, vs the oracle chain on CPU."""
+    from oracle import features_ref, sampler_ref
+    sd_f = features_ref.seeded_frontend_state(11)
+    sd_w = wavenet_sd(WN_SMALL, 101)
+    m = _frontend(dev, sd_f)
+    m.diffusion.denoise_fn.load_state_dict(sd_w, strict=True)
+    g = torch.Generator().manual_seed(6)
+    B, T = 2, 45
+    c, f0 = torch.randn(B, T, 256, generator=g), 100 + 400 * torch.rand(B, T, generator=g)
+    spk, x0 = torch.tensor([2, 5]), torch.randn(B, 128, T, generator=g)
+    with torch.no_grad():
+        feats = features_ref.forward_features(sd_f, c, spk, f0)["features"]
+        ref = sampler_ref.diffusion_sample(_oracle_den(sd_w, WN_SMALL), feats, x_init=x0, sampler_interval=100)
+    mel = m.infer(spk.to(dev), c.to(dev), f0.to(dev), sampler_interval=100, x_init=x0.to(dev))
+    assert rel_err(mel.cpu(), ref) < MEL_REL

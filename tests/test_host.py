@@ -273,3 +273,29 @@ def test_generator_checkpoint_contract(lib, tmp_path):
         NsfHifiGAN(str(tmp_path / "model"), sampling_rate=48000)
     voc.freeze()
     assert not any(p.requires_grad for p in voc.parameters())
+
+
+def test_diffsinger_frontend_state_dict_contract(lib):
+    """DiffSinger mirrors the reference's attribute names -> checkpoint keys (diffsinger.py:20-40, naive_projection.py:35-44)."""
+    from fish_diffusion_amd import DiffSinger, pitch_to_scale
+    cfg = dict(text_encoder=dict(type="NaiveProjectionEncoder", input_size=256, output_size=256),
+               speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=256, use_embedding=True),
+               pitch_encoder=dict(type="NaiveProjectionEncoder", input_size=1, output_size=256, preprocessing=pitch_to_scale),
+               diffusion=dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", mel_channels=128, d_encoder=256,
+                                                                      residual_channels=32, residual_layers=2, dilation_cycle=2,
+                                                                      use_linear_bias=True), spec_min=[-5], spec_max=[0]))
+    m = DiffSinger(cfg)
+    keys = set(m.state_dict())
+    for k in ("text_encoder.projection.weight", "text_encoder.projection.bias", "speaker_encoder.embedding.weight",
+              "pitch_encoder.projection.weight", "pitch_encoder.projection.bias",
+              "diffusion.denoise_fn.residual_layers.1.conv_layer.conv.weight", "diffusion.spec_min", "diffusion.betas"):
+        assert k in keys, k
+    assert tuple(m.pitch_encoder.projection.weight.shape) == (256, 1)
+    f0 = torch.tensor([[0.0, 50.0, 575.0, 1100.0, 5000.0]])
+    assert torch.allclose(pitch_to_scale(f0)[0, :, 0], torch.tensor([0.0, 0.0, 0.5, 1.0, 1.0]))
+    mask = DiffSinger.get_mask_from_lengths(torch.tensor([3, 1]), 4)
+    assert mask.tolist() == [[False, False, False, True], [False, True, True, True]]
+    with pytest.raises(NotImplementedError):
+        m.forward()
+    with pytest.raises(RuntimeError):   # CPU tensors: no fallback
+        m.forward_features(torch.tensor([1]), torch.zeros(1, 4, 256), torch.tensor([4]), 4, pitches=torch.zeros(1, 4))

@@ -98,3 +98,18 @@ def test_discrete_vp_interpolation_properties():
     # extrapolation below the first knot is linear
     below = ns.log_mean_coeff(torch.tensor([0.0005]))
     assert below > ns.log_alpha[0]
+
+
+def test_frontend_oracle_matches_reference():
+    """DiffSinger.forward_features restatement vs the output of the reference's own method source (oracle/make_golden.py)."""
+    from oracle import features_ref
+    g = load("frontend")
+    sd_a, sd_b = features_ref.seeded_frontend_state(11), features_ref.seeded_frontend_state(12, pitch_shift=True, energy=True)
+    assert sha1_state(sd_a) == str(g["sha1_a"]) and sha1_state(sd_b) == str(g["sha1_b"])
+    lens, T = torch.from_numpy(g["lens"]) if not torch.is_tensor(g["lens"]) else g["lens"], g["contents"].shape[1]
+    ids = torch.from_numpy(g["ids"]) if not torch.is_tensor(g["ids"]) else g["ids"]
+    for tag, sd, spk, kw in (("ids", sd_a, ids, {}), ("mix", sd_a, g["mix"], {}), ("mix_t", sd_a, g["mix_t"], {}),
+                             ("full", sd_b, ids, dict(pitch_shift=g["shift"], energy=g["energy"]))):
+        out = features_ref.forward_features(sd, g["contents"], spk, g["f0"], mel_lens=lens, mel_max_len=T, **kw)
+        assert rel_err(out["features"], g[f"features_{tag}"]) < 1e-6, tag
+        assert torch.equal(out["x_masks"], g["masks"].bool())
