@@ -127,7 +127,8 @@ struct fdx_ctx {
   float dft_key = 1e30f; int dft_nfft = 0, dft_win = 0;   // cache key of dft_packed
 
   // ---- debug / profiling
-  fdx::DevBuf dbg_w, dbg_x, dbg_b;
+  fdx::DevBuf scratch_a, scratch_b;   // small per-call scratch of the product paths (spec stats, rand_ini copies)
+  fdx::DevBuf dbg_w, dbg_x, dbg_b;    // fdx_debug_conv1d only
   fdx::ProfEvents prof;
 };
 

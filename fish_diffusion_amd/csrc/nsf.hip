@@ -289,9 +289,9 @@ static int nsf_source_core(fdx_ctx* h, const float* f0, int B, int T, const floa
   const float sr = (float)d.sampling_rate;
   // random draws: injected (parity) or device Philox (perf)
   if (!rand_ini) {
-    FDX_HIP(h, h->dbg_b.ensure((size_t)B * H * 4 + 64, false, s));
-    hipLaunchKernelGGL(k_rand_uniform, dim3(1 + B * H / 1024), dim3(256), 0, s, h->dbg_b.f(), (size_t)B * H, seed ^ 0x5eedULL, 0ULL);
-    rand_ini = h->dbg_b.f();
+    FDX_HIP(h, h->scratch_a.ensure((size_t)B * H * 4 + 64, false, s));
+    hipLaunchKernelGGL(k_rand_uniform, dim3(1 + B * H / 1024), dim3(256), 0, s, h->scratch_a.f(), (size_t)B * H, seed ^ 0x5eedULL, 0ULL);
+    rand_ini = h->scratch_a.f();
   }
   if (!src_noise) {
     const size_t n = (size_t)B * L * H;
@@ -300,10 +300,10 @@ static int nsf_source_core(fdx_ctx* h, const float* f0, int B, int T, const floa
     src_noise = h->vnoise.f();
   }
   // the fundamental carries no initial phase noise: rand_ini[:, 0] = 0 (models.py:213) -- enforced on a private copy
-  FDX_HIP(h, h->dbg_w.ensure((size_t)B * H * 4 + 64, false, s));
-  FDX_HIP(h, hipMemcpyAsync(h->dbg_w.p, rand_ini, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
-  FDX_HIP(h, hipMemset2DAsync(h->dbg_w.p, (size_t)H * 4, 0, 4, B, s));
-  const float* rini = h->dbg_w.f();
+  FDX_HIP(h, h->scratch_b.ensure((size_t)B * H * 4 + 64, false, s));
+  FDX_HIP(h, hipMemcpyAsync(h->scratch_b.p, rand_ini, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+  FDX_HIP(h, hipMemset2DAsync(h->scratch_b.p, (size_t)H * 4, 0, 4, B, s));
+  const float* rini = h->scratch_b.f();
 
   hipLaunchKernelGGL(k_f0_upsample, dim3((L + 255) / 256, B), dim3(256), 0, s, h->vf0up.f(), f0, T, L);
   double* part = reinterpret_cast<double*>(h->scan_part.p);

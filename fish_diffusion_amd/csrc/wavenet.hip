@@ -534,11 +534,11 @@ extern "C" int fdx_denorm_spec(fdx_handle h, const float* x, int B, int M, int T
   if (n_spec != 1 && n_spec != M) return fail(h, FDX_E_ARG, "spec_min and spec_max must be either of length 1 or mel_channels");
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
-  FDX_HIP(h, h->dbg_b.ensure(2 * (size_t)n_spec * 4, false, s));
-  FDX_HIP(h, hipMemcpyAsync(h->dbg_b.p, spec_min, n_spec * 4, hipMemcpyHostToDevice, s));
-  FDX_HIP(h, hipMemcpyAsync(h->dbg_b.f() + n_spec, spec_max, n_spec * 4, hipMemcpyHostToDevice, s));
+  FDX_HIP(h, h->scratch_a.ensure(2 * (size_t)n_spec * 4, false, s));
+  FDX_HIP(h, hipMemcpyAsync(h->scratch_a.p, spec_min, n_spec * 4, hipMemcpyHostToDevice, s));
+  FDX_HIP(h, hipMemcpyAsync(h->scratch_a.f() + n_spec, spec_max, n_spec * 4, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_denorm_transpose, dim3((T + 31) / 32, (M + 31) / 32, B), dim3(256), 0, s, mel, x, M, T,
-                     h->dbg_b.f(), h->dbg_b.f() + n_spec, n_spec);
+                     h->scratch_a.f(), h->scratch_a.f() + n_spec, n_spec);
   FDX_HIP(h, hipGetLastError());
   return FDX_OK;
 }
