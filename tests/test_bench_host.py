@@ -1,0 +1,38 @@
+"""CPU: the host-side arithmetic of bench.py (no GPU, no library calls)."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_algorithmic_flops_match_the_survey():
+    b = _bench()
+    # 95.18 MFLOP per frame per step (incl. 0.02 T-independent), 1.2737 MFLOP per output sample (config_v1)
+    assert abs(b.wavenet_flops_per_frame() / 1e6 - 95.16) < 0.05
+    assert abs(b.nsf_flops_per_sample() / 1e6 - 1.2737) < 1e-3
+    h256 = dict(b.NSF_V1, upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], hop_size=256)
+    assert abs(b.nsf_flops_per_sample(h256) / 1e6 - 2.402) < 5e-3        # config_v1_256: 2.402 MFLOP per sample
+    total = b.wavenet_flops_per_frame() * 861 * 100 + b.nsf_flops_per_sample() * 861 * 512
+    assert abs(total / 1e12 - 8.755) < 0.01                               # one 10 s utterance, 100 steps
+
+
+def test_usable_cores_and_traffic_file():
+    b = _bench()
+    n = b.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    traffic, src = b.pmc_traffic(1, 861)
+    assert src is None or os.path.exists(os.path.join(ROOT, src))
+    if traffic is not None:
+        with open(os.path.join(ROOT, src)) as f:
+            d = json.load(f)
+        k = next(v for name, v in d["kernels"].items() if "EpiGate" in name)
+        assert traffic == k["fetch_bytes"] + k["write_bytes"] and k["fetch_bytes"] == int(2 * k["FETCH_SIZE"] * 1024)
+    assert b.pmc_traffic(4, 861) == (None, None)                          # counters are only valid for the config they were taken on
