@@ -37,3 +37,12 @@ def test_usable_cores_and_traffic_file():
         assert traffic == k["fetch_bytes"] + k["write_bytes"]
         assert abs(k["fetch_bytes"] - 2 * k["FETCH_SIZE"] * 1024) < 2048    # FETCH_SIZE is stored rounded to 0.1 KiB
     assert b.pmc_traffic(4, 861) == (None, None)                          # counters are only valid for the config they were taken on
+
+
+def test_make_batches_rules():
+    from fish_diffusion_amd.pipeline import make_batches
+    assert make_batches([10, 9, 8, 3], 2) == [[0, 1], [2], [3]]              # full, then padding ratio
+    assert make_batches([5, 5, 5], 8) == [[0, 1, 2]]
+    assert make_batches([], 4) == []
+    flat = sorted(i for b in make_batches([7, 100, 90, 95, 20, 21, 60], 3) for i in b)
+    assert flat == list(range(7))
