@@ -14,11 +14,30 @@
 // all timesteps at once.
 #include "common.hip.h"
 #include "elementwise.hip.h"
+#include "convgemm16.hip.h"
 
 #include <cmath>
 #include <cstdlib>
 
 using namespace fdx;
+
+// Which MFMA shape runs the two residual-block kernels.  Default: the dilated conv + gate on v_mfma_f32_16x16x4_f32
+// (convgemm16.hip.h: 4 x dwordx4 operand loads per 32 MFMAs, 16-byte epilogue quads; ~1 us faster per launch), the
+// out-projection on 32x32x2 (its short K loop -- 16 iterations per wave -- measured 3 % slower on 16x16x4).
+// FDX_RESBLOCK_MFMA=32 / 16 forces one family for both.  The families want different weight fragment orders, so the
+// switch is read wherever weights are packed AND where they are used: it must be the same on every rank of a job.
+static int resblock_mode() {   // bit 0: dilated conv + gate on 16x16x4, bit 1: out-projection on 16x16x4
+  static const int v = [] {
+    const char* e = getenv("FDX_RESBLOCK_MFMA");
+    if (!e) return 1;
+    if (atoi(e) == 32) return 0;
+    if (atoi(e) == 16) return 3;
+    return 1;
+  }();
+  return v;
+}
+static bool conv16() { return resblock_mode() & 1; }
+static bool outp16() { return resblock_mode() & 2; }
 
 static long kMinTilesMT2 = 1L << 60;   // disabled; FDX_MT2_MIN_TILES overrides (read in fdx_wavenet_attach)
 
@@ -117,14 +136,32 @@ extern "C" int fdx_wavenet_pack(const fdx_wavenet_desc* d, const float* const* w
     const float* op_w = w[k]; const float* op_b = w[k + 1]; k += 2;
     // dilated conv, gate/filter paired: tile mt holds gate rows 32mt.. (rb 0) and filter rows C+32mt.. (rb 1)
     const PackedW& pc = l.conv[i];
-    pack_convgemm(A + pc.w_off, pc.n_mtiles, 2, pc.cin8, 3, [&](int mt, int rb, int r, int c, int tap) -> float {
-      const int ch = mt * 32 + r;
-      if (ch >= C || c >= C) return 0.f;
-      return conv_w[((size_t)(rb * C + ch) * C + c) * 3 + tap];
-    });
+    if (conv16()) {   // rbk 0,1: gate rows 32mt + 16rbk + r;  rbk 2,3: the matching filter rows
+      pack_convgemm16(A + pc.w_off, pc.n_mtiles, pc.cin8, 3, [&](int mt, int rbk, int r, int c, int tap) -> float {
+        const int ch = mt * 32 + (rbk & 1) * 16 + r;
+        if (ch >= C || c >= C) return 0.f;
+        return conv_w[((size_t)((rbk >> 1) * C + ch) * C + c) * 3 + tap];
+      });
+    } else {
+      pack_convgemm(A + pc.w_off, pc.n_mtiles, 2, pc.cin8, 3, [&](int mt, int rb, int r, int c, int tap) -> float {
+        const int ch = mt * 32 + r;
+        if (ch >= C || c >= C) return 0.f;
+        return conv_w[((size_t)(rb * C + ch) * C + c) * 3 + tap];
+      });
+    }
     // the hoisted conditioner slab also absorbs the conv bias: y = (conv + b_conv) + (cond + b_cond), wavenet.py:112
     for (int r = 0; r < 2 * C; ++r) A[l.cond.b_off + (size_t)i * 2 * C + r] = cp_b[r] + conv_b[r];
-    pack_plain(A, l.outp[i], op_w, 2 * C, C, op_b);
+    if (outp16()) {
+      const PackedW& po = l.outp[i];
+      pack_convgemm16(A + po.w_off, po.n_mtiles, po.cin8, 1, [&](int mt, int rbk, int r, int c, int) -> float {
+        const int row = mt * 64 + rbk * 16 + r;
+        if (row >= 2 * C || c >= C) return 0.f;
+        return op_w[(size_t)row * C + c];
+      });
+      for (int r = 0; r < 2 * C; ++r) A[po.b_off + r] = op_b[r];
+    } else {
+      pack_plain(A, l.outp[i], op_w, 2 * C, C, op_b);
+    }
   }
   {  // diffusion projections of all layers = one [L*C x C] GEMM; conditioner projections = one [L*2C x E] GEMM
     const PackedW& p = l.dproj;
@@ -291,9 +328,6 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   const float sqrtL = (float)std::sqrt((double)L);
   for (int i = 0; i < L; ++i) {
     const int dil = l.dil[i];
-    EpiGate g{};
-    g.out = Z; g.o_bs = bsC; g.ldo = ld;
-    g.P = (Pslab ? Pslab : h->P.f()) + kHalo + (size_t)i * 2 * C * ld; g.p_bs = (long)L * 2 * C * ld; g.ldp = ld; g.C = C;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (h->prof.on && (h->prof.seen++ % h->prof.stride) == 0) {
       auto& pe = h->prof;
@@ -305,15 +339,34 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       ev0 = pe.start[pe.used]; ev1 = pe.stop[pe.used]; pe.used++;
       pe.flops_per_launch = 2.0 * (2.0 * C) * (3.0 * C) * (double)B * T;
     }
-    FDX_HIP(h, (run_gemm<true, false>(A, l.conv[i], B, T, Y, bsC, ld, -dil, dil, 1.f, g, s, ev0, ev1)));
-
-    EpiResSkip r{};
-    r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
-    r.Y = (i + 1 < L) ? Y : nullptr;
-    r.sb = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn; r.sb_ld = ldn; r.sb_bs = sb_bs;
-    r.skip_mode = (L == 1) ? 3 : (i == 0 ? 0 : (i + 1 == L ? 2 : 1));
-    r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
-    FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s)));
+    const float* Pl = (Pslab ? Pslab : h->P.f()) + kHalo + (size_t)i * 2 * C * ld;
+    const long p_bs = (long)L * 2 * C * ld;
+    const float* sbn = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn;
+    const int skip_mode = (L == 1) ? 3 : (i == 0 ? 0 : (i + 1 == L ? 2 : 1));
+    if (conv16()) {
+      const ConvGeom gc{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles};
+      EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
+      FDX_HIP(h, launch_convgemm16(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
+    } else {
+      EpiGate g{};
+      g.out = Z; g.o_bs = bsC; g.ldo = ld;
+      g.P = Pl; g.p_bs = p_bs; g.ldp = ld; g.C = C;
+      FDX_HIP(h, (run_gemm<true, false>(A, l.conv[i], B, T, Y, bsC, ld, -dil, dil, 1.f, g, s, ev0, ev1)));
+    }
+    if (outp16()) {
+      const ConvGeom go{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles};
+      EpiResSkip16 r{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL,
+                     (float)(1.0 / (double)sqrtL)};
+      FDX_HIP(h, launch_convgemm16(go, reinterpret_cast<const float4*>(A + l.outp[i].w_off), Z, bsC, ld, r, s));
+    } else {
+      EpiResSkip r{};
+      r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
+      r.Y = (i + 1 < L) ? Y : nullptr;
+      r.sb = sbn; r.sb_ld = ldn; r.sb_bs = sb_bs;
+      r.skip_mode = skip_mode;
+      r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
+      FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s)));
+    }
   }
   {
     EpiBias e = epi_bias(H, bsC, ld, A + l.skip_proj.b_off, C, ACT_RELU);

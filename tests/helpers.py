@@ -99,3 +99,41 @@ def emulate_convgemm(packed, X, *, n_mtiles, RB, cin8, taps, shift0, dshift, T, 
         for rb in range(RB):
             out[(mt, rb)] = tiles[0][rb][:, :T]
     return out
+
+
+def emulate_convgemm16(packed, X, *, n_mtiles, cin8, taps, shift0, dshift, T, halo=32):
+    """numpy emulation of convgemm16_kernel (fish_diffusion_amd/csrc/convgemm16.hip.h): v_mfma_f32_16x16x4_f32 lane maps
+    (A: lane l = row l&15, k l>>4;  B: k-row l>>4, column group l&15, value m = column 4*(l&15)+m;  D: row (l>>4)*4+reg).
+    packed: flat float32 [n_mtiles][cin8*taps][2][64][4].  Returns dict mt -> [64, T] (tile rows rbk*16 + ...)."""
+    n_it = cin8 * taps
+    P = packed.reshape(n_mtiles, n_it, 2, 64, 4)
+    lanes = np.arange(64)
+    lj, lk = lanes & 15, lanes >> 4
+    cols = ((T + 63) // 64) * 64
+    out = {}
+    for mt in range(n_mtiles):
+        tile = np.zeros((64, cols))
+        for t0 in range(0, cols, 64):
+            acc = np.zeros((4, 4, 4, 64))                      # [rbk][m][reg][lane]
+            for it in range(n_it):
+                cb, tap = divmod(it, taps)
+                for h in range(2):
+                    ch = cb * 8 + h * 4 + lk                   # per lane: the k-row it loads
+                    base = halo + t0 + 4 * lj + shift0 + tap * dshift
+                    for m in range(4):
+                        b = X[ch, base + m]                    # per-lane B operand of column set m
+                        Bm = np.zeros((4, 16))
+                        Bm[lk, lj] = b
+                        for rbk in range(4):
+                            a = P[mt, it, h, :, rbk]           # per-lane A operand of row block rbk
+                            Am = np.zeros((16, 4))
+                            Am[lj, lk] = a                     # A[i = l&15][k = l>>4]
+                            D = Am.astype(np.float64) @ Bm.astype(np.float64)     # [16 rows, 16 col groups]
+                            for reg in range(4):
+                                acc[rbk, m, reg] += D[lk * 4 + reg, lj]
+            for rbk in range(4):
+                for m in range(4):
+                    for reg in range(4):
+                        tile[rbk * 16 + lk * 4 + reg, t0 + 4 * lj + m] = acc[rbk, m, reg]
+        out[mt] = tile[:, :T]
+    return out

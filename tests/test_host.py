@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.helpers import ROOT, WN_SMALL, emulate_convgemm, wavenet_sd
+from tests.helpers import emulate_convgemm16, ROOT, WN_SMALL, emulate_convgemm, wavenet_sd
 
 
 @pytest.fixture(scope="module")
@@ -110,11 +110,22 @@ def test_wavenet_packing_matches_kernel_index_math(lib):
     X = np.zeros((64, ld), np.float32)
     X[:, halo:halo + T] = y.numpy()
     o = off["conv1"]
-    acc = emulate_convgemm(arena[o["w"]:o["b"]], X, n_mtiles=o["mt"], RB=2, cin8=o["cin8"], taps=3, shift0=-2, dshift=2, T=T)
+    # (residual-block weights are packed for the 16x16x4 kernels: tile rows 0..31 = gate, 32..63 = filter)
+    acc = emulate_convgemm16(arena[o["w"]:o["b"]], X, n_mtiles=o["mt"], cin8=o["cin8"], taps=3, shift0=-2, dshift=2, T=T)
     ref = F.conv1d(y[None], sd["residual_layers.1.conv_layer.conv.weight"], None, padding=2, dilation=2)[0].numpy()
     for mt in range(o["mt"]):
-        np.testing.assert_allclose(acc[(mt, 0)], ref[mt * 32:mt * 32 + 32], rtol=1e-4, atol=1e-5)          # gate
-        np.testing.assert_allclose(acc[(mt, 1)], ref[64 + mt * 32:64 + mt * 32 + 32], rtol=1e-4, atol=1e-5)  # filter
+        np.testing.assert_allclose(acc[mt][:32], ref[mt * 32:mt * 32 + 32], rtol=1e-4, atol=1e-5)          # gate
+        np.testing.assert_allclose(acc[mt][32:], ref[64 + mt * 32:64 + mt * 32 + 32], rtol=1e-4, atol=1e-5)  # filter
+    # ---- output projection of layer 2: plain 64-row tiles on the 32x32x2 family
+    z = torch.randn(64, T, generator=g)
+    X = np.zeros((64, ld), np.float32)
+    X[:, halo:halo + T] = z.numpy()
+    o = off["outp2"]
+    acc = emulate_convgemm(arena[o["w"]:o["b"]], X, n_mtiles=o["mt"], RB=2, cin8=o["cin8"], taps=1, shift0=0, dshift=0, T=T)
+    ref = (sd["residual_layers.2.output_projection.conv.weight"][:, :, 0] @ z).numpy()
+    for mt in range(o["mt"]):
+        np.testing.assert_allclose(np.concatenate([acc[(mt, 0)], acc[(mt, 1)]]), ref[mt * 64:mt * 64 + 64], rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(arena[o["b"]:o["b"] + 128], sd["residual_layers.2.output_projection.conv.bias"].numpy())
     # ---- concatenated diffusion projection: row l*C + c
     s = torch.randn(64, 5, generator=g)
     X = np.zeros((64, ld), np.float32)
