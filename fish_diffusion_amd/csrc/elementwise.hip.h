@@ -90,6 +90,41 @@ static __global__ void k_unipc_post(float* __restrict__ x, float* __restrict__ m
   x[o] = xbase[o] - aB * corr;
 }
 
+// k_unipc_post of step r immediately followed by k_unipc_pre of step r+1 on the same element (one launch, one round trip
+// instead of two; the arithmetic and its order are unchanged).  After the corrector the history shifts: m0' = model_t,
+// m1' = m0 (uni_pc.py:797-804), so the next predictor's D1 = (m1' - m0') / rk' needs nothing from memory.
+static __global__ void k_unipc_post_pre(float* __restrict__ x, float* __restrict__ mt, float* __restrict__ xbase,
+                                 float* __restrict__ xt, const float* __restrict__ eps, const float* __restrict__ m0,
+                                 const float* __restrict__ m1, long bs, int ld, int M, int T, float sigma, float alpha,
+                                 float aB, float rk, int order, float rho0, float rho1, float n_cx, float n_cm, float n_aB,
+                                 float n_rk, int n_order) {
+  const int t = blockIdx.x * kEwBlock + threadIdx.x;
+  if (t >= T) return;
+  const long o = (blockIdx.y / M) * bs + (long)(blockIdx.y % M) * ld + t;
+  const float m0v = m0[o];
+  const float mtv = (xt[o] - sigma * eps[o]) / alpha;
+  const float D1t = mtv - m0v;
+  float corr;
+  if (order == 2) {
+    const float D1 = (m1[o] - m0v) / rk;
+    corr = rho0 * D1 + rho1 * D1t;
+  } else {
+    corr = rho1 * D1t;
+  }
+  const float xn = xbase[o] - aB * corr;
+  mt[o] = mtv;
+  x[o] = xn;
+  // ---- predictor of the next step (k_unipc_pre with x = xn, m0 = mtv, m1 = m0v)
+  const float xb = n_cx * xn - n_cm * mtv;
+  float r = xb;
+  if (n_order == 2) {
+    const float D1n = (m0v - mtv) / n_rk;
+    r = xb - n_aB * (0.5f * D1n);
+  }
+  xbase[o] = xb;
+  xt[o] = r;
+}
+
 // ---------------------------------------------------------------- DDPM ancestral step (noise_predictor.py:73-104)
 static __global__ void k_naive_step(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
                              long n_bs, int n_ld, long bs, int ld, int M, int T, float sr, float srm1, float c1,

@@ -431,15 +431,25 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
     float* m0 = h->sm[0].f() + kHalo; float* m1 = h->sm[1].f() + kHalo; float* mt = h->seps2.f() + kHalo;
     if (int rc = model(sx, 0, true)) return rc;
     hipLaunchKernelGGL(k_x0_pred, grid, blk, 0, s, m0, sx, eps, bs, ld, M, T, tab[1], tab[2]);
+    bool pre_done = false;   // the predictor of step r was already computed by the fused post+pre launch of step r-1
     for (int r = 1; r < n_rows; ++r) {
       const float* row = tab + (size_t)r * FDX_ROW;
       const float sigma = row[1], alpha = row[2], c_x = row[3], c_m = row[4], aB = row[5], rk = row[6];
       const int order = (int)row[7], corr = (int)row[8];
-      hipLaunchKernelGGL(k_unipc_pre, grid, blk, 0, s, xb, xt, sx, m0, m1, bs, ld, M, T, c_x, c_m, aB, rk, order);
+      if (!pre_done)
+        hipLaunchKernelGGL(k_unipc_pre, grid, blk, 0, s, xb, xt, sx, m0, m1, bs, ld, M, T, c_x, c_m, aB, rk, order);
+      pre_done = false;
       if (corr) {
         if (int rc = model(xt, r, true)) return rc;
-        hipLaunchKernelGGL(k_unipc_post, grid, blk, 0, s, sx, mt, xb, xt, eps, m0, m1, bs, ld, M, T, sigma, alpha, aB, rk,
-                           order, row[9], row[10]);
+        if (r + 1 < n_rows) {
+          const float* nx = row + FDX_ROW;
+          hipLaunchKernelGGL(k_unipc_post_pre, grid, blk, 0, s, sx, mt, xb, xt, eps, m0, m1, bs, ld, M, T, sigma, alpha, aB, rk,
+                             order, row[9], row[10], nx[3], nx[4], nx[5], nx[6], (int)nx[7]);
+          pre_done = true;
+        } else {
+          hipLaunchKernelGGL(k_unipc_post, grid, blk, 0, s, sx, mt, xb, xt, eps, m0, m1, bs, ld, M, T, sigma, alpha, aB, rk,
+                             order, row[9], row[10]);
+        }
         float* tmp = m1; m1 = m0; m0 = mt; mt = tmp;   // history shift (uni_pc.py:797-804)
       } else {
         FDX_HIP(h, hipMemcpyAsync(h->sx.p, h->sxt.p, bytes, hipMemcpyDeviceToDevice, s));
