@@ -33,6 +33,12 @@ class NsfDesc(C.Structure):
                 ("harmonic_num", C.c_int)]
 
 
+class RefineGanDesc(C.Structure):
+    _fields_ = [("sampling_rate", C.c_int), ("hop_length", C.c_int), ("n_down", C.c_int), ("downsample_rates", C.c_int * MAX_STAGES),
+                ("n_up", C.c_int), ("upsample_rates", C.c_int * MAX_STAGES), ("num_mels", C.c_int), ("start_channels", C.c_int),
+                ("leaky_relu_slope", C.c_float)]
+
+
 class FeatureTerm(C.Structure):
     _fields_ = [("kind", C.c_int), ("per_frame", C.c_int), ("preproc", C.c_int), ("_pad", C.c_int), ("values", C.c_void_p),
                 ("w", C.c_void_p), ("b", C.c_void_p), ("p0", C.c_float), ("p1", C.c_float)]
@@ -74,6 +80,12 @@ _SIGS = {
     "fdx_mel_num_frames": (C.c_int, [C.POINTER(MelDesc), C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int)]),
     "fdx_mel_filterbank": (C.c_int, [C.POINTER(MelDesc), _P]),
     "fdx_mel_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P]),
+    "fdx_refinegan_num_weights": (C.c_int, [C.POINTER(RefineGanDesc)]),
+    "fdx_refinegan_num_noises": (C.c_int, [C.POINTER(RefineGanDesc)]),
+    "fdx_refinegan_packed_bytes": (C.c_int, [C.POINTER(RefineGanDesc), C.POINTER(C.c_size_t)]),
+    "fdx_refinegan_pack": (C.c_int, [C.POINTER(RefineGanDesc), C.POINTER(_P), C.c_int, _P, C.c_size_t]),
+    "fdx_refinegan_attach": (C.c_int, [_P, C.POINTER(RefineGanDesc), _P, C.c_size_t]),
+    "fdx_refinegan_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.POINTER(_P), C.c_uint64, _P, _P]),
     "fdx_features_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm), C.c_int, _P, _P]),
     "fdx_debug_conv1d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, _P, _P]),

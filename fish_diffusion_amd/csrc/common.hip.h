@@ -120,6 +120,9 @@ struct fdx_ctx {
   std::vector<fdx::DevBuf> vU, vR, vTm, vXS;   // per stage
   fdx::DevBuf scan_part;
 
+  // ---- refinegan (opaque: refinegan.hip owns the type)
+  void* rg = nullptr;
+
   // ---- mel
   bool mel_ok = false;
   fdx_mel_desc md{};
@@ -131,6 +134,8 @@ struct fdx_ctx {
   fdx::DevBuf dbg_w, dbg_x, dbg_b;    // fdx_debug_conv1d only
   fdx::ProfEvents prof;
 };
+
+void fdx_rg_free(void* p);   // refinegan.hip
 
 namespace fdx {
 

@@ -42,6 +42,7 @@ extern "C" int fdx_create(int device, fdx_handle* out) {
 extern "C" int fdx_destroy(fdx_handle h) {
   if (!h) return FDX_OK;
   (void)hipSetDevice(h->device);
+  if (h->rg) fdx_rg_free(h->rg);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   for (auto e : h->prof.start) (void)hipEventDestroy(e);

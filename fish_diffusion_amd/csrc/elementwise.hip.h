@@ -28,6 +28,16 @@ static __global__ void k_copy_rows(float* __restrict__ dst, long d_bs, int ldd, 
   dst[b * d_bs + (long)c * ldd + t] = v;
 }
 
+// padded -> padded copy with a leaky-relu (slope 1 = plain copy): dst[b][c][t] = lrelu(src[b][c][t])
+static __global__ void k_copy_rows_act(float* __restrict__ dst, long d_bs, int ldd, const float* __restrict__ src, long s_bs, int lds,
+                                int C, int T, float slope) {
+  const int t = blockIdx.x * kEwBlock + threadIdx.x;
+  if (t >= T) return;
+  const int b = blockIdx.y / C, c = blockIdx.y - b * C;
+  const float v = src[b * s_bs + (long)c * lds + t];
+  dst[b * d_bs + (long)c * ldd + t] = v > 0.f ? v : v * slope;
+}
+
 // wavenet.py:20-27 -- E[k][j] = sin(t_j * f_k) (k < half) | cos(t_j * f_{k-half}); f_k = exp(k * -(ln 1e4/(half-1)))
 static __global__ void k_step_embed(float* __restrict__ E, int ldn, const float* __restrict__ t, int n, int dim) {
   const int j = blockIdx.x * kEwBlock + threadIdx.x;

@@ -12,10 +12,10 @@
 #include <cstdlib>
 #include "elementwise.hip.h"
 #include "nsf_kernels.hip.h"
+#include "convplan.hip.h"
 
 using namespace fdx;
 
-static long kNoSplitMinWgs = 512;   // FDX_NOSPLIT_MIN_WGS overrides (tuning knob, read once)
 
 // ================================================================================================ layout
 static int nsf_validate(const fdx_nsf_desc* d) {
@@ -44,20 +44,6 @@ static int nsf_validate(const fdx_nsf_desc* d) {
   }
   if (d->harmonic_num < 0 || d->harmonic_num > 31) return fail(nullptr, FDX_E_ARG, "bad harmonic_num");
   return FDX_OK;
-}
-
-static PackedW plan_conv(size_t& cur, int rows, int cin, int taps) {
-  PackedW p;
-  p.RB = rows <= 32 ? 1 : 2;
-  p.rows = rows;
-  p.cin8 = (cin + 7) / 8;
-  p.taps = taps;
-  p.n_mtiles = (rows + 32 * p.RB - 1) / (32 * p.RB);
-  p.w_off = cur;
-  cur += packed_floats(p.n_mtiles, p.RB, p.cin8, p.taps);
-  p.b_off = cur;
-  cur += (size_t)round_up(rows, 64);
-  return p;
 }
 
 // polyphase geometry of ConvTranspose1d(k, stride u, padding (k-u)/2): output n = u*q + r reads input q - delta with
@@ -125,16 +111,6 @@ extern "C" int fdx_nsf_packed_bytes(const fdx_nsf_desc* d, size_t* bytes) {
   return FDX_OK;
 }
 
-static void pack_conv1d(float* A, const PackedW& p, const float* w, int rows, int cin, const float* bias) {
-  const int R = 32 * p.RB;
-  pack_convgemm(A + p.w_off, p.n_mtiles, p.RB, p.cin8, p.taps, [&](int mt, int rb, int i, int c, int tap) -> float {
-    const int row = mt * R + rb * 32 + i;
-    if (row >= rows || c >= cin) return 0.f;
-    return w[((size_t)row * cin + c) * p.taps + tap];
-  });
-  for (int r = 0; r < rows; ++r) A[p.b_off + r] = bias[r];
-}
-
 extern "C" int fdx_nsf_pack(const fdx_nsf_desc* d, const float* const* w, int n, void* out, size_t bytes) {
   if (nsf_validate(d)) return FDX_E_ARG;
   if (!w || !out) return fail(nullptr, FDX_E_ARG, "null pointer");
@@ -190,23 +166,9 @@ extern "C" int fdx_nsf_attach(fdx_handle h, const fdx_nsf_desc* d, const void* d
   NsfLayout l;
   nsf_layout(*d, l);
   if (!dev || bytes != l.total_floats * sizeof(float)) return fail(h, FDX_E_ARG, "packed arena size mismatch");
-  if (const char* e = getenv("FDX_NOSPLIT_MIN_WGS")) kNoSplitMinWgs = atol(e);
   h->nd = *d; h->nl = l; h->nsf_arena = static_cast<const float*>(dev); h->nsf_ok = true;
   h->vB = h->vT = 0;
   return FDX_OK;
-}
-
-// ================================================================================================ launch helper
-// Decomposition heuristic: one 64-col tile per wave (no LDS) when that already fills the chip, else 4-wave split-K.
-template <bool LRELU, class Epi>
-static hipError_t run_conv(const float* arena, const PackedW& p, int B, int T, const float* X, long x_bs, int ldx, int shift0,
-                           int dshift, float slope, const Epi& e, hipStream_t s) {
-  ConvGeom g{B, T, p.cin8, p.taps, shift0, dshift, p.n_mtiles};
-  const float4* Wp = reinterpret_cast<const float4*>(arena + p.w_off);
-  const long wg_nosplit = (long)B * ((T + 255) / 256) * p.n_mtiles;
-  if (p.RB == 1) return launch_convgemm<1, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
-  if (wg_nosplit >= kNoSplitMinWgs || p.cin8 * p.taps < 4) return launch_convgemm<2, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
-  return launch_convgemm<2, true, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
 }
 
 // ================================================================================================ noise convs

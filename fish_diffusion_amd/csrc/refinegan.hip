@@ -1,0 +1,390 @@
+// refinegan.hip -- RefineGAN generator (what configs/_base_/archs/hifi_svc_v2.py and
+// configs/vocoder_refinegan.py run): fish_diffusion/modules/vocoders/refinegan/generator.py:313-478.
+//
+//   template = CombToothGen(upsample(f0))                         fp64 blocked scan + sinc               :174-194
+//   x = lrelu(template_conv(template))            -> downs[0]     1-channel VALU conv                    :449,454
+//   per down stage i:  x = linear_down(x, rate_i); x = ResBlock_{c->2c, k7}(x); x = lrelu(x) -> downs[i+1] / bottleneck
+//   x = cat[x, mel_conv(mel)]                                     MFMA conv k7                           :458
+//   per up stage i:    x = linear_up(lrelu(x), rate_i) [+ source_conv(template) at i = 0]; x = cat[x, downs[n-1-i]]
+//                      x = input_conv(x);  x = mean_k AdaIN(ResBlock_k(AdaIN(x)))   k = 3, 7, 11         :147-152,460-474
+//   wav = tanh(output_conv(lrelu(x)))                                                                    :476-478
+//
+// Every Conv1d with more than one input channel runs on the convgemm MFMA family (leaky-relu fused on the B operand,
+// residual add fused in the epilogue); torch.cat never materialises: producers write straight into channel slices of
+// the consumer's input buffer.  Only template_generator="comb" (the default, and what the shipped configs use).
+#include "common.hip.h"
+#include "convplan.hip.h"
+#include "elementwise.hip.h"
+#include "nsf_kernels.hip.h"
+#include "refinegan_kernels.hip.h"
+
+using namespace fdx;
+
+namespace {
+
+constexpr int kMaxStages = 8;
+const int kBranchK[3] = {3, 7, 11};
+const int kDil[3] = {1, 3, 5};
+
+struct RgRes { PackedW c1[3], c2[3]; };
+struct RgLayout {
+  size_t tmpl_w = 0, tmpl_b = 0; int c0 = 0;                      // template_conv raw [c0][1][7]
+  std::vector<RgRes> down; std::vector<int> down_cin;
+  PackedW mel_conv; int c_bott = 0;                                // channels after the down path (= mel_conv out)
+  size_t src_w = 0, src_b = 0; int src_c = 0, src_k = 0, src_stride = 1;
+  struct Up { PackedW input; size_t ad0[3], ad2[3]; RgRes res[3]; int cin = 0, cout = 0, ccat = 0; };
+  std::vector<Up> up;
+  size_t out_w = 0, out_b = 0; int out_c = 0;
+  size_t total_floats = 0;
+};
+
+int rg_validate(const fdx_refinegan_desc* d) {
+  if (!d) return fail(nullptr, FDX_E_ARG, "null refinegan desc");
+  if (d->n_down <= 0 || d->n_down > kMaxStages || d->n_up != d->n_down)
+    return fail(nullptr, FDX_E_ARG, "refinegan: need as many upsample as downsample stages (1..%d)", kMaxStages);
+  long pd = 1, pu = 1;
+  for (int i = 0; i < d->n_down; ++i) {
+    if (d->downsample_rates[i] < 1 || d->upsample_rates[i] < 1) return fail(nullptr, FDX_E_ARG, "refinegan: bad rate");
+    pd *= d->downsample_rates[i]; pu *= d->upsample_rates[i];
+  }
+  if (pd != d->hop_length || pu != d->hop_length)
+    return fail(nullptr, FDX_E_ARG, "refinegan: prod(downsample_rates) == prod(upsample_rates) == hop_length required");
+  for (int i = 0; i < d->n_down; ++i)   // skip connections pair up stage i with down stage n-1-i: lengths must agree
+    if (d->upsample_rates[i] != d->downsample_rates[d->n_down - 1 - i])
+      return fail(nullptr, FDX_E_ARG, "refinegan: upsample_rates must mirror downsample_rates (U-Net skip lengths)");
+  if (d->start_channels < 8 || d->start_channels % 8) return fail(nullptr, FDX_E_ARG, "refinegan: start_channels must be a multiple of 8");
+  if (d->num_mels <= 0 || d->num_mels % 8) return fail(nullptr, FDX_E_ARG, "refinegan: num_mels must be a multiple of 8");
+  int sf0 = 1;
+  for (int i = 1; i < d->n_up; ++i) sf0 *= d->upsample_rates[i];
+  if (2 * sf0 > 128 || (sf0 & (sf0 - 1)) || sf0 / 2 > kHalo) return fail(nullptr, FDX_E_NOIMPL, "refinegan: source_conv kernel %d unsupported", 2 * sf0);
+  return FDX_OK;
+}
+
+void rg_layout(const fdx_refinegan_desc& d, RgLayout& l) {
+  size_t cur = 0;
+  int c = d.start_channels;
+  l.c0 = c;
+  l.tmpl_w = cur; cur += round_up(c * 7, 64);
+  l.tmpl_b = cur; cur += round_up(c, 64);
+  l.down.clear(); l.down_cin.clear();
+  for (int i = 0; i < d.n_down; ++i) {
+    RgRes r;
+    for (int j = 0; j < 3; ++j) {
+      r.c1[j] = plan_conv(cur, 2 * c, j == 0 ? c : 2 * c, 7);
+      r.c2[j] = plan_conv(cur, 2 * c, 2 * c, 7);
+    }
+    l.down.push_back(r); l.down_cin.push_back(c);
+    c *= 2;
+  }
+  l.c_bott = c;
+  l.mel_conv = plan_conv(cur, c, d.num_mels, 7);
+  c *= 2;
+  int sf0 = 1;
+  for (int i = 1; i < d.n_up; ++i) sf0 *= d.upsample_rates[i];
+  l.src_c = c; l.src_k = 2 * sf0; l.src_stride = sf0;
+  l.src_w = cur; cur += round_up(c * l.src_k, 64);
+  l.src_b = cur; cur += round_up(c, 64);
+  l.up.clear();
+  for (int i = 0; i < d.n_up; ++i) {
+    RgLayout::Up u;
+    u.cin = c; u.ccat = c + c / 4; u.cout = c / 2;
+    u.input = plan_conv(cur, u.cout, u.ccat, 7);
+    for (int b = 0; b < 3; ++b) {
+      u.ad0[b] = cur; cur += round_up(u.cout, 64);
+      for (int j = 0; j < 3; ++j) {
+        u.res[b].c1[j] = plan_conv(cur, u.cout, u.cout, kBranchK[b]);
+        u.res[b].c2[j] = plan_conv(cur, u.cout, u.cout, kBranchK[b]);
+      }
+      u.ad2[b] = cur; cur += round_up(u.cout, 64);
+    }
+    l.up.push_back(u);
+    c = u.cout;
+  }
+  l.out_c = c;
+  l.out_w = cur; cur += round_up(c * 7, 64);
+  l.out_b = cur; cur += 64;
+  l.total_floats = cur;
+}
+
+struct RgBufs {   // lives in fdx_ctx as an opaque block (see common.hip.h: rg_state)
+  DevBuf f0up, tmpl, part, noise, bott, mel;
+  // One buffer set PER STAGE: padded rows rely on their halos staying zero, which a buffer re-used with another row
+  // pitch would not guarantee.  [0, n): down stages (ds, ra, tm); [n, 2n): up stages (cat, xi, a1, ra, tm, xm).
+  std::vector<DevBuf> cat, ds, ra, tm, xi, a1, xm;
+  int B = 0, T = 0;
+};
+
+}  // namespace
+
+struct fdx_rg_state {
+  bool ok = false;
+  fdx_refinegan_desc d{};
+  RgLayout l;
+  const float* arena = nullptr;
+  RgBufs b;
+};
+
+static fdx_rg_state* rg(fdx_ctx* h) {
+  if (!h->rg) h->rg = new fdx_rg_state();
+  return static_cast<fdx_rg_state*>(h->rg);
+}
+void fdx_rg_free(void* p) { delete static_cast<fdx_rg_state*>(p); }
+
+extern "C" int fdx_refinegan_num_weights(const fdx_refinegan_desc* d) {
+  if (rg_validate(d)) return FDX_E_ARG;
+  return 2 + d->n_down * 12 + 2 + 2 + d->n_up * (2 + 3 * (1 + 12 + 1)) + 2;
+}
+
+extern "C" int fdx_refinegan_num_noises(const fdx_refinegan_desc* d) {
+  if (rg_validate(d)) return FDX_E_ARG;
+  return 1 + 6 * d->n_up;
+}
+
+extern "C" int fdx_refinegan_packed_bytes(const fdx_refinegan_desc* d, size_t* bytes) {
+  if (rg_validate(d) || !bytes) return FDX_E_ARG;
+  RgLayout l;
+  rg_layout(*d, l);
+  *bytes = l.total_floats * sizeof(float);
+  return FDX_OK;
+}
+
+// Canonical tensor order = the reference module's state_dict order with weight norm folded (generator.py:333-423):
+// template_conv.{w,b}; per down stage: per j: convs1.j.{w,b}, convs2.j.{w,b}; mel_conv.{w,b}; source_conv.{w,b};
+// per up stage: input_conv.{w,b}, per branch: blocks.b.0.weight, per j: convs1.j.{w,b}, convs2.j.{w,b}, blocks.b.2.weight;
+// output_conv.{w,b}.
+extern "C" int fdx_refinegan_pack(const fdx_refinegan_desc* d, const float* const* w, int n, void* out, size_t bytes) {
+  if (rg_validate(d)) return FDX_E_ARG;
+  if (!w || !out) return fail(nullptr, FDX_E_ARG, "null pointer");
+  if (n != fdx_refinegan_num_weights(d)) return fail(nullptr, FDX_E_ARG, "expected %d weight tensors, got %d", fdx_refinegan_num_weights(d), n);
+  RgLayout l;
+  rg_layout(*d, l);
+  if (bytes != l.total_floats * sizeof(float)) return fail(nullptr, FDX_E_ARG, "packed size mismatch");
+  float* A = static_cast<float*>(out);
+  memset(A, 0, bytes);
+  int k = 0;
+  memcpy(A + l.tmpl_w, w[k], (size_t)l.c0 * 7 * sizeof(float));
+  memcpy(A + l.tmpl_b, w[k + 1], (size_t)l.c0 * sizeof(float));
+  k += 2;
+  for (int i = 0; i < d->n_down; ++i) {
+    const int c = l.down_cin[i];
+    for (int j = 0; j < 3; ++j) {
+      pack_conv1d(A, l.down[i].c1[j], w[k], 2 * c, j == 0 ? c : 2 * c, w[k + 1]); k += 2;
+      pack_conv1d(A, l.down[i].c2[j], w[k], 2 * c, 2 * c, w[k + 1]); k += 2;
+    }
+  }
+  pack_conv1d(A, l.mel_conv, w[k], l.c_bott, d->num_mels, w[k + 1]); k += 2;
+  memcpy(A + l.src_w, w[k], (size_t)l.src_c * l.src_k * sizeof(float));
+  memcpy(A + l.src_b, w[k + 1], (size_t)l.src_c * sizeof(float));
+  k += 2;
+  for (int i = 0; i < d->n_up; ++i) {
+    const auto& u = l.up[i];
+    pack_conv1d(A, u.input, w[k], u.cout, u.ccat, w[k + 1]); k += 2;
+    for (int b = 0; b < 3; ++b) {
+      memcpy(A + u.ad0[b], w[k], (size_t)u.cout * sizeof(float)); k += 1;
+      for (int j = 0; j < 3; ++j) {
+        pack_conv1d(A, u.res[b].c1[j], w[k], u.cout, u.cout, w[k + 1]); k += 2;
+        pack_conv1d(A, u.res[b].c2[j], w[k], u.cout, u.cout, w[k + 1]); k += 2;
+      }
+      memcpy(A + u.ad2[b], w[k], (size_t)u.cout * sizeof(float)); k += 1;
+    }
+  }
+  memcpy(A + l.out_w, w[k], (size_t)l.out_c * 7 * sizeof(float));
+  A[l.out_b] = w[k + 1][0];
+  return FDX_OK;
+}
+
+extern "C" int fdx_refinegan_attach(fdx_handle h, const fdx_refinegan_desc* d, const void* dev, size_t bytes) {
+  if (!h) return FDX_E_ARG;
+  if (rg_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
+  fdx_rg_state* st = rg(h);
+  rg_layout(*d, st->l);
+  if (!dev || bytes != st->l.total_floats * sizeof(float)) return fail(h, FDX_E_ARG, "packed arena size mismatch");
+  st->d = *d; st->arena = static_cast<const float*>(dev); st->ok = true;
+  st->b.B = st->b.T = 0;
+  return FDX_OK;
+}
+
+// ================================================================================================ helpers
+namespace {
+
+template <int MODE>
+hipError_t launch_conv1ch(float* y, long y_bs, int ldy, const float* src, long src_bs, const float* w, const float* bias, int C, int L,
+                          int K, int stride, int pad, float slope, int B, hipStream_t s) {
+  const int col_blocks = (L + 255) / 256;
+  int groups = 1;
+  while (groups < C && (long)col_blocks * groups * B < 1024) groups *= 2;
+  const int CG = (C + groups - 1) / groups;
+  const dim3 grid(col_blocks, (C + CG - 1) / CG, B), blk(256);
+#define FDX_C1(KK) case KK: hipLaunchKernelGGL((k_conv1ch<KK, MODE>), grid, blk, 0, s, y, y_bs, ldy, src, src_bs, w, bias, C, CG, L, stride, pad, slope); break;
+  switch (K) {
+    FDX_C1(7) FDX_C1(2) FDX_C1(4) FDX_C1(8) FDX_C1(16) FDX_C1(32) FDX_C1(64) FDX_C1(128)
+    default: return hipErrorInvalidValue;
+  }
+#undef FDX_C1
+  return hipGetLastError();
+}
+
+struct View { float* p; long bs; int ld; };   // p points at (b = 0, c = 0, t = 0) of a padded [B][C][ld] buffer
+
+// ResBlock.forward (generator.py:63-75): three (conv1, conv2) pairs, both dilated by d_j; `same`: first pair has a residual
+int resblock(fdx_ctx* h, const float* A, const RgRes& r, int k, int cout, bool same, int B, int L, View x, View out, View tm,
+             float slope, hipStream_t s) {
+  View cur = x;
+  for (int j = 0; j < 3; ++j) {
+    const int dil = kDil[j], sh = -(k - 1) / 2 * dil;
+    EpiResblock e1{};
+    e1.out = tm.p; e1.resid = nullptr; e1.bs = tm.bs; e1.ld = tm.ld; e1.bias = A + r.c1[j].b_off; e1.M = cout; e1.mode = 0;
+    FDX_HIP(h, (run_conv<true>(A, r.c1[j], B, L, cur.p, cur.bs, cur.ld, sh, dil, slope, e1, s)));
+    EpiResblock e2{};
+    e2.out = out.p; e2.bs = out.bs; e2.ld = out.ld; e2.bias = A + r.c2[j].b_off; e2.M = cout; e2.mode = 0;
+    e2.resid = (j != 0 || same) ? cur.p : nullptr;
+    if (e2.resid && (cur.bs != out.bs || cur.ld != out.ld)) return fail(h, FDX_E_STATE, "refinegan: residual layout mismatch");
+    FDX_HIP(h, (run_conv<true>(A, r.c2[j], B, L, tm.p, tm.bs, tm.ld, sh, dil, slope, e2, s)));
+    cur = out;
+  }
+  return FDX_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ forward
+extern "C" int fdx_refinegan_forward(fdx_handle h, const float* mel, const float* f0, int B, int T, float mel_scale,
+                                     const float* const* noises, uint64_t seed, float* wav, fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  fdx_rg_state* S = rg(h);
+  if (!S->ok) return fail(h, FDX_E_STATE, "fdx_refinegan_forward: no weights attached");
+  if (!mel || !f0 || !wav || B <= 0 || T <= 0) return fail(h, FDX_E_ARG, "fdx_refinegan_forward: bad arguments");
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const auto& d = S->d;
+  const auto& l = S->l;
+  const float* A = S->arena;
+  RgBufs& b = S->b;
+  const float slope = d.leaky_relu_slope, sr = (float)d.sampling_rate;
+  const int n = d.n_down, L = T * d.hop_length;
+  const bool geom = B != b.B || T != b.T;
+  b.B = B; b.T = T;
+
+  // ---- stage geometry.  Down: len[0] = L, len[i+1] = len[i] / rate_i (exact: L = T * prod(rates)); up mirrors it.
+  int dlen[kMaxStages + 1];
+  dlen[0] = L;
+  for (int i = 0; i < n; ++i) dlen[i + 1] = dlen[i] / d.downsample_rates[i];
+  int ulen[kMaxStages];
+  { int t = T; for (int i = 0; i < n; ++i) { t *= d.upsample_rates[i]; ulen[i] = t; } }
+  const int ldL = padded_ld(L, 256), ldT = padded_ld(T, 256);
+  const int n_chunks = (L + kScanChunk - 1) / kScanChunk;
+  FDX_HIP(h, b.f0up.ensure((size_t)B * L * 4, false, s));
+  FDX_HIP(h, b.tmpl.ensure((size_t)B * ldL * 4, geom, s));
+  FDX_HIP(h, b.part.ensure((size_t)B * n_chunks * 8, false, s));
+  if ((int)b.ds.size() != 2 * n)
+    for (auto* v : {&b.ds, &b.ra, &b.tm, &b.xi, &b.a1, &b.xm}) *v = std::vector<DevBuf>(2 * n);
+  for (int i = 0; i < n; ++i) {
+    const size_t dn = (size_t)B * 2 * l.down_cin[i] * padded_ld(dlen[i + 1], 256) * 4;
+    const size_t un = (size_t)B * l.up[i].cout * padded_ld(ulen[i], 256) * 4;
+    FDX_HIP(h, b.ds[i].ensure(dn, geom, s)); FDX_HIP(h, b.ra[i].ensure(dn, geom, s)); FDX_HIP(h, b.tm[i].ensure(dn, geom, s));
+    for (auto* v : {&b.xi, &b.a1, &b.ra, &b.tm, &b.xm}) FDX_HIP(h, (*v)[n + i].ensure(un, geom, s));
+  }
+  FDX_HIP(h, b.bott.ensure((size_t)B * 2 * l.c_bott * ldT * 4, geom, s));
+  FDX_HIP(h, b.mel.ensure((size_t)B * d.num_mels * ldT * 4, geom, s));
+  if ((int)b.cat.size() != n) b.cat = std::vector<DevBuf>(n);
+  for (int i = 0; i < n; ++i) FDX_HIP(h, b.cat[i].ensure((size_t)B * l.up[i].ccat * padded_ld(ulen[i], 256) * 4, geom, s));
+  size_t max_noise = (size_t)B * L;
+  for (int i = 0; i < n; ++i) max_noise = std::max(max_noise, (size_t)B * l.up[i].cout * ulen[i]);
+  if (!noises) FDX_HIP(h, b.noise.ensure(max_noise * 4, false, s));
+  int noise_idx = 0;
+  auto next_noise = [&](size_t count) -> const float* {   // injected draw, or a fresh Philox fill of the scratch buffer
+    const int idx = noise_idx++;
+    if (noises) return noises[idx];
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)(((count + 3) / 4 + 255) / 256)), dim3(256), 0, s, b.noise.f(), count, seed,
+                       (uint64_t)idx << 40);
+    return b.noise.f();
+  };
+
+  // ---- template (generator.py:446-447)
+  hipLaunchKernelGGL(k_f0_upsample, dim3((L + 255) / 256, B), dim3(256), 0, s, b.f0up.f(), f0, T, L);
+  double* part = reinterpret_cast<double*>(b.part.p);
+  hipLaunchKernelGGL(k_comb_partial, dim3(n_chunks, B), dim3(kScanThreads), 0, s, part, b.f0up.f(), L, n_chunks, sr);
+  hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
+  float* tmpl = b.tmpl.f() + kHalo;
+  hipLaunchKernelGGL(k_comb_final, dim3(n_chunks, B), dim3(kScanThreads), 0, s, tmpl, (long)ldL, part, b.f0up.f(),
+                     next_noise((size_t)B * L), L, n_chunks, sr, 0.1f, 0.003f);
+
+  // View of channel slice [c0, ..) of cat buffer i
+  auto cat_view = [&](int i, int c0) {
+    const int ld = padded_ld(ulen[i], 256);
+    return View{b.cat[i].f() + kHalo + (size_t)c0 * ld, (long)l.up[i].ccat * ld, ld};
+  };
+  auto work_view = [&](DevBuf& q, int C, int len) {
+    const int ld = padded_ld(len, 256);
+    return View{q.f() + kHalo, (long)C * ld, ld};
+  };
+
+  // ---- down path.  downs[j] (the leaky-relu'd x, generator.py:454-455) is written straight into the tail channels of the
+  // cat buffer of up stage n-1-j.
+  {
+    View d0 = cat_view(n - 1, l.up[n - 1].cin);   // x = lrelu(template_conv(template)) -> downs[0]
+    FDX_HIP(h, (launch_conv1ch<0>(d0.p, d0.bs, d0.ld, tmpl, (long)ldL, A + l.tmpl_w, A + l.tmpl_b, l.c0, L, 7, 1, 3, slope, B, s)));
+  }
+  for (int i = 0; i < n; ++i) {
+    const int c = l.down_cin[i], len_in = dlen[i], len = dlen[i + 1];
+    View src = cat_view(n - 1 - i, l.up[n - 1 - i].cin);            // downs[i]
+    View xs = work_view(b.ds[i], c, len);
+    hipLaunchKernelGGL(k_resample_down, dim3((len + 255) / 256, B * c), dim3(256), 0, s, xs.p, xs.bs, xs.ld, src.p, src.bs, src.ld, c,
+                       len_in, len, d.downsample_rates[i]);
+    View out = work_view(b.ra[i], 2 * c, len), tm = work_view(b.tm[i], 2 * c, len);
+    if (int rc = resblock(h, A, l.down[i], 7, 2 * c, /*same=*/false, B, len, xs, out, tm, slope, s)) return rc;
+    // the next stage's x = lrelu(x) (saved as downs[i+1]); after the last stage x goes into the bottleneck un-activated
+    if (i + 1 < n) {
+      View dn = cat_view(n - 2 - i, l.up[n - 2 - i].cin);
+      hipLaunchKernelGGL(k_copy_rows_act, ew_grid(len, B * 2 * c), dim3(kEwBlock), 0, s, dn.p, dn.bs, dn.ld, out.p, out.bs, out.ld,
+                         2 * c, len, slope);
+    } else {
+      hipLaunchKernelGGL(k_copy_rows_act, ew_grid(len, B * 2 * c), dim3(kEwBlock), 0, s, b.bott.f() + kHalo, (long)2 * l.c_bott * ldT,
+                         ldT, out.p, out.bs, out.ld, 2 * c, len, 1.f);
+    }
+  }
+  // ---- x = cat[x, mel_conv(mel)]  (generator.py:458; RefineGAN.spec2wav's log10 -> ln rescale folded into the staging copy)
+  hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * d.num_mels), dim3(kEwBlock), 0, s, b.mel.f() + kHalo, (long)d.num_mels * ldT, ldT, mel,
+                     (long)d.num_mels * T, T, d.num_mels, T, mel_scale, (const uint8_t*)nullptr);
+  {
+    EpiBias e{};
+    e.out = b.bott.f() + kHalo + (size_t)l.c_bott * ldT; e.o_bs = (long)2 * l.c_bott * ldT; e.ldo = ldT;
+    e.bias = A + l.mel_conv.b_off; e.M = l.c_bott; e.act = ACT_NONE;
+    FDX_HIP(h, (run_conv<false>(A, l.mel_conv, B, T, b.mel.f() + kHalo, (long)d.num_mels * ldT, ldT, -3, 1, 1.f, e, s)));
+  }
+
+  // ---- up path
+  View x{b.bott.f() + kHalo, (long)2 * l.c_bott * ldT, ldT};
+  int x_len = T;
+  for (int i = 0; i < n; ++i) {
+    const auto& u = l.up[i];
+    const int len = ulen[i];
+    View up = cat_view(i, 0);
+    hipLaunchKernelGGL(k_lrelu_resample_up, dim3((len + 255) / 256, B * u.cin), dim3(256), 0, s, up.p, up.bs, up.ld, x.p, x.bs, x.ld, u.cin,
+                       x_len, len, d.upsample_rates[i], slope);
+    if (i == 0)   // x = x + source_conv(template)
+      FDX_HIP(h, (launch_conv1ch<1>(up.p, up.bs, up.ld, tmpl, (long)ldL, A + l.src_w, A + l.src_b, l.src_c, len, l.src_k, l.src_stride,
+                                    l.src_stride / 2, slope, B, s)));
+    View xi = work_view(b.xi[n + i], u.cout, len), a1 = work_view(b.a1[n + i], u.cout, len), ra = work_view(b.ra[n + i], u.cout, len),
+         tm = work_view(b.tm[n + i], u.cout, len), xm = work_view(b.xm[n + i], u.cout, len);
+    {
+      EpiBias e{};
+      e.out = xi.p; e.o_bs = xi.bs; e.ldo = xi.ld; e.bias = A + u.input.b_off; e.M = u.cout; e.act = ACT_NONE;
+      FDX_HIP(h, (run_conv<false>(A, u.input, B, len, up.p, up.bs, up.ld, -3, 1, 1.f, e, s)));
+    }
+    const dim3 g_ad((len + 255) / 256, B * u.cout), blk(256);
+    const size_t cnt = (size_t)B * u.cout * len;
+    for (int br = 0; br < 3; ++br) {
+      hipLaunchKernelGGL(k_adain, g_ad, blk, 0, s, a1.p, xi.p, xi.bs, xi.ld, next_noise(cnt), A + u.ad0[br], u.cout, len, slope, 0, 1.f);
+      if (int rc = resblock(h, A, u.res[br], kBranchK[br], u.cout, /*same=*/true, B, len, a1, ra, tm, slope, s)) return rc;
+      hipLaunchKernelGGL(k_adain, g_ad, blk, 0, s, xm.p, ra.p, ra.bs, ra.ld, next_noise(cnt), A + u.ad2[br], u.cout, len, slope,
+                         br == 0 ? 0 : (br == 2 ? 2 : 1), 3.f);
+    }
+    x = xm; x_len = len;
+  }
+  // ---- wav = tanh(output_conv(lrelu(x)))
+  hipLaunchKernelGGL(k_conv_post, dim3((L + 255) / 256, B), dim3(256), 0, s, wav, (long)L, x.p, x.bs, x.ld, A + l.out_w, A + l.out_b, l.out_c, L,
+                     slope);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}

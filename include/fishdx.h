@@ -162,6 +162,38 @@ int fdx_nsf_source(fdx_handle h, const float* f0, int B, int T, const float* ran
                    const float* src_noise, uint64_t seed, float* har, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * RefineGAN generator -- replaces modules/vocoders/refinegan/generator.py:313-478
+ * (RefineGANGenerator), :14-83 (ResBlock), :86-107 (AdaIN), :110-156 (ParallelResBlock), :159-194
+ * (CombToothGen) and the scalar glue of RefineGAN.spec2wav, refinegan/refinegan.py:67-78.
+ * template_generator = "comb" only (the default; what hifi_svc_v2 / vocoder_refinegan configure).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int sampling_rate;            /* 44100 */
+  int hop_length;               /* 256 = prod(downsample_rates) = prod(upsample_rates) */
+  int n_down; int downsample_rates[FDX_MAX_STAGES];   /* (2, 2, 8, 8) */
+  int n_up;   int upsample_rates[FDX_MAX_STAGES];     /* (8, 8, 2, 2): must mirror the downsample rates */
+  int num_mels;                 /* 128 (256 inside HiFiSinger) */
+  int start_channels;           /* 16 */
+  float leaky_relu_slope;       /* 0.2 */
+} fdx_refinegan_desc;
+/* Canonical order = the module's state_dict order with weight norm folded: template_conv.{weight,bias};
+ * per down stage i, per j<3: downsample_blocks.i.1.convs1.j.{weight,bias}, convs2.j.{weight,bias}; mel_conv.*;
+ * source_conv.*; per up stage i: upsample_conv_blocks.i.input_conv.*, per branch b<3: blocks.b.0.weight,
+ * per j<3: blocks.b.1.convs1.j.*, convs2.j.*, then blocks.b.2.weight; output_conv.*. */
+int fdx_refinegan_num_weights(const fdx_refinegan_desc* d);
+int fdx_refinegan_num_noises(const fdx_refinegan_desc* d);   /* 1 + 6 * n_up */
+int fdx_refinegan_packed_bytes(const fdx_refinegan_desc* d, size_t* bytes);
+int fdx_refinegan_pack(const fdx_refinegan_desc* d, const float* const* host_weights, int n_weights,
+                       void* host_packed, size_t bytes);
+int fdx_refinegan_attach(fdx_handle h, const fdx_refinegan_desc* d, const void* dev_packed, size_t bytes);
+/* mel: dev [B][num_mels][T]; f0: dev [B][T]; wav: dev [B][T*hop_length].  noises: HOST array of
+ * fdx_refinegan_num_noises() device pointers holding the standard-normal draws in the reference's order
+ * ([B][1][L] comb noise, then per up stage / branch / (pre, post) AdaIN: [B][C][L_stage]), or NULL =>
+ * device Philox(seed). */
+int fdx_refinegan_forward(fdx_handle h, const float* mel, const float* f0, int B, int T, float mel_scale,
+                          const float* const* noises, uint64_t seed, float* wav, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * STFT / mel -- replaces utils/pitch_adjustable_mel.py:33-96 (PitchAdjustableMelSpectrogram.__call__),
  * utils/audio.py:11-18 (dynamic_range_compression) and the tail of NsfHifiGAN.wav2spec,
  * nsf_hifigan.py:101-107.

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
-from oracle import _ref_import, features_ref, mel_ref, nsf_hifigan_ref, sampler_ref, wavenet_ref  # noqa: E402
+from oracle import _ref_import, features_ref, mel_ref, nsf_hifigan_ref, refinegan_ref, sampler_ref, wavenet_ref  # noqa: E402
 
 
 def sha1_of(tensors) -> str:
@@ -257,6 +257,34 @@ def main():
     arrays.update(ids=ids, mix=mix, mix_t=mix_t, shift=shift, energy=energy, masks=ref["x_masks"],
                   sha1_a=np.array(state_sha1(sd_a)), sha1_b=np.array(state_sha1(sd_b)))
     save("frontend", **arrays)
+
+    # ---------------------------------------------------------------- RefineGAN generator
+    print("refinegan")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fish_diffusion_refinegan_generator", os.path.join(_ref_import.REFERENCE_ROOT, "fish_diffusion/modules/vocoders/refinegan/generator.py"))
+    rgmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rgmod)
+    for tag, cfg, seed, (B, T) in (("small", dict(refinegan_ref.CONFIG), 21, (2, 5)),
+                                   ("hifisinger", dict(refinegan_ref.CONFIG, num_mels=256), 22, (1, 37))):
+        gen = rgmod.RefineGANGenerator(**cfg)
+        gen.remove_weight_norm()
+        gen.eval()
+        rsd = refinegan_ref.seeded_state(seed, cfg)
+        gen.load_state_dict(rsd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        mel = torch.randn(B, cfg["num_mels"], T, generator=g) * 0.5 - 2.0
+        f0 = torch.stack([synth_f0(T, cfg["sampling_rate"] / cfg["hop_length"]) * (1 + 0.3 * b) for b in range(B)])[:, None]
+        torch.manual_seed(seed + 2)
+        ref = gen(mel, f0)
+        torch.manual_seed(seed + 2)                      # replay the reference's randn_like draws, in order
+        noises = [torch.randn(sh) for sh in refinegan_ref.noise_shapes(cfg, B, T)]
+        taps = {}
+        mine = refinegan_ref.generator_forward(rsd, cfg, mel, f0, noises, taps)
+        assert torch.equal(mine, ref), f"oracle refinegan {tag} != reference"
+        save(f"refinegan_{tag}", mel=mel, f0=f0, wav=ref, template=taps["template"], bottleneck=taps["bottleneck"], up_0=taps["up_0"],
+             seed=np.int64(seed), noise_seed=np.int64(seed + 2), weights_sha1=np.array(state_sha1(rsd)),
+             noise_sha1=np.array(sha1_of(noises)), config=np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()})))
 
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)

@@ -580,3 +580,67 @@ def test_pipeline_ragged_utterances_sharded_and_batched(dev):
                     wref = nsf_hifigan_ref.spec2wav(gsd, h, ref[b, :n].T.contiguous(), f0s[i], ri_all[i:i + 1], sn_all[i:i + 1, :n * 256],
                                                     use_natural_log=False)
                     assert abs_err(seen[i][1], wref) < 5e-4, i   # vocoder fed with the HIP mel (<=1e-3 rel off the oracle's)
+
+
+# ------------------------------------------------------------------------------------------------ RefineGAN (8f row 2)
+def _refinegan(cfg, sd, dev):
+    from fish_diffusion_amd import RefineGANGenerator
+    gen = RefineGANGenerator(**cfg)
+    gen.load_folded_state(sd)
+    return gen.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag", ["small", "hifisinger"])
+def test_refinegan_generator_matches_reference_golden(dev, tag):
+    import hashlib
+    from oracle import refinegan_ref
+    g = load(f"refinegan_{tag}")
+    cfg = json.loads(str(g["config"]))
+    sd = refinegan_ref.seeded_state(int(g["seed"]), cfg)
+    assert sha1_state(sd) == str(g["weights_sha1"])
+    gen = _refinegan(cfg, sd, dev)
+    B, _, T = g["mel"].shape
+    assert gen.noise_shapes(B, T) == refinegan_ref.noise_shapes(cfg, B, T)
+    torch.manual_seed(int(g["noise_seed"]))
+    noises = [torch.randn(s) for s in gen.noise_shapes(B, T)]
+    hsh = hashlib.sha1()
+    for nz in noises:
+        hsh.update(nz.numpy().tobytes())
+    assert hsh.hexdigest() == str(g["noise_sha1"])
+    wav = gen(g["mel"].to(dev), g["f0"].to(dev), noises=[nz.to(dev) for nz in noises])
+    assert wav.shape == g["wav"].shape
+    err = abs_err(wav.cpu(), g["wav"])
+    print(f"refinegan {tag}: wav abs err {err:.3e}  (peak |wav| {float(g['wav'].abs().max()):.3f})")
+    assert err < WAV_ABS
+
+
+def test_refinegan_interfaces_and_device_rng(dev):
+    """RefineGAN wrapper (refinegan.py:16-100): spec2wav glue (log10 rescale, in-place key shift), wav2spec, perf-mode RNG."""
+    from fish_diffusion_amd import RefineGAN
+    from oracle import mel_ref, refinegan_ref
+    cfg = dict(refinegan_ref.CONFIG)
+    sd = refinegan_ref.seeded_state(31, cfg)
+    config = dict(generator=cfg, sampling_rate=44100, n_fft=2048, win_length=2048, hop_length=256, f_min=40, f_max=16000, num_mels=128)
+    voc = RefineGAN.from_state(config, sd, use_natural_log=False).to(dev)
+    T = 9
+    g = torch.Generator().manual_seed(2)
+    mel = (torch.randn(128, T, generator=g) * 0.5 - 2.0) / 2.30259
+    f0 = synth_f0(T, 44100 / 256)
+    noises = [torch.randn(s, generator=g) for s in voc.model.noise_shapes(1, T)]
+    with torch.no_grad():
+        ref = refinegan_ref.spec2wav(sd, cfg, mel, f0.clone(), noises, key_shift=2, use_natural_log=False)
+    f0d = f0.clone().to(dev)
+    wav = voc.model(mel.to(dev)[None], (f0d * 2 ** (2 / 12))[None], noises=[n.to(dev) for n in noises], mel_scale=2.30259)
+    assert abs_err(wav.view(-1).cpu(), ref) < WAV_ABS
+    voc.model.rng = "philox"
+    a = voc.spec2wav(mel.to(dev), f0d, key_shift=0)
+    assert a.shape == (T * 256,) and torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
+    audio = load("mel")["wav"].to(dev)
+    out = voc.wav2spec(audio)
+    want = mel_ref.wav2spec(load("mel")["wav"], use_natural_log=False, hop=256)
+    assert out.shape == want.shape and abs_err(out.cpu(), want) < 2e-3
+    with pytest.raises(NotImplementedError):
+        from fish_diffusion_amd import RefineGANGenerator
+        RefineGANGenerator(template_generator="sine")
+    with pytest.raises(ValueError):
+        voc.model(mel.to(dev)[None], f0d[None, :-1])

@@ -113,3 +113,20 @@ def test_frontend_oracle_matches_reference():
         out = features_ref.forward_features(sd, g["contents"], spk, g["f0"], mel_lens=lens, mel_max_len=T, **kw)
         assert rel_err(out["features"], g[f"features_{tag}"]) < 1e-6, tag
         assert torch.equal(out["x_masks"], g["masks"].bool())
+
+
+@pytest.mark.parametrize("tag", ["small", "hifisinger"])
+def test_refinegan_oracle_matches_reference(tag):
+    from oracle import refinegan_ref
+    g = load(f"refinegan_{tag}")
+    cfg = json.loads(str(g["config"]))
+    sd = refinegan_ref.seeded_state(int(g["seed"]), cfg)
+    assert sha1_state(sd) == str(g["weights_sha1"])
+    B, _, T = g["mel"].shape
+    torch.manual_seed(int(g["noise_seed"]))
+    noises = [torch.randn(s) for s in refinegan_ref.noise_shapes(cfg, B, T)]
+    taps = {}
+    with torch.no_grad():
+        wav = refinegan_ref.generator_forward(sd, cfg, g["mel"], g["f0"], noises, taps)
+    assert abs_err(wav, g["wav"]) < 1e-5
+    assert abs_err(taps["template"], g["template"]) < 1e-6 and rel_err(taps["up_0"], g["up_0"]) < 1e-5
