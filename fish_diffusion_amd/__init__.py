@@ -8,6 +8,7 @@ from .nsf_hifigan import NsfHifiGAN, Generator  # noqa: F401
 from .mel import PitchAdjustableMelSpectrogram  # noqa: F401
 from .diffsinger import ENCODERS, DiffSinger, NaiveProjectionEncoder, pitch_to_scale  # noqa: F401
 from .refinegan import RefineGAN, RefineGANGenerator  # noqa: F401
+from .hifisinger import HiFiSinger  # noqa: F401
 
 __all__ = ["DENOISERS", "DIFFUSIONS", "VOCODERS", "install", "WaveNet", "GaussianDiffusion", "NsfHifiGAN", "Generator",
-           "PitchAdjustableMelSpectrogram", "ENCODERS", "DiffSinger", "NaiveProjectionEncoder", "pitch_to_scale", "RefineGAN", "RefineGANGenerator"]
+           "PitchAdjustableMelSpectrogram", "ENCODERS", "DiffSinger", "NaiveProjectionEncoder", "pitch_to_scale", "RefineGAN", "RefineGANGenerator", "HiFiSinger"]

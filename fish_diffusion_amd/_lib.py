@@ -47,6 +47,7 @@ class FeatureTerm(C.Structure):
 TERM_VECTOR, TERM_EMBEDDING, TERM_SCALAR_LINEAR = 0, 1, 2
 PRE_NONE, PRE_PITCH_TO_SCALE = 0, 1
 MAX_FEATURE_TERMS = 6
+ACT_NONE, ACT_SILU = 0, 1
 
 
 class MelDesc(C.Structure):
@@ -87,6 +88,8 @@ _SIGS = {
     "fdx_refinegan_attach": (C.c_int, [_P, C.POINTER(RefineGanDesc), _P, C.c_size_t]),
     "fdx_refinegan_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.POINTER(_P), C.c_uint64, _P, _P]),
     "fdx_features_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm), C.c_int, _P, _P]),
+    "fdx_features_forward_ex": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm), C.c_int, C.c_int, _P,
+                                           C.c_int, _P, _P]),
     "fdx_debug_conv1d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, _P, _P]),
     "fdx_prof_enable": (C.c_int, [_P, C.c_int]),

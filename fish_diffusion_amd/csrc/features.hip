@@ -23,8 +23,9 @@ constexpr int kTC = 32;   // contraction chunk
 
 struct FeatArgs {
   const float* x; const float* w; const float* bias;   // contents [B][T][Din], W [E][Din], bias [E] or null
-  float* out;                                           // [B][T][E]
-  int B, T, Din, E, n_terms;
+  float* out;                                           // [B][T][E], or [B][E][T] when channel_first
+  const uint8_t* mask;                                  // [B][T] bytes (1 = padding -> output 0) or null
+  int B, T, Din, E, n_terms, act, channel_first;
   fdx_feature_term terms[FDX_MAX_FEATURE_TERMS];
 };
 
@@ -86,7 +87,10 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
         v += y;
       }
     }
-    a.out[((long)b * a.T + t) * a.E + e] = v;
+    if (a.act == FDX_ACT_SILU) v = v / (1.f + expf(-v));      // nn.SiLU
+    if (a.mask && a.mask[(long)b * a.T + t]) v = 0.f;
+    if (a.channel_first) a.out[((long)b * a.E + e) * a.T + t] = v;
+    else a.out[((long)b * a.T + t) * a.E + e] = v;
   }
 }
 
@@ -95,7 +99,14 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
 extern "C" int fdx_features_forward(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
                                     const float* b_text, const fdx_feature_term* terms, int n_terms, float* features,
                                     fdx_stream st) {
+  return fdx_features_forward_ex(h, contents, B, T, Din, E, w_text, b_text, terms, n_terms, FDX_ACT_NONE, nullptr, 0, features, st);
+}
+
+extern "C" int fdx_features_forward_ex(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
+                                       const float* b_text, const fdx_feature_term* terms, int n_terms, int act,
+                                       const uint8_t* mask, int channel_first, float* features, fdx_stream st) {
   if (!h) return FDX_E_ARG;
+  if (act != FDX_ACT_NONE && act != FDX_ACT_SILU) return fail(h, FDX_E_ARG, "fdx_features_forward_ex: unknown activation %d", act);
   if (!contents || !w_text || !features || B <= 0 || T <= 0 || Din <= 0 || E <= 0)
     return fail(h, FDX_E_ARG, "fdx_features_forward: bad arguments");
   if (n_terms < 0 || n_terms > FDX_MAX_FEATURE_TERMS || (n_terms && !terms))
@@ -103,6 +114,7 @@ extern "C" int fdx_features_forward(fdx_handle h, const float* contents, int B, 
   FeatArgs a{};
   a.x = contents; a.w = w_text; a.bias = b_text; a.out = features;
   a.B = B; a.T = T; a.Din = Din; a.E = E; a.n_terms = n_terms;
+  a.act = act; a.mask = mask; a.channel_first = channel_first;
   for (int k = 0; k < n_terms; ++k) {
     const fdx_feature_term& m = terms[k];
     if (m.kind < FDX_TERM_VECTOR || m.kind > FDX_TERM_SCALAR_LINEAR || !m.values)

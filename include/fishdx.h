@@ -240,6 +240,13 @@ typedef struct {
 /* contents: dev [B][T][Din]; w_text: dev [E][Din]; b_text: dev [E] or NULL; terms: HOST array; features: dev [B][T][E]. */
 int fdx_features_forward(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
                          const float* b_text, const fdx_feature_term* terms, int n_terms, float* features, fdx_stream s);
+/* Same launch with a trailing activation (nn.SiLU), an optional padding mask (dev [B][T] bytes, 1 => output 0) and an
+ * optional channel-first output [B][E][T]: the two Linear + SiLU layers of HiFiSinger's feature_fuser and its
+ * `features *= 1 - src_masks` (archs/hifisinger/core.py:24-29,109-110), writing what the generator consumes (:136-139). */
+enum { FDX_ACT_NONE = 0, FDX_ACT_SILU = 1 };
+int fdx_features_forward_ex(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
+                            const float* b_text, const fdx_feature_term* terms, int n_terms, int act,
+                            const uint8_t* mask, int channel_first, float* features, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level test / profiling hooks (used by tests/ and bench.py only)

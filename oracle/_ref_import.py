@@ -71,6 +71,22 @@ def available() -> bool:
 _loaded = {}
 
 
+def _hifisinger_methods():
+    """`HiFiSinger.get_mask_from_lengths`, `.forward_features` and `.forward` compiled from the reference file's own source
+    (fish_diffusion/archs/hifisinger/core.py:39-141); the module imports the whole encoders package at the top."""
+    import ast
+    import torch
+    path = os.path.join(REFERENCE_ROOT, "fish_diffusion/archs/hifisinger/core.py")
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "HiFiSinger")
+    names = ("get_mask_from_lengths", "forward_features", "forward")
+    funcs = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), path, "exec"), ns)
+    return tuple(ns[n] for n in names)
+
+
 def _diffsinger_methods():
     """`DiffSinger.get_mask_from_lengths` and `DiffSinger.forward_features` compiled from the reference file's own source
     (fish_diffusion/archs/diffsinger/diffsinger.py:42-134) -- the module itself imports loralib / lightning / wandb /
@@ -155,6 +171,7 @@ def load():
         NaiveProjectionEncoder=naive.NaiveProjectionEncoder,
         pitch_to_scale=pitch.pitch_to_scale,
         diffsinger_methods=_diffsinger_methods,
+        hifisinger_methods=_hifisinger_methods,
         WaveNet=wavenet.WaveNet,
         GaussianDiffusion=diffusion.GaussianDiffusion,
         DENOISERS=diffusion.DENOISERS,

@@ -82,3 +82,47 @@ def seeded_frontend_state(seed: int, content_dim=256, hidden=256, n_speakers=10,
     if energy:
         sd["energy_encoder.projection.weight"], sd["energy_encoder.projection.bias"] = lin(hidden, 1)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------ HiFiSinger (hifi_svc_v2)
+def hifisinger_features(sd: SD, contents, speakers, contents_lens, contents_max_len, pitch_shift=None, energy=None) -> dict:
+    """archs/hifisinger/core.py:55-115 without the phones2mel gather: text Linear + speaker embedding (+ pitch-shift / energy
+    projections), then feature_fuser = Linear, SiLU, Linear, SiLU (:24-29) and `features *= 1 - src_masks` (:109-110).
+    Keys: text_encoder.projection.*, speaker_encoder.embedding.weight, {pitch_shift,energy}_encoder.projection.*,
+    feature_fuser.{0,2}.{weight,bias}."""
+    src_masks = mask_from_lengths(contents_lens, contents_max_len) if contents_lens is not None else None
+    features = F.linear(contents, sd["text_encoder.projection.weight"], sd["text_encoder.projection.bias"])
+    if speakers.ndim in (2, 3) and torch.is_floating_point(speakers):
+        emb = speakers
+    else:
+        emb = F.embedding(speakers, sd["speaker_encoder.embedding.weight"])
+    if emb.ndim == 2:
+        emb = emb[:, None, :]
+    features = features + emb
+    if pitch_shift is not None and "pitch_shift_encoder.projection.weight" in sd:
+        e = F.linear(pitch_shift, sd["pitch_shift_encoder.projection.weight"], sd["pitch_shift_encoder.projection.bias"])
+        features = features + (e[:, None, :] if e.ndim == 2 else e)
+    if energy is not None and "energy_encoder.projection.weight" in sd:
+        e = F.linear(energy, sd["energy_encoder.projection.weight"], sd["energy_encoder.projection.bias"])
+        features = features + (e[:, None, :] if e.ndim == 2 else e)
+    features = F.silu(F.linear(features, sd["feature_fuser.0.weight"], sd["feature_fuser.0.bias"]))
+    features = F.silu(F.linear(features, sd["feature_fuser.2.weight"], sd["feature_fuser.2.bias"]))
+    features = features * (1 - src_masks[:, :, None].float())
+    return dict(features=features, src_masks=src_masks)
+
+
+def seeded_hifisinger_state(seed: int, content_dim=768, hidden=256, n_speakers=10) -> SD:
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out_f, in_f):
+        bound = (6.0 / (out_f + in_f)) ** 0.5
+        return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound, (torch.rand(out_f, generator=g) * 2 - 1) * 0.05
+
+    sd = {}
+    sd["text_encoder.projection.weight"], sd["text_encoder.projection.bias"] = lin(hidden, content_dim)
+    sd["speaker_encoder.embedding.weight"] = torch.randn(n_speakers, hidden, generator=g) * hidden ** -0.5
+    sd["pitch_shift_encoder.projection.weight"], sd["pitch_shift_encoder.projection.bias"] = lin(hidden, 1)
+    sd["energy_encoder.projection.weight"], sd["energy_encoder.projection.bias"] = lin(hidden, 1)
+    sd["feature_fuser.0.weight"], sd["feature_fuser.0.bias"] = lin(hidden, hidden)
+    sd["feature_fuser.2.weight"], sd["feature_fuser.2.bias"] = lin(hidden, hidden)
+    return sd

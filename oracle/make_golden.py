@@ -286,6 +286,51 @@ def main():
              seed=np.int64(seed), noise_seed=np.int64(seed + 2), weights_sha1=np.array(state_sha1(rsd)),
              noise_sha1=np.array(sha1_of(noises)), config=np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()})))
 
+    # ---------------------------------------------------------------- HiFiSinger (svc_hifisinger_v2): encoders + fuser + RefineGAN
+    print("hifisinger")
+    get_mask_h, fwd_feat_h, fwd_h = R["hifisinger_methods"]()
+    hcfg = dict(refinegan_ref.CONFIG, num_mels=256)
+
+    class RefHiFiSinger(torch.nn.Module):   # encoders + generator are real reference classes, the 3 methods its own source
+        forward_features = fwd_feat_h
+        forward = fwd_h
+
+        def __init__(self):
+            super().__init__()
+            self.get_mask_from_lengths = get_mask_h.__func__ if hasattr(get_mask_h, "__func__") else get_mask_h
+            self.text_encoder = Enc(768, 256)
+            self.speaker_encoder = Enc(10, 256, use_embedding=True)
+            self.pitch_shift_encoder = Enc(1, 256)
+            self.energy_encoder = Enc(1, 256)
+            self.feature_fuser = torch.nn.Sequential(torch.nn.Linear(256, 256), torch.nn.SiLU(), torch.nn.Linear(256, 256), torch.nn.SiLU())
+            self.encoder_type = "RefineGAN"
+            self.encoder = rgmod.RefineGANGenerator(**hcfg)
+            self.encoder.remove_weight_norm()
+
+    hsd = features_ref.seeded_hifisinger_state(8)
+    hgsd = refinegan_ref.seeded_state(9, hcfg)
+    ref_mod = RefHiFiSinger().eval()
+    ref_mod.load_state_dict({**hsd, **{"encoder." + k: v for k, v in hgsd.items()}}, strict=True)
+    g = torch.Generator().manual_seed(40)
+    B, T = 2, 11
+    contents = torch.randn(B, T, 768, generator=g)
+    ids = torch.tensor([1, 4])
+    lens = torch.tensor([11, 8])
+    f0 = torch.stack([synth_f0(T, 44100 / 256), synth_f0(T, 44100 / 256) * 1.5])[:, :, None]
+    shift = torch.randn(B, 1, generator=g)
+    energy = torch.rand(B, T, 1, generator=g)
+    torch.manual_seed(41)
+    ref = ref_mod(ids, contents, lens, T, pitches=f0, pitch_shift=shift, energy=energy)
+    ref_feat = ref_mod.forward_features(ids, contents, lens, T, pitch_shift=shift, energy=energy)["features"]
+    torch.manual_seed(41)
+    noises = [torch.randn(sh) for sh in refinegan_ref.noise_shapes(hcfg, B, T)]
+    feats = features_ref.hifisinger_features(hsd, contents, ids, lens, T, shift, energy)
+    mine = refinegan_ref.generator_forward(hgsd, hcfg, feats["features"].transpose(1, 2), f0.transpose(1, 2), noises)
+    assert torch.equal(feats["features"], ref_feat) and torch.equal(mine, ref), "oracle hifisinger != reference"
+    save("hifisinger", contents=contents, ids=ids, lens=lens, f0=f0, shift=shift, energy=energy, features=ref_feat, wav=ref,
+         noise_seed=np.int64(41), sha1_frontend=np.array(state_sha1(hsd)), sha1_generator=np.array(state_sha1(hgsd)),
+         config=np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in hcfg.items()})))
+
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("done")

@@ -644,3 +644,38 @@ def test_refinegan_interfaces_and_device_rng(dev):
         RefineGANGenerator(template_generator="sine")
     with pytest.raises(ValueError):
         voc.model(mel.to(dev)[None], f0d[None, :-1])
+
+
+def test_hifisinger_end_to_end_matches_reference_golden(dev):
+    """svc_hifisinger_v2's model (archs/hifisinger/core.py): encoders -> feature_fuser -> RefineGAN generator, features and
+    waveform vs the reference's own code on real encoder / generator instances (oracle/make_golden.py)."""
+    from fish_diffusion_amd import HiFiSinger
+    from oracle import features_ref, refinegan_ref
+    g = load("hifisinger")
+    cfg = json.loads(str(g["config"]))
+    hsd, gsd = features_ref.seeded_hifisinger_state(8), refinegan_ref.seeded_state(9, cfg)
+    assert sha1_state(hsd) == str(g["sha1_frontend"]) and sha1_state(gsd) == str(g["sha1_generator"])
+    lin1 = dict(type="NaiveProjectionEncoder", input_size=1, output_size=256)
+    model = HiFiSinger(dict(hidden_size=256, text_encoder=dict(type="NaiveProjectionEncoder", input_size=768, output_size=256),
+                            speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=256, use_embedding=True),
+                            pitch_shift_encoder=lin1, energy_encoder=lin1, encoder=dict(type="RefineGAN", **cfg)))
+    model.encoder.load_folded_state(gsd)
+    missing, unexpected = model.load_state_dict(hsd, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") for k in missing)
+    model = model.to(dev).eval()
+    lens, ids = torch.as_tensor(g["lens"]).to(dev), torch.as_tensor(g["ids"]).to(dev)
+    B, T, _ = g["contents"].shape
+    c, shift, energy, f0 = g["contents"].to(dev), g["shift"].to(dev), g["energy"].to(dev), g["f0"].to(dev)
+    out = model.forward_features(ids, c, lens, T, pitch_shift=shift, energy=energy)
+    assert rel_err(out["features"].cpu(), g["features"]) < 1e-5
+    assert (out["features"][1, 8:] == 0).all()                      # masked frames are exactly 0 (core.py:110)
+    torch.manual_seed(int(g["noise_seed"]))
+    noises = [torch.randn(s).to(dev) for s in model.encoder.noise_shapes(B, T)]
+    wav = model(ids, c, lens, T, pitches=f0, pitch_shift=shift, energy=energy, noises=noises)
+    err = abs_err(wav.cpu(), g["wav"])
+    print(f"hifisinger end to end: wav abs err {err:.3e}")
+    assert wav.shape == g["wav"].shape and err < WAV_ABS
+    with pytest.raises(NotImplementedError):
+        HiFiSinger(dict(hidden_size=256, text_encoder=dict(type="NaiveProjectionEncoder", input_size=768, output_size=256),
+                        speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=256, use_embedding=True),
+                        encoder=dict(resblock="1")))

@@ -130,3 +130,20 @@ def test_refinegan_oracle_matches_reference(tag):
         wav = refinegan_ref.generator_forward(sd, cfg, g["mel"], g["f0"], noises, taps)
     assert abs_err(wav, g["wav"]) < 1e-5
     assert abs_err(taps["template"], g["template"]) < 1e-6 and rel_err(taps["up_0"], g["up_0"]) < 1e-5
+
+
+def test_hifisinger_oracle_matches_reference():
+    from oracle import features_ref, refinegan_ref
+    g = load("hifisinger")
+    cfg = json.loads(str(g["config"]))
+    hsd, gsd = features_ref.seeded_hifisinger_state(8), refinegan_ref.seeded_state(9, cfg)
+    assert sha1_state(hsd) == str(g["sha1_frontend"]) and sha1_state(gsd) == str(g["sha1_generator"])
+    lens, ids = torch.as_tensor(g["lens"]), torch.as_tensor(g["ids"])
+    B, T, _ = g["contents"].shape
+    feats = features_ref.hifisinger_features(hsd, g["contents"], ids, lens, T, g["shift"], g["energy"])
+    assert rel_err(feats["features"], g["features"]) < 1e-6
+    torch.manual_seed(int(g["noise_seed"]))
+    noises = [torch.randn(s) for s in refinegan_ref.noise_shapes(cfg, B, T)]
+    with torch.no_grad():
+        wav = refinegan_ref.generator_forward(gsd, cfg, feats["features"].transpose(1, 2), g["f0"].transpose(1, 2), noises)
+    assert abs_err(wav, g["wav"]) < 1e-5
