@@ -240,8 +240,10 @@ def main():
         _lib.check(_lib.lib().fdx_prof_enable(eng.h, args.prof_stride), eng.h)
         sync_barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         wav = one_step(diff, voc, feats, f0, args.interval, streams)
+        if k == 0 and not args.no_prof:   # the dominant kernel is timed on the first timed step only (it needs the eager
+            _lib.check(_lib.lib().fdx_prof_enable(eng.h, -1), eng.h)   # launch path); the other steps replay the hipGraph
     sync_barrier()
     dt = time.perf_counter() - t0
     dt = fdist.barrier_max(dt, dev)
@@ -260,7 +262,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": "convgemm_kernel<2,splitK,EpiGate> (dilated conv k=3 + gate, residual block)",
                         "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                        "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch", "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch of the first timed step", "avg_launch_us": round(avg_ms * 1e3, 2),
                         "timing": "hipExtLaunchKernel start/stop events on the launch stream, timed region",
                         "flops_per_launch": fl.value}
 

@@ -58,6 +58,7 @@ extern "C" const char* fdx_last_error(fdx_handle h) {
 
 extern "C" int fdx_prof_enable(fdx_handle h, int on) {
   if (!h) return FDX_E_ARG;
+  if (on < 0) { h->prof.on = false; return FDX_OK; }   // pause: keep what was recorded for fdx_prof_read
   h->prof.on = on != 0;
   h->prof.stride = on > 1 ? on : 1;   // on = N > 1: sample every N-th launch (keeps the probe effect out of `value`)
   h->prof.seen = 0;

@@ -262,7 +262,8 @@ int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, int T, const 
  * events carry that dispatch's own begin/end timestamps on its stream (the quantity rocprofv3's
  * kernel trace reports).  fdx_prof_read returns the number of launches recorded and their total
  * duration (synchronises those events). */
-/* on = 0: off; 1: every launch; N > 1: every N-th launch (sampling keeps the probe effect negligible). */
+/* on = 0: off (and forget); 1: every launch; N > 1: every N-th launch (sampling keeps the probe effect negligible);
+ * -1: pause -- stop recording but keep the recorded launches for fdx_prof_read. */
 int fdx_prof_enable(fdx_handle h, int on);
 int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch);
 /* Median elapsed time (ms) of an EMPTY hipEventRecord start/stop pair on stream s (diagnostic: what
