@@ -6,7 +6,8 @@ forward_features = three fused launches of the front-end kernel (`fdx_features_f
     feature_fuser[0] Linear + SiLU                                            core.py:24-29,107
     feature_fuser[2] Linear + SiLU, `*= 1 - src_masks`, written channel-first core.py:107-110 (and the transpose of :137)
 forward = forward_features + `RefineGANGenerator(features, pitches)` (core.py:136-139).
-The HiFiGAN-generator variant of the encoder (`encoder.type` absent, core.py:36-37) and phones2mel are not built.
+Both encoder variants are built: RefineGAN (hifi_svc_v2) and the NSF-HiFiGAN generator with num_mels = hidden_size
+(hifi_svc v1, core.py:35-37,140-141).  phones2mel (SVS) is not.
 """
 from __future__ import annotations
 
@@ -17,6 +18,7 @@ from torch import nn
 
 from . import _lib
 from .diffsinger import ENCODERS, DiffSinger, NaiveProjectionEncoder, _cfg_get
+from .nsf_hifigan import AttrDict, Generator
 from .refinegan import RefineGANGenerator
 
 
@@ -32,11 +34,13 @@ class HiFiSinger(nn.Module):
         hidden = _cfg_get(model_config, "hidden_size")
         self.feature_fuser = nn.Sequential(nn.Linear(hidden, hidden), nn.SiLU(), nn.Linear(hidden, hidden), nn.SiLU())
         enc = dict(_cfg_get(model_config, "encoder"))
-        if enc.pop("type", None) != "RefineGAN":
-            raise NotImplementedError("only the RefineGAN encoder of HiFiSinger (hifi_svc_v2) is built; the NSF-HiFiGAN "
-                                      "generator variant (core.py:36-37) is not")
-        self.encoder_type = "RefineGAN"
-        self.encoder = RefineGANGenerator(**enc)
+        if enc.get("type") == "RefineGAN":        # hifi_svc_v2 (core.py:31-34)
+            enc.pop("type")
+            self.encoder_type = "RefineGAN"
+            self.encoder = RefineGANGenerator(**enc)
+        else:                                      # hifi_svc v1: the NSF-HiFiGAN generator fed with the fused features (core.py:35-37)
+            self.encoder_type = "HiFiGAN"
+            self.encoder = Generator(AttrDict(enc))
         self._handle: Optional[_lib.Handle] = None
 
     get_mask_from_lengths = staticmethod(DiffSinger.get_mask_from_lengths)
@@ -108,4 +112,7 @@ class HiFiSinger(nn.Module):
         """core.py:117-141: pitches [B, T, 1] -> waveform [B, 1, T * hop_length]."""
         f = self.forward_features(speakers, contents, contents_lens, contents_max_len, pitch_shift=pitch_shift, phones2mel=phones2mel,
                                   energy=energy, channel_first=True)
-        return self.encoder(f["features"], pitches.transpose(1, 2), noises=noises)
+        if self.encoder_type == "RefineGAN":
+            return self.encoder(f["features"], pitches.transpose(1, 2), noises=noises)
+        rand_ini, src_noise = noises if noises is not None else (None, None)   # (rand_ini [B,9], src_noise [B,L,9])
+        return self.encoder(f["features"], pitches[:, :, 0], rand_ini=rand_ini, src_noise=src_noise)

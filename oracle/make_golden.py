@@ -331,6 +331,48 @@ def main():
          noise_seed=np.int64(41), sha1_frontend=np.array(state_sha1(hsd)), sha1_generator=np.array(state_sha1(hgsd)),
          config=np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in hcfg.items()})))
 
+    # HiFiSinger v1 (configs/_base_/archs/hifi_svc.py): same front end (256-dim contents), NSF-HiFiGAN generator with num_mels=256
+    h1 = dict(nsf_hifigan_ref.CONFIG_V1, num_mels=256)
+
+    class RefHiFiSingerV1(torch.nn.Module):
+        forward_features = fwd_feat_h
+        forward = fwd_h
+
+        def __init__(self):
+            super().__init__()
+            self.get_mask_from_lengths = get_mask_h.__func__ if hasattr(get_mask_h, "__func__") else get_mask_h
+            self.text_encoder = Enc(256, 256)
+            self.speaker_encoder = Enc(10, 256, use_embedding=True)
+            self.pitch_shift_encoder = Enc(1, 256)
+            self.energy_encoder = Enc(1, 256)
+            self.feature_fuser = torch.nn.Sequential(torch.nn.Linear(256, 256), torch.nn.SiLU(), torch.nn.Linear(256, 256), torch.nn.SiLU())
+            self.encoder_type = "HiFiGAN"
+            self.encoder = R["Generator"](R["AttrDict"](h1))
+            self.encoder.remove_weight_norm()
+
+    hsd1 = features_ref.seeded_hifisinger_state(18, content_dim=256)
+    gsd1 = nsf_hifigan_ref.seeded_generator_state(19, h1)
+    ref1 = RefHiFiSingerV1().eval()
+    ref1.load_state_dict({**hsd1, **{"encoder." + k: v for k, v in gsd1.items()}}, strict=True)
+    B, T = 2, 9
+    lens = torch.tensor([9, 6])
+    f0 = torch.stack([synth_f0(T), synth_f0(T) * 1.5])[:, :, None]
+    # RNG order inside Generator: rand_ini (models.py:210) then src_noise (:289)
+    g = torch.Generator().manual_seed(50)
+    contents = torch.randn(B, T, 256, generator=g)
+    energy1 = torch.rand(B, T, 1, generator=g)
+    torch.manual_seed(51)
+    ref = ref1(ids, contents, lens, T, pitches=f0, pitch_shift=shift, energy=energy1)
+    torch.manual_seed(51)
+    rand_ini = torch.rand(B, 9)
+    rand_ini[:, 0] = 0
+    src_noise = torch.randn(B, T * 512, 9)
+    feats1 = features_ref.hifisinger_features(hsd1, contents, ids, lens, T, shift, energy1)
+    mine = nsf_hifigan_ref.generator_forward(gsd1, h1, feats1["features"].transpose(1, 2), f0[:, :, 0], rand_ini, src_noise)
+    assert torch.equal(mine, ref), "oracle hifisinger v1 != reference"
+    save("hifisinger_v1", contents=contents, ids=ids, lens=lens, f0=f0, shift=shift, energy=energy1, wav=ref, noise_seed=np.int64(51),
+         sha1_frontend=np.array(state_sha1(hsd1)), sha1_generator=np.array(state_sha1(gsd1)), config=np.array(json.dumps(h1)))
+
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("done")

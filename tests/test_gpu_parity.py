@@ -675,7 +675,33 @@ def test_hifisinger_end_to_end_matches_reference_golden(dev):
     err = abs_err(wav.cpu(), g["wav"])
     print(f"hifisinger end to end: wav abs err {err:.3e}")
     assert wav.shape == g["wav"].shape and err < WAV_ABS
-    with pytest.raises(NotImplementedError):
-        HiFiSinger(dict(hidden_size=256, text_encoder=dict(type="NaiveProjectionEncoder", input_size=768, output_size=256),
-                        speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=256, use_embedding=True),
-                        encoder=dict(resblock="1")))
+
+
+def test_hifisinger_v1_nsf_generator_variant_matches_reference_golden(dev):
+    """configs/_base_/archs/hifi_svc.py: HiFiSinger whose encoder is the NSF-HiFiGAN generator fed with the fused 256-dim
+    features (core.py:35-37,140-141)."""
+    from fish_diffusion_amd import HiFiSinger
+    from oracle import features_ref, nsf_hifigan_ref
+    g = load("hifisinger_v1")
+    h = json.loads(str(g["config"]))
+    hsd, gsd = features_ref.seeded_hifisinger_state(18, content_dim=256), nsf_hifigan_ref.seeded_generator_state(19, h)
+    assert sha1_state(hsd) == str(g["sha1_frontend"]) and sha1_state(gsd) == str(g["sha1_generator"])
+    lin1 = dict(type="NaiveProjectionEncoder", input_size=1, output_size=256)
+    model = HiFiSinger(dict(hidden_size=256, text_encoder=dict(type="NaiveProjectionEncoder", input_size=256, output_size=256),
+                            speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=256, use_embedding=True),
+                            pitch_shift_encoder=lin1, energy_encoder=lin1, encoder=dict(type="HiFiGAN", **h)))
+    assert model.encoder_type == "HiFiGAN"
+    model.encoder.load_folded_state(gsd)
+    missing, unexpected = model.load_state_dict(hsd, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") for k in missing)
+    model = model.to(dev).eval()
+    B, T, _ = g["contents"].shape
+    torch.manual_seed(int(g["noise_seed"]))
+    rand_ini = torch.rand(B, 9)
+    rand_ini[:, 0] = 0
+    src_noise = torch.randn(B, T * 512, 9)
+    wav = model(torch.as_tensor(g["ids"]).to(dev), g["contents"].to(dev), torch.as_tensor(g["lens"]).to(dev), T, pitches=g["f0"].to(dev),
+                pitch_shift=g["shift"].to(dev), energy=g["energy"].to(dev), noises=(rand_ini.to(dev), src_noise.to(dev)))
+    err = abs_err(wav.cpu(), g["wav"])
+    print(f"hifisinger v1 end to end: wav abs err {err:.3e}")
+    assert wav.shape == g["wav"].shape and err < WAV_ABS
