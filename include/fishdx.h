@@ -16,6 +16,9 @@
  *     synchronises the device inside *_forward / *_run.  Buffers grow only in *_prepare / first call
  *     with a new geometry.
  *   - all arithmetic is fp32 (f32-in/f32-acc MFMA), activations are [B][C][T] with T contiguous.
+ *   - multi-GPU: there is deliberately no collective in this ABI.  The packed arenas (fdx_*_pack) are plain byte blobs;
+ *     rank 0 packs, `torch.distributed.broadcast` (RCCL) ships them, every rank calls fdx_*_attach
+ *     (fish_diffusion_amd/dist.py).  The path itself has no exchange step.
  *   - a handle is NOT re-entrant: one in-flight call per handle (the Python wrapper holds a lock;
  *     the reference's flask_api.py:86 can call forward from several threads).
  */

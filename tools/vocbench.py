@@ -6,12 +6,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+HOP256 = "--hop256" in sys.argv        # tools/nsf_hifigan/config_v1_256.json, what configs/vocoder_nsf_hifigan.py points at
 dev = torch.device("cuda", 0)
+if HOP256:
+    bench.NSF_V1 = dict(bench.NSF_V1, upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], hop_size=256)
 diff, voc = bench.seeded_modules(dev)
+del diff
 voc.model.rng = "philox"
-T = 861
+hop = bench.NSF_V1["hop_size"]
+T = int(10 * 44100) // hop
 mel = (torch.randn(B, 128, T, device=dev) * 0.5 - 2.0)
 _, f0 = bench.synth_inputs(B, T, dev, 1)
+f0 = f0.contiguous()
 for _ in range(3):
     voc.model(mel, f0)
 torch.cuda.synchronize()
@@ -21,5 +27,5 @@ for _ in range(N):
     voc.model(mel, f0)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
-fl = bench.nsf_flops_per_sample() * T * 512 * B
+fl = bench.nsf_flops_per_sample(bench.NSF_V1) * T * hop * B
 print(f"B={B}: {dt*1e3:.3f} ms per batch, {fl/dt/1e12:.1f} TFLOP/s ({fl/dt/1e12/157.3*100:.1f}% of fp32 peak), {B*10/dt:.0f}x real-time")
