@@ -3,6 +3,7 @@
 See DESIGN.md / INTEGRATION.md.  HIP only: no CPU, no PyTorch-eager fallback."""
 from .registry import DENOISERS, DIFFUSIONS, VOCODERS, install  # noqa: F401
 from .wavenet import WaveNet  # noqa: F401
+from .convnext import ConvNext  # noqa: F401
 from .diffusion import GaussianDiffusion  # noqa: F401
 from .nsf_hifigan import NsfHifiGAN, Generator  # noqa: F401
 from .mel import PitchAdjustableMelSpectrogram  # noqa: F401
@@ -10,5 +11,5 @@ from .diffsinger import ENCODERS, DiffSinger, NaiveProjectionEncoder, pitch_to_s
 from .refinegan import RefineGAN, RefineGANGenerator  # noqa: F401
 from .hifisinger import HiFiSinger  # noqa: F401
 
-__all__ = ["DENOISERS", "DIFFUSIONS", "VOCODERS", "install", "WaveNet", "GaussianDiffusion", "NsfHifiGAN", "Generator",
+__all__ = ["DENOISERS", "DIFFUSIONS", "VOCODERS", "install", "WaveNet", "ConvNext", "GaussianDiffusion", "NsfHifiGAN", "Generator",
            "PitchAdjustableMelSpectrogram", "ENCODERS", "DiffSinger", "NaiveProjectionEncoder", "pitch_to_scale", "RefineGAN", "RefineGANGenerator", "HiFiSinger"]

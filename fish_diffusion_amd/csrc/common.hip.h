@@ -122,6 +122,10 @@ struct fdx_ctx {
 
   // ---- refinegan (opaque: refinegan.hip owns the type)
   void* rg = nullptr;
+  // ---- convnext denoiser (opaque: convnext.hip owns the type); den_kind says which denoiser the sampler loop drives
+  void* cn = nullptr;
+  int den_kind = 0;      // 0 = WaveNet (wavenet.hip), 1 = ConvNext (convnext.hip)
+  int den_M = 0;         // mel channels of the prepared denoiser
 
   // ---- mel
   bool mel_ok = false;
@@ -136,6 +140,12 @@ struct fdx_ctx {
 };
 
 void fdx_rg_free(void* p);   // refinegan.hip
+void fdx_cn_free(void* p);   // convnext.hip
+// convnext.hip: the two hooks fdx_sampler_run needs (same contracts as wn_embed / wn_forward_core in wavenet.hip)
+int fdx_cn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s);
+int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
+                        hipStream_t s, bool unmasked_cond);
+int fdx_cn_plms_setup(fdx_ctx* h, hipStream_t s);   // PLMS + cond_masks: projections of the unmasked condition
 
 namespace fdx {
 

@@ -98,7 +98,10 @@ __device__ __forceinline__ float div_const(float x, float c, float rc) {
 }
 __device__ __forceinline__ f2 div_const(f2 x, float c, float rc) { return f2{div_const(x.x, c, rc), div_const(x.y, c, rc)}; }
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3 };
+
+// nn.GELU() (exact, erf form): 0.5 * x * (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float mish_f(float x) {
   // x * tanh(softplus(x)); F.softplus: beta=1, threshold=20 (wavenet.py:8-10)
@@ -128,6 +131,7 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
     if (bias) v += bv;
     if (act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (act == ACT_MISH) v = mish_f(v);
+    else if (act == ACT_GELU) v = gelu_f(v);
     return masked ? 0.f : v;
   }
   __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
@@ -210,6 +214,29 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
       if (skip_mode >= 2) s = div_const(s, inv_div, r_inv_div);
       st2p(SK + o, s, two);
     }
+  }
+};
+
+struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) + bias); masked_fill(x_masks)
+  static constexpr bool kPaired = false;
+  float* X; long bs; int ld;                 // residual in, result out (in place), padded rows
+  const float* bias; const float* gamma; int M;
+  const uint8_t* mask; int mask_ld;
+  struct Pre { f2 old; float bias, gamma; bool m0, m1; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p{f2{0.f, 0.f}, 0.f, 0.f, false, false};
+    if (row >= M) return p;
+    p.old = ld2(X + b * bs + (long)row * ld + t, two);
+    p.bias = bias[row]; p.gamma = gamma[row];
+    if (mask) { p.m0 = mask[(long)b * mask_ld + t] != 0; p.m1 = two && mask[(long)b * mask_ld + t + 1] != 0; }
+    return p;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
+    if (row >= M) return;
+    v = p.old + p.gamma * (v + p.bias);
+    if (p.m0) v.x = 0.f;
+    if (p.m1) v.y = 0.f;
+    st2p(X + b * bs + (long)row * ld + t, v, two);
   }
 };
 

@@ -1,0 +1,407 @@
+// convnext.hip -- the ConvNext denoiser: fish_diffusion/modules/convnext.py:12-92 (ConvNeXtBlock),
+// :155-262 (ConvNext, cross_attention = False), registered as DENOISERS "ConvNextDenoiser"
+// (archs/diffsinger/diffusions/builder.py:12).  Same call contract as the WaveNet denoiser, so the sampler loop of
+// wavenet.hip drives it through the two hooks fdx_cn_embed / fdx_cn_forward_core.
+//
+// Per denoiser call (B items, T frames, D = dim, H = D * mlp_factor, L layers):
+//   1 x  input_projection      GEMM [D x M]     epilogue: +bias, GELU, mask                                   :231-239
+//   L x  dwconv + LayerNorm    VALU             u = dwconv_d(mask(x + step_l + cond_l)); n = LN_channels(u)   :66-80
+//   L x  pwconv1               GEMM [H x D]     epilogue: +bias, GELU                                         :81-82
+//   L x  pwconv2               GEMM [D x H]     epilogue: x = x + gamma * (. + bias), mask                    :83-92
+//   1 x  output_projection.0   GEMM [D x D]     epilogue: +bias, GELU                                         :256
+//   1 x  output_projection.2   GEMM [M x D]     epilogue: +bias, mask                                         :256-258
+// Hoisted, exactly as for the WaveNet: the conditioner path (conditioner_projection MLP, then the L condition_projection
+// 1x1 convs as ONE [L*D x D] GEMM) runs once per utterance batch (fdx_convnext_prepare); the step-embedding MLP and the L
+// diffusion_step_projection 1x1 convs run once per sampler run for all timesteps.
+#include "common.hip.h"
+#include "convplan.hip.h"
+#include "elementwise.hip.h"
+
+#include <cmath>
+
+using namespace fdx;
+
+namespace {
+
+struct CnLayout {
+  PackedW in_proj, emb1, emb3, cond0, cond2, dsp, cproj, out0, out2;   // dsp / cproj: all layers concatenated along rows
+  std::vector<PackedW> pw1, pw2;
+  std::vector<size_t> dw_w, dw_b, ln_w, ln_b, gamma;
+  std::vector<int> dil;
+  size_t total_floats = 0;
+};
+
+PackedW plan64(size_t& cur, int rows, int cin) {   // plain GEMM, 64-row tiles
+  PackedW p;
+  p.RB = 2; p.rows = rows; p.cin8 = (cin + 7) / 8; p.taps = 1; p.n_mtiles = (rows + 63) / 64;
+  p.w_off = cur; cur += packed_floats(p.n_mtiles, 2, p.cin8, 1);
+  p.b_off = cur; cur += (size_t)round_up(rows, 64);
+  return p;
+}
+PackedW plan32(size_t& cur, int rows, int cin) {   // 32-row tiles: twice the workgroups for the D-row GEMM with the long K
+  PackedW p;
+  p.RB = 1; p.rows = rows; p.cin8 = (cin + 7) / 8; p.taps = 1; p.n_mtiles = (rows + 31) / 32;
+  p.w_off = cur; cur += packed_floats(p.n_mtiles, 1, p.cin8, 1);
+  p.b_off = cur; cur += (size_t)round_up(rows, 64);
+  return p;
+}
+
+int cn_validate(const fdx_convnext_desc* d) {
+  if (!d) return fail(nullptr, FDX_E_ARG, "null convnext desc");
+  if (d->dim < 32 || d->dim % 32 || d->dim > 512) return fail(nullptr, FDX_E_ARG, "convnext: dim must be a multiple of 32 in [32, 512], got %d", d->dim);
+  if (d->mlp_factor < 1 || d->mlp_factor > 8) return fail(nullptr, FDX_E_ARG, "convnext: mlp_factor out of range");
+  if (d->mel_channels <= 0 || d->mel_channels % 8 || d->condition_dim <= 0 || d->condition_dim % 8)
+    return fail(nullptr, FDX_E_ARG, "convnext: mel_channels and condition_dim must be multiples of 8");
+  if (d->num_layers <= 0) return fail(nullptr, FDX_E_ARG, "convnext: num_layers must be positive");
+  if (d->dilation_cycle < 1 || d->dilation_cycle > 4) return fail(nullptr, FDX_E_ARG, "convnext: dilation_cycle %d unsupported (3 * dilation must fit the %d-column halo)", d->dilation_cycle, kHalo);
+  if (d->cross_attention) return fail(nullptr, FDX_E_NOIMPL, "convnext: cross_attention=True is not built");
+  return FDX_OK;
+}
+
+void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
+  const int D = d.dim, H = d.dim * d.mlp_factor, L = d.num_layers;
+  size_t cur = 0;
+  l.in_proj = plan64(cur, D, d.mel_channels);
+  l.emb1 = plan64(cur, H, D);
+  l.emb3 = plan64(cur, D, H);
+  l.cond0 = plan64(cur, H, d.condition_dim);
+  l.cond2 = plan64(cur, D, H);
+  l.dsp = plan64(cur, L * D, D);
+  l.cproj = plan64(cur, L * D, D);
+  l.pw1.clear(); l.pw2.clear(); l.dw_w.clear(); l.dw_b.clear(); l.ln_w.clear(); l.ln_b.clear(); l.gamma.clear(); l.dil.clear();
+  for (int i = 0; i < L; ++i) {
+    l.pw1.push_back(plan64(cur, H, D));
+    l.pw2.push_back(plan32(cur, D, H));
+    l.dw_w.push_back(cur); cur += round_up(D * 7, 64);
+    for (auto* v : {&l.dw_b, &l.ln_w, &l.ln_b, &l.gamma}) { v->push_back(cur); cur += round_up(D, 64); }
+    l.dil.push_back(1 << (i % d.dilation_cycle));
+  }
+  l.out0 = plan64(cur, D, D);
+  l.out2 = plan64(cur, d.mel_channels, D);
+  l.total_floats = cur;
+}
+
+void pack_lin(float* A, const PackedW& p, const float* w, int rows, int cin, const float* bias, int row0 = 0) {
+  // weight [rows][cin] placed at logical rows row0.. of the packed matrix (used to concatenate per-layer projections)
+  const int R = 32 * p.RB;
+  const int n_it = p.cin8;
+  for (int r = 0; r < rows; ++r) {
+    const int row = row0 + r, mt = row / R, rb = (row % R) / 32, i = row % 32;
+    for (int c = 0; c < cin; ++c) {
+      const int cb = c / 8, half = (c % 8) / 4, j = c % 4;
+      A[p.w_off + ((((size_t)mt * n_it + cb) * p.RB + rb) * 64 + half * 32 + i) * 4 + j] = w[(size_t)r * cin + c];
+    }
+    A[p.b_off + row] = bias ? bias[r] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dwconv + LayerNorm
+// One workgroup = 16 frames x all D channels (T / 16 workgroups per item: the op is latency-, not bandwidth-bound, so it
+// wants many small workgroups); thread (tc, cg) owns channels cg*CPT .. +CPT (CPT = D / 16 <= 32) of frame t0 + tc and keeps
+// its conv outputs in registers; the LayerNorm statistics (two-pass: mean, then centred variance) are reduced over the 16
+// channel groups through LDS.  v(t') = mask(x + step + cond)(t'), zero outside [0, T): exactly the zero padding of the
+// reference's depthwise Conv1d applied after the adds and the mask (convnext.py:64-77).
+constexpr int kCnFr = 16, kCnCg = 16, kCnCpt = 32;
+
+__global__ __launch_bounds__(256) void k_dwconv_ln(float* __restrict__ N, const float* __restrict__ X, long bs, int ld,
+                                                   const float* __restrict__ CP, long cp_bs,   // layer slab [D][ld]
+                                                   const float* __restrict__ SB, int sb_ld, int sb_bs,   // [D][sb_ld], column = step
+                                                   const uint8_t* __restrict__ mask, const float* __restrict__ dw_w,
+                                                   const float* __restrict__ dw_b, const float* __restrict__ ln_w,
+                                                   const float* __restrict__ ln_b, int D, int T, int dil, float eps) {
+  __shared__ float red[kCnCg][kCnFr];
+  const int tc = threadIdx.x & (kCnFr - 1), cg = threadIdx.x / kCnFr;
+  const int b = blockIdx.y, t = blockIdx.x * kCnFr + tc;
+  const int cpt = D / kCnCg;
+  const bool live = t < T;
+  bool ok[7];
+  int off[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    off[k] = (k - 3) * dil;
+    const int tt = t + off[k];
+    ok[k] = live && tt >= 0 && tt < T && !(mask && mask[(long)b * T + tt]);
+    if (!ok[k]) off[k] = 0;
+  }
+  const int tl = live ? t : T - 1;   // dead lanes read a valid address and discard
+  const float* xb = X + b * bs + tl;
+  const float* cb = CP + b * cp_bs + tl;
+  float u[kCnCpt];
+  float s1 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < kCnCpt; ++ci) {
+    u[ci] = 0.f;
+    if (ci < cpt) {
+      const int c = cg * cpt + ci;
+      const float sb = SB[(long)c * sb_ld + b * sb_bs];
+      const float* xr = xb + (long)c * ld;
+      const float* cr = cb + (long)c * ld;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float v = (xr[off[k]] + sb) + cr[off[k]];
+        acc += dw_w[c * 7 + k] * (ok[k] ? v : 0.f);
+      }
+      u[ci] = acc + dw_b[c];
+      s1 += u[ci];
+    }
+  }
+  auto total = [&](float v) {
+    __syncthreads();
+    red[cg][tc] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kCnCg; ++g) s += red[g][tc];
+    return s;
+  };
+  const float mean = total(s1) / (float)D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < kCnCpt; ++ci)
+    if (ci < cpt) { const float dlt = u[ci] - mean; s2 += dlt * dlt; }
+  const float var = total(s2) / (float)D;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (!live) return;
+  float* nb = N + b * bs + t;
+#pragma unroll
+  for (int ci = 0; ci < kCnCpt; ++ci)
+    if (ci < cpt) {
+      const int c = cg * cpt + ci;
+      nb[(long)c * ld] = (u[ci] - mean) * rstd * ln_w[c] + ln_b[c];
+    }
+}
+
+struct CnBufs {
+  DevBuf X, N, G, H2, condp, c1, c2, CP;
+  DevBuf c2raw, CP2;   // PLMS + cond_masks: condition / per-layer projections of the UNMASKED conditioner (diffusion.py:285)
+  DevBuf E, Hm, S0, SB;
+  int ldn = 0, n_emb = 0;
+};
+
+}  // namespace
+
+struct fdx_cn_state {
+  bool ok = false;
+  fdx_convnext_desc d{};
+  CnLayout l;
+  const float* arena = nullptr;
+  CnBufs b;
+};
+
+static fdx_cn_state* cn(fdx_ctx* h) {
+  if (!h->cn) h->cn = new fdx_cn_state();
+  return static_cast<fdx_cn_state*>(h->cn);
+}
+void fdx_cn_free(void* p) { delete static_cast<fdx_cn_state*>(p); }
+
+extern "C" int fdx_convnext_num_weights(const fdx_convnext_desc* d) {
+  if (cn_validate(d)) return FDX_E_ARG;
+  return 10 + d->num_layers * 13 + 4;
+}
+
+extern "C" int fdx_convnext_packed_bytes(const fdx_convnext_desc* d, size_t* bytes) {
+  if (cn_validate(d) || !bytes) return FDX_E_ARG;
+  CnLayout l;
+  cn_layout(*d, l);
+  *bytes = l.total_floats * sizeof(float);
+  return FDX_OK;
+}
+
+// Canonical order = the module's state_dict order (convnext.py:170-205): input_projection.{weight,bias},
+// diffusion_embedding.1.*, diffusion_embedding.3.*, conditioner_projection.0.*, conditioner_projection.2.*, then per layer:
+// gamma, dwconv.{weight,bias}, norm.{weight,bias}, pwconv1.*, pwconv2.*, diffusion_step_projection.*, condition_projection.*;
+// then output_projection.0.*, output_projection.2.*.
+extern "C" int fdx_convnext_pack(const fdx_convnext_desc* d, const float* const* w, int n, void* out, size_t bytes) {
+  if (cn_validate(d)) return FDX_E_ARG;
+  if (!w || !out) return fail(nullptr, FDX_E_ARG, "null pointer");
+  if (n != fdx_convnext_num_weights(d)) return fail(nullptr, FDX_E_ARG, "expected %d weight tensors, got %d", fdx_convnext_num_weights(d), n);
+  CnLayout l;
+  cn_layout(*d, l);
+  if (bytes != l.total_floats * sizeof(float)) return fail(nullptr, FDX_E_ARG, "packed size mismatch");
+  float* A = static_cast<float*>(out);
+  memset(A, 0, bytes);
+  const int D = d->dim, H = D * d->mlp_factor, L = d->num_layers;
+  int k = 0;
+  pack_lin(A, l.in_proj, w[k], D, d->mel_channels, w[k + 1]); k += 2;
+  pack_lin(A, l.emb1, w[k], H, D, w[k + 1]); k += 2;
+  pack_lin(A, l.emb3, w[k], D, H, w[k + 1]); k += 2;
+  pack_lin(A, l.cond0, w[k], H, d->condition_dim, w[k + 1]); k += 2;
+  pack_lin(A, l.cond2, w[k], D, H, w[k + 1]); k += 2;
+  for (int i = 0; i < L; ++i) {
+    memcpy(A + l.gamma[i], w[k], D * sizeof(float)); k += 1;
+    memcpy(A + l.dw_w[i], w[k], (size_t)D * 7 * sizeof(float)); memcpy(A + l.dw_b[i], w[k + 1], D * sizeof(float)); k += 2;
+    memcpy(A + l.ln_w[i], w[k], D * sizeof(float)); memcpy(A + l.ln_b[i], w[k + 1], D * sizeof(float)); k += 2;
+    pack_lin(A, l.pw1[i], w[k], H, D, w[k + 1]); k += 2;
+    pack_lin(A, l.pw2[i], w[k], D, H, w[k + 1]); k += 2;
+    pack_lin(A, l.dsp, w[k], D, D, w[k + 1], i * D); k += 2;
+    pack_lin(A, l.cproj, w[k], D, D, w[k + 1], i * D); k += 2;
+  }
+  pack_lin(A, l.out0, w[k], D, D, w[k + 1]); k += 2;
+  pack_lin(A, l.out2, w[k], d->mel_channels, D, w[k + 1]); k += 2;
+  return FDX_OK;
+}
+
+extern "C" int fdx_convnext_attach(fdx_handle h, const fdx_convnext_desc* d, const void* dev, size_t bytes) {
+  if (!h) return FDX_E_ARG;
+  if (cn_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
+  fdx_cn_state* S = cn(h);
+  cn_layout(*d, S->l);
+  if (!dev || bytes != S->l.total_floats * sizeof(float)) return fail(h, FDX_E_ARG, "packed arena size mismatch");
+  S->d = *d; S->arena = static_cast<const float*>(dev); S->ok = true;
+  ++g_alloc_generation;   // cached sampler graphs bake the arena address in
+  h->prepared = false;
+  return FDX_OK;
+}
+
+namespace {
+
+EpiBias bias_epi(float* out, long o_bs, int ldo, const float* bias, int M, int act) {
+  EpiBias e{};
+  e.out = out; e.o_bs = o_bs; e.ldo = ldo; e.bias = bias; e.M = M; e.act = act;
+  return e;
+}
+
+template <class Epi>
+hipError_t gemm(const float* A, const PackedW& p, int B, int T, const float* X, long x_bs, int ldx, const Epi& e, hipStream_t s) {
+  ConvGeom g{B, T, p.cin8, 1, 0, 0, p.n_mtiles};
+  const float4* Wp = reinterpret_cast<const float4*>(A + p.w_off);
+  if (p.RB == 1) return launch_convgemm<1, true, false, Epi>(g, Wp, X, x_bs, ldx, 1.f, e, s);
+  return launch_convgemm<2, true, false, Epi>(g, Wp, X, x_bs, ldx, 1.f, e, s);
+}
+
+}  // namespace
+
+// ================================================================================================ prepare (hoisted conditioner path)
+extern "C" int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask, fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  fdx_cn_state* S = cn(h);
+  if (!S->ok) return fail(h, FDX_E_STATE, "fdx_convnext_prepare: no weights attached");
+  if (!cond || B <= 0 || T <= 0) return fail(h, FDX_E_ARG, "fdx_convnext_prepare: bad cond/B/T");
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const auto& d = S->d;
+  const auto& l = S->l;
+  const float* A = S->arena;
+  const int D = d.dim, H = D * d.mlp_factor, L = d.num_layers, E = d.condition_dim, M = d.mel_channels;
+  const int ld = padded_ld(T, 64);
+  const bool geom = B != h->B || T != h->T || h->den_kind != 1;
+  h->B = B; h->T = T; h->ld = ld; h->den_kind = 1; h->den_M = M;
+  auto sz = [&](int ch) { return (size_t)B * ch * ld * sizeof(float); };
+  CnBufs& b = S->b;
+  FDX_HIP(h, h->xin.ensure(sz(M), geom, s));
+  FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
+  FDX_HIP(h, b.X.ensure(sz(D), geom, s)); FDX_HIP(h, b.N.ensure(sz(D), geom, s)); FDX_HIP(h, b.H2.ensure(sz(D), geom, s));
+  FDX_HIP(h, b.G.ensure(sz(H), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s)); FDX_HIP(h, b.c2.ensure(sz(D), geom, s));
+  FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.CP.ensure(sz(L * D), geom, s));
+  // condition = conditioner_projection(conditioner).masked_fill(cond_masks)  (convnext.py:242,247-248)
+  hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, b.condp.f() + kHalo, (long)E * ld, ld, cond, (long)E * T, T, E, T,
+                     1.f, (const uint8_t*)nullptr);
+  FDX_HIP(h, gemm(A, l.cond0, B, T, b.condp.f() + kHalo, (long)E * ld, ld,
+                  bias_epi(b.c1.f() + kHalo, (long)H * ld, ld, A + l.cond0.b_off, H, ACT_GELU), s));
+  {
+    EpiBias e = bias_epi(b.c2.f() + kHalo, (long)D * ld, ld, A + l.cond2.b_off, D, ACT_NONE);
+    e.mask = cond_mask; e.mask_ld = T;
+    FDX_HIP(h, gemm(A, l.cond2, B, T, b.c1.f() + kHalo, (long)H * ld, ld, e, s));
+  }
+  if (cond_mask) {   // PLMS evaluates the denoiser once WITHOUT masks (diffusion.py:285): keep the unmasked condition for that call
+    FDX_HIP(h, b.c2raw.ensure(sz(D), geom || b.c2raw.cap < sz(D), s));
+    FDX_HIP(h, gemm(A, l.cond2, B, T, b.c1.f() + kHalo, (long)H * ld, ld,
+                    bias_epi(b.c2raw.f() + kHalo, (long)D * ld, ld, A + l.cond2.b_off, D, ACT_NONE), s));
+  }
+  // per-layer condition_projection(condition) for all layers in one GEMM (convnext.py:72)
+  FDX_HIP(h, gemm(A, l.cproj, B, T, b.c2.f() + kHalo, (long)D * ld, ld,
+                  bias_epi(b.CP.f() + kHalo, (long)L * D * ld, ld, A + l.cproj.b_off, L * D, ACT_NONE), s));
+  h->cond_masked = cond_mask != nullptr;
+  h->prepared = true;
+  return FDX_OK;
+}
+
+// ================================================================================================ step embeddings
+// SB[(l*D + c)][j] = diffusion_step_projection_l(MLP(embedding(t_j)))[c]   (convnext.py:241,64)
+int fdx_cn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s) {
+  fdx_cn_state* S = cn(h);
+  const auto& d = S->d;
+  const auto& l = S->l;
+  const float* A = S->arena;
+  const int D = d.dim, H = D * d.mlp_factor, L = d.num_layers;
+  const int ldn = padded_ld(n, 64);
+  CnBufs& b = S->b;
+  const bool geom = ldn != b.ldn;
+  b.ldn = ldn; b.n_emb = n;
+  FDX_HIP(h, b.E.ensure((size_t)D * ldn * 4, geom, s));
+  FDX_HIP(h, b.Hm.ensure((size_t)H * ldn * 4, geom, s));
+  FDX_HIP(h, b.S0.ensure((size_t)D * ldn * 4, geom, s));
+  FDX_HIP(h, b.SB.ensure((size_t)L * D * ldn * 4, geom, s));
+  hipLaunchKernelGGL(k_step_embed, ew_grid(n, D), dim3(kEwBlock), 0, s, b.E.f() + kHalo, ldn, t_dev, n, D);
+  FDX_HIP(h, gemm(A, l.emb1, 1, n, b.E.f() + kHalo, 0, ldn, bias_epi(b.Hm.f() + kHalo, 0, ldn, A + l.emb1.b_off, H, ACT_GELU), s));
+  FDX_HIP(h, gemm(A, l.emb3, 1, n, b.Hm.f() + kHalo, 0, ldn, bias_epi(b.S0.f() + kHalo, 0, ldn, A + l.emb3.b_off, D, ACT_NONE), s));
+  FDX_HIP(h, gemm(A, l.dsp, 1, n, b.S0.f() + kHalo, 0, ldn, bias_epi(b.SB.f() + kHalo, 0, ldn, A + l.dsp.b_off, L * D, ACT_NONE), s));
+  return FDX_OK;
+}
+
+// PLMS set-up when the batch was prepared with cond_masks: per-layer projections of the unmasked condition
+int fdx_cn_plms_setup(fdx_ctx* h, hipStream_t s) {
+  fdx_cn_state* S = cn(h);
+  const auto& l = S->l;
+  const int D = S->d.dim, L = S->d.num_layers, ld = h->ld;
+  FDX_HIP(h, S->b.CP2.ensure((size_t)h->B * L * D * ld * sizeof(float), false, s));
+  FDX_HIP(h, gemm(S->arena, l.cproj, h->B, h->T, S->b.c2raw.f() + kHalo, (long)D * ld, ld,
+                  bias_epi(S->b.CP2.f() + kHalo, (long)L * D * ld, ld, S->arena + l.cproj.b_off, L * D, ACT_NONE), s));
+  return FDX_OK;
+}
+
+// ================================================================================================ forward
+int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
+                        hipStream_t s, bool unmasked_cond) {
+  fdx_cn_state* S = cn(h);
+  const auto& d = S->d;
+  const auto& l = S->l;
+  const float* A = S->arena;
+  const int D = d.dim, H = D * d.mlp_factor, L = d.num_layers, M = d.mel_channels;
+  const int B = h->B, T = h->T, ld = h->ld;
+  CnBufs& b = S->b;
+  const long bsD = (long)D * ld, bsH = (long)H * ld;
+  float* X = b.X.f() + kHalo; float* N = b.N.f() + kHalo; float* G = b.G.f() + kHalo; float* H2 = b.H2.f() + kHalo;
+  const float* SB = b.SB.f() + kHalo + col0;
+  const float* CP = (unmasked_cond ? b.CP2.f() : b.CP.f()) + kHalo;
+  {  // x = gelu(input_projection(x)).masked_fill(x_masks)
+    EpiBias e = bias_epi(X, bsD, ld, A + l.in_proj.b_off, D, ACT_GELU);
+    e.mask = mask; e.mask_ld = T;
+    FDX_HIP(h, gemm(A, l.in_proj, B, T, xin, (long)M * ld, ld, e, s));
+  }
+  for (int i = 0; i < L; ++i) {
+    hipLaunchKernelGGL(k_dwconv_ln, dim3((T + kCnFr - 1) / kCnFr, B), dim3(256), 0, s, N, X, bsD, ld, CP + (size_t)i * D * ld,
+                       (long)L * D * ld, SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, mask, A + l.dw_w[i], A + l.dw_b[i], A + l.ln_w[i],
+                       A + l.ln_b[i], D, T, l.dil[i], 1e-6f);
+    FDX_HIP(h, gemm(A, l.pw1[i], B, T, N, bsD, ld, bias_epi(G, bsH, ld, A + l.pw1[i].b_off, H, ACT_GELU), s));
+    EpiScaleRes e{};
+    e.X = X; e.bs = bsD; e.ld = ld; e.bias = A + l.pw2[i].b_off; e.gamma = A + l.gamma[i]; e.M = D; e.mask = mask; e.mask_ld = T;
+    FDX_HIP(h, gemm(A, l.pw2[i], B, T, G, bsH, ld, e, s));
+  }
+  FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
+  {
+    EpiBias e = bias_epi(eps_out, o_bs, ldo, A + l.out2.b_off, M, ACT_NONE);
+    e.mask = mask; e.mask_ld = T;
+    e.tight = ldo != ld;
+    FDX_HIP(h, gemm(A, l.out2, B, T, H2, bsD, ld, e, s));
+  }
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
+
+extern "C" int fdx_convnext_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask, float* eps,
+                                    fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  fdx_cn_state* S = cn(h);
+  if (!S->ok || !h->prepared || h->den_kind != 1) return fail(h, FDX_E_STATE, "fdx_convnext_forward: call attach + prepare first");
+  if (!x || !t || !eps) return fail(h, FDX_E_ARG, "fdx_convnext_forward: null pointer");
+  if (n_t != 1 && n_t != h->B) return fail(h, FDX_E_ARG, "diffusion_step must have 1 or B=%d entries, got %d", h->B, n_t);
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const int M = S->d.mel_channels, B = h->B, T = h->T, ld = h->ld;
+  if (int rc = fdx_cn_embed(h, t, n_t, s)) return rc;
+  hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * M), dim3(kEwBlock), 0, s, h->xin.f() + kHalo, (long)M * ld, ld, x, (long)M * T, T, M, T, 1.f,
+                     (const uint8_t*)nullptr);
+  return fdx_cn_forward_core(h, h->xin.f() + kHalo, 0, n_t == 1 ? 0 : 1, x_mask, eps, (long)M * T, T, s, false);
+}

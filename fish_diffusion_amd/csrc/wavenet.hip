@@ -230,7 +230,7 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   const auto& d = h->wd;
   const int C = d.residual_channels, L = d.residual_layers, M = d.mel_channels, E = d.d_encoder;
   const int ld = padded_ld(T, 64);
-  const bool geom = (B != h->B || T != h->T);
+  const bool geom = (B != h->B || T != h->T || h->den_kind != 0);
   h->B = B; h->T = T; h->ld = ld;
   auto sz = [&](int ch) { return (size_t)B * ch * ld * sizeof(float); };
   // every buffer that is read with column shifts must have zero halos => re-zero on geometry change
@@ -269,6 +269,7 @@ extern "C" int fdx_wavenet_prepare(fdx_handle h, const float* cond, int B, int T
                      (long)E * T, T, E, T, 1.f, cond_mask);
   if (int rc = wn_cond_slab(h, h->condp.f(), h->P.f(), s)) return rc;
   // PLMS evaluates the denoiser once WITHOUT masks (diffusion.py:285): keep the unmasked conditioner for that call
+  h->den_kind = 0; h->den_M = d.mel_channels;
   h->cond_masked = cond_mask != nullptr;
   if (h->cond_masked) {
     const bool geom = h->condraw.cap < (size_t)B * E * ld * sizeof(float) || h->condraw_ld != ld;
@@ -414,7 +415,7 @@ extern "C" int fdx_randn(fdx_handle h, float* out, size_t n, uint64_t seed, uint
 // and every scalar is a kernel argument, so the same code is used to run eagerly and to record a hipGraph.
 static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, const float* step_noise, uint64_t seed,
                         const uint8_t* x_mask, hipStream_t s) {
-  const int M = h->wd.mel_channels, B = h->B, T = h->T, ld = h->ld;
+  const int M = h->den_M, B = h->B, T = h->T, ld = h->ld;
   const long bs = (long)M * ld;
   const size_t bytes = (size_t)B * M * ld * sizeof(float);
   const dim3 grid = ew_grid(T, B * M), blk(kEwBlock);
@@ -422,6 +423,7 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
   float* eps = h->EPS.f() + kHalo;
   auto model = [&](const float* xin, int col, bool masked) {
     // the one unmasked call of PLMS uses the conditioner slab of the UNMASKED conditioner (built in the set-up phase)
+    if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked);
     const float* P = (!masked && h->cond_masked) ? h->P2.f() : nullptr;
     return wn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, P);
   };
@@ -502,14 +504,14 @@ static uint64_t fnv1a(const void* p, size_t n, uint64_t hsh = 146959810393466560
 extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_rows, float* x, const float* step_noise,
                                uint64_t seed, const uint8_t* x_mask, fdx_stream st) {
   if (!h) return FDX_E_ARG;
-  if (!h->wn_ok || !h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run: call attach + prepare first");
+  if (!h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run: call attach + prepare first");
   if (!tab || n_rows <= 0 || !x) return fail(h, FDX_E_ARG, "fdx_sampler_run: bad table / x");
   if (kind != FDX_SAMPLER_NAIVE && kind != FDX_SAMPLER_UNIPC && kind != FDX_SAMPLER_PLMS)
     return fail(h, FDX_E_NOIMPL, "Unknown noise predictor: %d", kind);
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
   const auto& d = h->wd;
-  const int M = d.mel_channels, B = h->B, T = h->T, ld = h->ld;
+  const int M = h->den_M, B = h->B, T = h->T, ld = h->ld;
   const long bs = (long)M * ld;
   const size_t bytes = (size_t)B * M * ld * sizeof(float);
   const dim3 grid = ew_grid(T, B * M), blk(kEwBlock);
@@ -522,7 +524,7 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   if (kind == FDX_SAMPLER_PLMS) ts.push_back(tab[1]);   // t_prev of the first step (diffusion.py:285)
   FDX_HIP(h, h->tdev.ensure(ts.size() * 4, false, s));
   FDX_HIP(h, hipMemcpyAsync(h->tdev.p, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, s));
-  if (int rc = wn_embed(h, h->tdev.f(), (int)ts.size(), s)) return rc;
+  if (int rc = (h->den_kind == 1 ? fdx_cn_embed(h, h->tdev.f(), (int)ts.size(), s) : wn_embed(h, h->tdev.f(), (int)ts.size(), s))) return rc;
 
   FDX_HIP(h, h->sx.ensure(bytes, true, s));
   if (kind == FDX_SAMPLER_UNIPC) {
@@ -536,10 +538,12 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
     FDX_HIP(h, h->sxt.ensure(bytes, true, s));
     FDX_HIP(h, h->seps2.ensure(bytes, true, s));
     for (auto& b : h->shist) FDX_HIP(h, b.ensure(bytes, true, s));
-    if (h->cond_masked) {   // conditioner slab of the unmasked conditioner for the one unmasked call
+    if (h->cond_masked && h->den_kind == 0) {   // conditioner slab of the unmasked conditioner for the one unmasked call
       FDX_HIP(h, h->P2.ensure((size_t)B * d.residual_layers * 2 * d.residual_channels * ld * sizeof(float), false, s));
       if (int rc = wn_cond_slab(h, h->condraw.f(), h->P2.f(), s)) return rc;
     }
+    if (h->cond_masked && h->den_kind == 1)
+      if (int rc = fdx_cn_plms_setup(h, s)) return rc;
   }
   hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, h->sx.f() + kHalo, bs, ld, x, (long)M * T, T, M, T, 1.f, (const uint8_t*)nullptr);
   if (x_mask) {   // private copy: a stable address for the recorded graph, whatever tensor the caller passes next time
@@ -560,7 +564,8 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   } else {
     uint64_t key = fnv1a(tab, (size_t)n_rows * FDX_ROW * sizeof(float));
     const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
-                              (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, g_alloc_generation};
+                              (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, g_alloc_generation,
+                              (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn};
     key = fnv1a(parts, sizeof parts, key);
     fdx_ctx::GraphEntry* hit = nullptr;
     for (auto& g : h->graphs) if (g.key == key) hit = &g;

@@ -18,7 +18,7 @@ from torch import nn
 
 from . import _lib, schedule
 from .registry import DENOISERS, DIFFUSIONS
-from .wavenet import WaveNet, _Group
+from .wavenet import HipDenoiser, _Group
 
 
 def _buffers(mod: nn.Module, **arrays):
@@ -110,8 +110,8 @@ class GaussianDiffusion(nn.Module):
         noise_predictor = noise_predictor.lower()
         if noise_predictor not in schedule.KINDS:
             raise NotImplementedError(f"Unknown noise predictor: {noise_predictor}")
-        if not isinstance(self.denoise_fn, WaveNet):
-            raise NotImplementedError("the MI355X sampler loop drives the HIP WaveNetDenoiser only")
+        if not isinstance(self.denoise_fn, HipDenoiser):
+            raise NotImplementedError("the MI355X sampler loop drives the HIP denoisers (WaveNetDenoiser, ConvNextDenoiser) only")
         _lib.require_gpu(features, "GaussianDiffusion features")
         device = features.device
         cond = features.transpose(1, 2)

@@ -82,11 +82,11 @@ def broadcast_arena(desc, kind: str, tensors: Optional[Sequence[torch.Tensor]], 
 
 
 def broadcast_model_weights(denoiser, generator, device: torch.device, src: int = 0):
-    """Attach broadcast arenas to a `WaveNet` and a `Generator` (either may be None).  On non-source ranks the
+    """Attach broadcast arenas to a denoiser (`WaveNet` / `ConvNext`) and a `Generator` (either may be None).  On non-source ranks the
     modules' own (random) parameters are never packed or uploaded."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     if denoiser is not None:
-        arena = broadcast_arena(denoiser._desc, "wavenet", denoiser._params() if rank == src else None, device, src)
+        arena = broadcast_arena(denoiser._desc, denoiser._KIND, denoiser._params() if rank == src else None, device, src)
         if device.type == "cuda":
             denoiser.attach_arena(arena)
     if generator is not None:

@@ -52,6 +52,7 @@ def install(override: bool = True) -> bool:
     Returns True when the reference registries were found."""
     from .diffusion import GaussianDiffusion
     from .nsf_hifigan import NsfHifiGAN
+    from .convnext import ConvNext
     from .wavenet import WaveNet
 
     try:  # pragma: no cover - needs the reference package + mmengine
@@ -59,7 +60,7 @@ def install(override: bool = True) -> bool:
         from fish_diffusion.modules.vocoders.builder import VOCODERS as R_VOC
     except Exception:
         return False
-    for reg, base, cls in ((R_DEN, "WaveNetDenoiser", WaveNet), (R_DIF, "GaussianDiffusion", GaussianDiffusion),
+    for reg, base, cls in ((R_DEN, "WaveNetDenoiser", WaveNet), (R_DEN, "ConvNextDenoiser", ConvNext), (R_DIF, "GaussianDiffusion", GaussianDiffusion),
                            (R_VOC, "NsfHifiGAN", NsfHifiGAN)):
         reg.register_module(name=base + "MI355X", module=cls, force=True)
         if override:

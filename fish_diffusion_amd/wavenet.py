@@ -64,8 +64,106 @@ def param_table(mel_channels, d_encoder, residual_channels, residual_layers, use
     return rows
 
 
-class WaveNet(nn.Module):
+class HipDenoiser(nn.Module):
+    """Engine plumbing shared by the HIP denoisers (WaveNet here, ConvNext in convnext.py).  A subclass registers its
+    parameters under the reference's state-dict names and sets `_keys` (canonical pack order), `_desc` (the C-ABI
+    descriptor), `_KIND` (the `fdx_<kind>_*` entry-point family), `mel_channels` and `_cond_channels`."""
+
+    _KIND = ""
+
+    def _init_engine(self):
+        # fail at construction (like a bad config would) rather than at first forward
+        nb = C.c_size_t()
+        _lib.check(self._fn("packed_bytes")(C.byref(self._desc), C.byref(nb)))
+        self._handle: Optional[_lib.Handle] = None
+        self._arena: Optional[torch.Tensor] = None
+        self._packed_sig = None
+        self._prep_sig = None
+
+    def _fn(self, name):
+        return getattr(_lib.lib(), f"fdx_{self._KIND}_{name}")
+
+    # ------------------------------------------------------------------ weights
+    def _params(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in self._keys]
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self._params())
+
+    def engine(self, device: torch.device) -> _lib.Handle:
+        """The fdx handle for `device` with the current weights attached (repacked if they changed)."""
+        device = torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
+        if self._handle is None or self._handle.device != device:
+            self._handle = _lib.Handle(device)
+            self._packed_sig = None
+        sig = self._signature()
+        if sig != self._packed_sig:
+            self.attach_arena(_lib.pack_to_device(self._desc, self._params(), self._KIND, self._handle.device))
+            self._packed_sig = sig
+        return self._handle
+
+    def attach_arena(self, arena: torch.Tensor):
+        """Attach an already packed arena (e.g. one received by RCCL broadcast, see dist.py)."""
+        if self._handle is None:
+            self._handle = _lib.Handle(arena.device)
+        _lib.check(self._fn("attach")(self._handle.h, C.byref(self._desc), _lib.ptr(arena), arena.numel()),
+                   self._handle.h)
+        self._arena = arena
+        self._prep_sig = None
+        self._packed_sig = self._signature()
+
+    def packed_arena(self, device) -> torch.Tensor:
+        self.engine(torch.device(device))
+        return self._arena
+
+    # ------------------------------------------------------------------ step-invariant conditioner work
+    def prepare(self, conditioner: torch.Tensor, cond_masks: Optional[torch.Tensor] = None) -> _lib.Handle:
+        """Hoisted conditioner projections of all layers (wavenet.py:108 is step-invariant)."""
+        _lib.require_gpu(conditioner, "denoiser conditioner")
+        eng = self.engine(conditioner.device)
+        sig = (conditioner.data_ptr(), conditioner._version, tuple(conditioner.shape),
+               None if cond_masks is None else (cond_masks.data_ptr(), cond_masks._version), self._packed_sig)
+        if sig != self._prep_sig:
+            B, E, T = conditioner.shape
+            if E != self._cond_channels:
+                raise ValueError(f"conditioner has {E} channels, expected {self._cond_channels}")
+            cond = conditioner.to(torch.float32).contiguous()
+            cm = None if cond_masks is None else cond_masks.to(torch.uint8).contiguous()
+            with eng.lock:
+                _lib.check(self._fn("prepare")(eng.h, _lib.ptr(cond), B, T, _lib.ptr(cm),
+                                                          _lib.stream_ptr(cond.device)), eng.h)
+            self._prep_sig = sig
+        return eng
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, diffusion_step, conditioner, x_masks=None, cond_masks=None):
+        """x [B, M, T] (or [B, 1, M, T]); diffusion_step [B] or [1] (long or float); conditioner [B, E, T]."""
+        use_4_dim = False
+        if x.dim() == 4:  # DiffSVC compatibility, wavenet.py:203-207
+            x = x[:, 0]
+            use_4_dim = True
+        assert x.dim() == 3, f"mel must be 3 dim tensor, but got {x.dim()}"
+        _lib.require_gpu(x, "denoiser input")
+        eng = self.prepare(conditioner, cond_masks)
+        B, M, T = x.shape
+        if M != self.mel_channels or conditioner.shape[0] != B or conditioner.shape[2] != T:
+            raise ValueError(f"x {tuple(x.shape)} does not match conditioner {tuple(conditioner.shape)}")
+        xin = x.to(torch.float32).contiguous()
+        t = diffusion_step.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()
+        out = torch.empty_like(xin)
+        with eng.lock:
+            _lib.check(self._fn("forward")(eng.h, _lib.ptr(xin), _lib.ptr(t), t.numel(), _lib.ptr(xm),
+                                                      _lib.ptr(out), _lib.stream_ptr(x.device)), eng.h)
+        return out[:, None] if use_4_dim else out
+
+
+class WaveNet(HipDenoiser):
     """Drop-in for the reference `WaveNet` (registered as DENOISERS "WaveNetDenoiser")."""
+
+    _KIND = "wavenet"
 
     def __init__(self, mel_channels=128, d_encoder=256, residual_channels=512, residual_layers=20,
                  use_linear_bias=False, dilation_cycle=None):
@@ -95,89 +193,8 @@ class WaveNet(nn.Module):
             self._keys.append(key)
         self._desc = _lib.WavenetDesc(mel_channels, d_encoder, residual_channels, residual_layers,
                                       int(dilation_cycle or 0), int(self.use_linear_bias))
-        # fail at construction (like a bad config would) rather than at first forward
-        nb = C.c_size_t()
-        _lib.check(_lib.lib().fdx_wavenet_packed_bytes(C.byref(self._desc), C.byref(nb)))
-        self._handle: Optional[_lib.Handle] = None
-        self._arena: Optional[torch.Tensor] = None
-        self._packed_sig = None
-        self._prep_sig = None
-
-    # ------------------------------------------------------------------ weights
-    def _params(self):
-        sd = dict(self.named_parameters())
-        return [sd[k] for k in self._keys]
-
-    def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self._params())
-
-    def engine(self, device: torch.device) -> _lib.Handle:
-        """The fdx handle for `device` with the current weights attached (repacked if they changed)."""
-        device = torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
-        if self._handle is None or self._handle.device != device:
-            self._handle = _lib.Handle(device)
-            self._packed_sig = None
-        sig = self._signature()
-        if sig != self._packed_sig:
-            self.attach_arena(_lib.pack_to_device(self._desc, self._params(), "wavenet", self._handle.device))
-            self._packed_sig = sig
-        return self._handle
-
-    def attach_arena(self, arena: torch.Tensor):
-        """Attach an already packed arena (e.g. one received by RCCL broadcast, see dist.py)."""
-        if self._handle is None:
-            self._handle = _lib.Handle(arena.device)
-        _lib.check(_lib.lib().fdx_wavenet_attach(self._handle.h, C.byref(self._desc), _lib.ptr(arena), arena.numel()),
-                   self._handle.h)
-        self._arena = arena
-        self._prep_sig = None
-        self._packed_sig = self._signature()
-
-    def packed_arena(self, device) -> torch.Tensor:
-        self.engine(torch.device(device))
-        return self._arena
-
-    # ------------------------------------------------------------------ step-invariant conditioner work
-    def prepare(self, conditioner: torch.Tensor, cond_masks: Optional[torch.Tensor] = None) -> _lib.Handle:
-        """Hoisted conditioner projections of all layers (wavenet.py:108 is step-invariant)."""
-        _lib.require_gpu(conditioner, "WaveNet conditioner")
-        eng = self.engine(conditioner.device)
-        sig = (conditioner.data_ptr(), conditioner._version, tuple(conditioner.shape),
-               None if cond_masks is None else (cond_masks.data_ptr(), cond_masks._version), self._packed_sig)
-        if sig != self._prep_sig:
-            B, E, T = conditioner.shape
-            if E != self.d_encoder:
-                raise ValueError(f"conditioner has {E} channels, expected d_encoder={self.d_encoder}")
-            cond = conditioner.to(torch.float32).contiguous()
-            cm = None if cond_masks is None else cond_masks.to(torch.uint8).contiguous()
-            with eng.lock:
-                _lib.check(_lib.lib().fdx_wavenet_prepare(eng.h, _lib.ptr(cond), B, T, _lib.ptr(cm),
-                                                          _lib.stream_ptr(cond.device)), eng.h)
-            self._prep_sig = sig
-        return eng
-
-    # ------------------------------------------------------------------ forward
-    @torch.no_grad()
-    def forward(self, x, diffusion_step, conditioner, x_masks=None, cond_masks=None):
-        """x [B, M, T] (or [B, 1, M, T]); diffusion_step [B] or [1] (long or float); conditioner [B, E, T]."""
-        use_4_dim = False
-        if x.dim() == 4:  # DiffSVC compatibility, wavenet.py:203-207
-            x = x[:, 0]
-            use_4_dim = True
-        assert x.dim() == 3, f"mel must be 3 dim tensor, but got {x.dim()}"
-        _lib.require_gpu(x, "WaveNet input")
-        eng = self.prepare(conditioner, cond_masks)
-        B, M, T = x.shape
-        if M != self.mel_channels or conditioner.shape[0] != B or conditioner.shape[2] != T:
-            raise ValueError(f"x {tuple(x.shape)} does not match conditioner {tuple(conditioner.shape)}")
-        xin = x.to(torch.float32).contiguous()
-        t = diffusion_step.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
-        xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()
-        out = torch.empty_like(xin)
-        with eng.lock:
-            _lib.check(_lib.lib().fdx_wavenet_forward(eng.h, _lib.ptr(xin), _lib.ptr(t), t.numel(), _lib.ptr(xm),
-                                                      _lib.ptr(out), _lib.stream_ptr(x.device)), eng.h)
-        return out[:, None] if use_4_dim else out
+        self._cond_channels = d_encoder
+        self._init_engine()
 
 
 DENOISERS.register_module(name="WaveNetDenoiser", module=WaveNet, force=True)

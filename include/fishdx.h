@@ -92,6 +92,37 @@ int fdx_wavenet_forward(fdx_handle h, const float* x, const float* t, int n_t, c
                         float* eps, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * ConvNext denoiser -- replaces fish_diffusion/modules/convnext.py:155-262 (class ConvNext,
+ * cross_attention=False; blocks :12-92), DENOISERS "ConvNextDenoiser"
+ * (archs/diffsinger/diffusions/builder.py:12).  Same call contract as the WaveNet: whichever of
+ * fdx_wavenet_prepare / fdx_convnext_prepare ran last selects the denoiser fdx_sampler_run drives.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fdx_convnext_desc {
+  int mel_channels;    /* 128; multiple of 8 */
+  int dim;             /* 512; multiple of 32, <= 512 */
+  int mlp_factor;      /* 4 */
+  int condition_dim;   /* 256; multiple of 8 */
+  int num_layers;      /* 20 */
+  int dilation_cycle;  /* 4 (dilations 2^(i % cycle), convnext.py:200) */
+  int cross_attention; /* must be 0: the cross-attention blocks (convnext.py:95-152) are not built */
+} fdx_convnext_desc;
+/* Canonical tensor order = the module's state_dict order (convnext.py:170-205): input_projection.{weight,bias},
+ * diffusion_embedding.{1,3}.{weight,bias}, conditioner_projection.{0,2}.{weight,bias}, per layer gamma,
+ * dwconv.{weight,bias}, norm.{weight,bias}, pwconv1.*, pwconv2.*, diffusion_step_projection.*, condition_projection.*;
+ * then output_projection.{0,2}.{weight,bias}. */
+int fdx_convnext_num_weights(const fdx_convnext_desc* d);
+int fdx_convnext_packed_bytes(const fdx_convnext_desc* d, size_t* bytes);
+int fdx_convnext_pack(const fdx_convnext_desc* d, const float* const* host_weights, int n_weights,
+                      void* host_packed, size_t bytes);
+int fdx_convnext_attach(fdx_handle h, const fdx_convnext_desc* d, const void* dev_packed, size_t bytes);
+/* cond: dev [B][condition_dim][T]; cond_mask: dev [B][T] bytes or NULL (convnext.py:247-248,69-70). */
+int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask,
+                         fdx_stream s);
+/* eps = ConvNext(x, t, cond); arguments as fdx_wavenet_forward. */
+int fdx_convnext_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask,
+                         float* eps, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Sampler loop -- replaces GaussianDiffusion.forward's loop, diffusion.py:234-311, and the three
  * predictors (noise_predictor.py:19-222, uni_pc.py:583-818).  The per-step scalars are computed by
  * the host (fish_diffusion_amd/schedule.py mirrors the reference's fp32 arithmetic) and passed as a

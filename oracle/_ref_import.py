@@ -142,10 +142,6 @@ def load():
     # drags in transformers): stand-ins keep the registry import working.
     if "fish_diffusion.modules.llama" not in sys.modules:
         _stub("fish_diffusion.modules.llama", LlamaDenoiser=type("LlamaDenoiser", (), {}))
-    if "fish_diffusion.modules.convnext" not in sys.modules:
-        _stub("fish_diffusion.modules.convnext", ConvNext=type("ConvNext", (), {}),
-              TransformerDecoderDenoiser=type("TransformerDecoderDenoiser", (), {}))
-
     def by_path(modname, relpath):
         spec = importlib.util.spec_from_file_location(modname, os.path.join(REFERENCE_ROOT, relpath))
         mod = importlib.util.module_from_spec(spec)
@@ -154,6 +150,7 @@ def load():
         return mod
 
     wavenet = importlib.import_module("fish_diffusion.modules.wavenet")
+    convnext = importlib.import_module("fish_diffusion.modules.convnext")   # the real module: torch + wavenet.DiffusionEmbedding only
     diffusion = importlib.import_module("fish_diffusion.archs.diffsinger.diffusions.diffusion")
     noise_predictor = importlib.import_module("fish_diffusion.archs.diffsinger.diffusions.noise_predictor")
     uni_pc = importlib.import_module("fish_diffusion.archs.diffsinger.diffusions.uni_pc")
@@ -173,6 +170,7 @@ def load():
         diffsinger_methods=_diffsinger_methods,
         hifisinger_methods=_hifisinger_methods,
         WaveNet=wavenet.WaveNet,
+        ConvNext=convnext.ConvNext,
         GaussianDiffusion=diffusion.GaussianDiffusion,
         DENOISERS=diffusion.DENOISERS,
         DIFFUSIONS=diffusion.DIFFUSIONS,

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
-from oracle import _ref_import, features_ref, mel_ref, nsf_hifigan_ref, refinegan_ref, sampler_ref, wavenet_ref  # noqa: E402
+from oracle import _ref_import, convnext_ref, features_ref, mel_ref, nsf_hifigan_ref, refinegan_ref, sampler_ref, wavenet_ref  # noqa: E402
 
 
 def sha1_of(tensors) -> str:
@@ -73,6 +73,84 @@ def build_ref_diffusion(R, wn_cfg, sd, **kw):
 def oracle_denoiser(sd, cfg):
     return lambda x, t, c, xm, cm: wavenet_ref.wavenet_forward(
         sd, x, t, c, xm, cm, residual_layers=cfg["residual_layers"], dilation_cycle=cfg["dilation_cycle"])
+
+
+CN_SMALL = dict(mel_channels=128, dim=64, mlp_factor=2, condition_dim=256, num_layers=4, dilation_cycle=4)
+CN_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=20, dilation_cycle=4)   # convnext.py:156-163 defaults
+
+
+@torch.no_grad()
+def golden_convnext(R):
+    """ConvNext denoiser: forward + the sampler loop driving it, outputs from the real reference classes."""
+    print("convnext")
+
+    def oracle_den(sd, cfg):
+        return lambda x, t, c, xm, cm: convnext_ref.convnext_forward(sd, x, t, c, xm, cm, num_layers=cfg["num_layers"],
+                                                                     dilation_cycle=cfg["dilation_cycle"])
+
+    def shapes_kw(cfg):
+        return {k: v for k, v in cfg.items() if k != "dilation_cycle"}
+
+    for tag, cfg, seed, (B, T) in (("small", CN_SMALL, 301, (2, 50)), ("full", CN_FULL, 4321, (2, 96))):
+        sd = convnext_ref.seeded_state(seed, **shapes_kw(cfg))
+        net = R["ConvNext"](**cfg).eval()
+        net.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(B, 128, T, generator=g)
+        cond = torch.randn(B, 256, T, generator=g)
+        t = torch.tensor([37.0, 912.5])[:B]
+        masks = torch.zeros(B, T, dtype=torch.bool)
+        masks[1, T - T // 4:] = True
+        eps = net(x, t, cond)
+        eps_masked = net(x, t, cond, x_masks=masks, cond_masks=masks)
+        eps_long = net(x, torch.tensor([400], dtype=torch.long), cond)
+        den = oracle_den(sd, cfg)
+        assert torch.equal(den(x, t, cond, None, None), eps), "oracle ConvNext != reference"
+        assert torch.equal(den(x, t, cond, masks, masks), eps_masked), "oracle ConvNext (masked) != reference"
+        arrays = dict(x=x, cond=cond, t=t, masks=masks, eps=eps, eps_masked=eps_masked, eps_long=eps_long, seed=np.int64(seed),
+                      weights_sha1=np.array(state_sha1(sd)))
+        if tag == "small":
+            arrays.update({"w:" + k: v for k, v in sd.items()})
+        save(f"convnext_{tag}", **arrays)
+
+    # the reference's own sampler loop driving the reference ConvNext (small net, every predictor, masks)
+    sd = convnext_ref.seeded_state(301, **shapes_kw(CN_SMALL))
+    diff = R["GaussianDiffusion"](denoiser=dict(type="ConvNextDenoiser", **CN_SMALL), spec_min=[-5], spec_max=[0]).eval()
+    diff.denoise_fn.load_state_dict(sd, strict=True)
+    den = oracle_den(sd, CN_SMALL)
+    B, T = 2, 40
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(B, T, 256, generator=g)
+    masks = torch.zeros(B, T, dtype=torch.bool)
+    masks[1, 30:] = True
+    for pred, interval in (("unipc", 50), ("plms", 50), ("naive", 100)):
+        seed = 3000 + interval
+        torch.manual_seed(seed)
+        ref = diff(feats, sampler_interval=interval, noise_predictor=pred, x_masks=masks, cond_masks=masks)
+        torch.manual_seed(seed)
+        x_init = torch.randn(B, 128, T)
+        n = len(range(0, 1000, interval))
+        step_noise = torch.stack([torch.randn(B, 128, T) for _ in range(n)]) if pred == "naive" else torch.zeros(0)
+        mine = sampler_ref.diffusion_sample(den, feats, x_init=x_init, sampler_interval=interval, predictor=pred,
+                                            step_noise=step_noise, x_masks=masks, cond_masks=masks)
+        assert torch.equal(mine, ref), f"oracle sampler over ConvNext {pred}/{interval} != reference"
+        save(f"convnext_sampler_small_{pred}_i{interval}", features=feats, masks=masks, x_init=x_init, step_noise=step_noise, mel=ref,
+             interval=np.int64(interval))
+
+    # full-size net: 5 s, 20-step UniPC (the shape of BASELINE configs[0] with the denoiser swapped)
+    sd = convnext_ref.seeded_state(4321, **shapes_kw(CN_FULL))
+    diff = R["GaussianDiffusion"](denoiser=dict(type="ConvNextDenoiser", **CN_FULL), spec_min=[-5], spec_max=[0]).eval()
+    diff.denoise_fn.load_state_dict(sd, strict=True)
+    T, interval, seed = 430, 50, 4400
+    feats = torch.randn(1, T, 256, generator=torch.Generator().manual_seed(seed))
+    torch.manual_seed(seed + 100)
+    ref = diff(feats, sampler_interval=interval)
+    torch.manual_seed(seed + 100)
+    x_init = torch.randn(1, 128, T)
+    mine = sampler_ref.diffusion_sample(oracle_den(sd, CN_FULL), feats, x_init=x_init, sampler_interval=interval)
+    assert torch.equal(mine, ref)
+    save("convnext_sampler_full_c1", features=feats, x_init=x_init, mel=ref, interval=np.int64(interval), seed=np.int64(4321),
+         weights_sha1=np.array(state_sha1(sd)))
 
 
 @torch.no_grad()
@@ -373,10 +451,17 @@ def main():
     save("hifisinger_v1", contents=contents, ids=ids, lens=lens, f0=f0, shift=shift, energy=energy1, wav=ref, noise_seed=np.int64(51),
          sha1_frontend=np.array(state_sha1(hsd1)), sha1_generator=np.array(state_sha1(gsd1)), config=np.array(json.dumps(h1)))
 
+    golden_convnext(R)
+
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("done")
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["convnext"]:   # regenerate one section only
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(os.cpu_count())
+        golden_convnext(_ref_import.load())
+    else:
+        main()

@@ -15,6 +15,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 WN_SMALL = dict(mel_channels=128, d_encoder=256, residual_channels=64, residual_layers=4, dilation_cycle=4, use_linear_bias=True)
 WN_FULL = dict(mel_channels=128, d_encoder=256, residual_channels=512, residual_layers=20, dilation_cycle=4, use_linear_bias=True)
+CN_SMALL = dict(mel_channels=128, dim=64, mlp_factor=2, condition_dim=256, num_layers=4, dilation_cycle=4)
+CN_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=20, dilation_cycle=4)
 
 
 def load(name):
@@ -42,6 +44,17 @@ def wavenet_sd(cfg, seed):
     from oracle import wavenet_ref
     kw = {k: v for k, v in cfg.items() if k != "dilation_cycle"}
     return wavenet_ref.seeded_wavenet_state(seed, **kw)
+
+
+def convnext_sd(cfg, seed):
+    from oracle import convnext_ref
+    return convnext_ref.seeded_state(seed, **{k: v for k, v in cfg.items() if k != "dilation_cycle"})
+
+
+def convnext_den(sd, cfg):
+    from oracle import convnext_ref
+    return lambda x, t, c, xm, cm: convnext_ref.convnext_forward(sd, x, t, c, xm, cm, num_layers=cfg["num_layers"],
+                                                                 dilation_cycle=cfg["dilation_cycle"])
 
 
 def synth_f0(T, frame_rate=44100 / 512):

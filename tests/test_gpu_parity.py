@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import WN_FULL, WN_SMALL, abs_err, load, rel_err, sha1_state, synth_f0, wavenet_sd
+from tests.helpers import CN_FULL, CN_SMALL, WN_FULL, WN_SMALL, abs_err, convnext_den, convnext_sd, load, rel_err, sha1_state, synth_f0, wavenet_sd
 
 pytestmark = pytest.mark.gpu
 
@@ -705,3 +705,90 @@ def test_hifisinger_v1_nsf_generator_variant_matches_reference_golden(dev):
     err = abs_err(wav.cpu(), g["wav"])
     print(f"hifisinger v1 end to end: wav abs err {err:.3e}")
     assert wav.shape == g["wav"].shape and err < WAV_ABS
+
+
+# ------------------------------------------------------------------------------------------------ ConvNext denoiser
+def _convnext(cfg, sd, dev):
+    from fish_diffusion_amd import DENOISERS
+    net = DENOISERS.build(dict(type="ConvNextDenoiser", **cfg))
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev).eval()
+
+
+def _convnext_diffusion(cfg, sd, dev, **kw):
+    from fish_diffusion_amd import DIFFUSIONS
+    d = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="ConvNextDenoiser", **cfg), spec_min=[-5], spec_max=[0], **kw))
+    d.denoise_fn.load_state_dict(sd, strict=True)
+    return d.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag,cfg", [("small", CN_SMALL), ("full", CN_FULL)])
+def test_convnext_forward_matches_reference_golden(dev, tag, cfg):
+    g = load(f"convnext_{tag}")
+    sd = convnext_sd(cfg, int(g["seed"]))
+    assert sha1_state(sd) == str(g["weights_sha1"])
+    net = _convnext(cfg, sd, dev)
+    x, cond, t, m = g["x"].to(dev), g["cond"].to(dev), g["t"].to(dev), g["masks"].bool().to(dev)
+    eps = net(x, t, cond)
+    print(f"convnext {tag}: eps rel err {rel_err(eps.cpu(), g['eps']):.3e}")
+    assert rel_err(eps.cpu(), g["eps"]) < 2e-5
+    eps_m = net(x, t, cond, x_masks=m, cond_masks=m)
+    assert rel_err(eps_m.cpu(), g["eps_masked"]) < 2e-5
+    assert (eps_m[1, :, g["masks"][1].bool()] == 0).all()
+    eps_l = net(x, torch.tensor([400], device=dev), cond)
+    assert rel_err(eps_l.cpu(), g["eps_long"]) < 2e-5
+    eps4 = net(x[:, None], t, cond)
+    assert eps4.shape == (x.shape[0], 1, 128, x.shape[2]) and torch.equal(eps4[:, 0], eps)
+
+
+def test_convnext_ragged_lengths_and_odd_configs_vs_oracle(dev):
+    """T smaller than the dilated receptive field / not a multiple of any tile, per-item timesteps, a dim that is not a power of
+    two, dilation_cycle 1, x_masks without cond_masks."""
+    for cfg, seed in ((CN_SMALL, 301), (dict(mel_channels=128, dim=96, mlp_factor=3, condition_dim=256, num_layers=3, dilation_cycle=1), 302)):
+        sd = convnext_sd(cfg, seed)
+        net = _convnext(cfg, sd, dev)
+        den = convnext_den(sd, cfg)
+        for B, T in ((1, 1), (3, 7), (2, 65), (1, 257), (2, 1000)):
+            g = torch.Generator().manual_seed(T)
+            x, cond = torch.randn(B, 128, T, generator=g), torch.randn(B, 256, T, generator=g)
+            t = torch.rand(B, generator=g) * 999
+            xm = torch.zeros(B, T, dtype=torch.bool)
+            xm[-1, T - T // 3:] = True
+            with torch.no_grad():
+                ref = den(x, t, cond, None, None)
+                ref_m = den(x, t, cond, xm, None)
+            assert rel_err(net(x.to(dev), t.to(dev), cond.to(dev)).cpu(), ref) < 2e-5, (cfg["dim"], B, T)
+            assert rel_err(net(x.to(dev), t.to(dev), cond.to(dev), x_masks=xm.to(dev)).cpu(), ref_m) < 2e-5, (cfg["dim"], B, T)
+
+
+@pytest.mark.parametrize("name", ["unipc_i50", "plms_i50", "naive_i100"])
+def test_sampler_over_convnext_matches_reference_golden(dev, name):
+    """GaussianDiffusion driving the ConvNext denoiser: same sampler loop kernels, the other denoiser."""
+    g = load(f"convnext_sampler_small_{name}")
+    diff = _convnext_diffusion(CN_SMALL, convnext_sd(CN_SMALL, 301), dev)
+    pred = name.split("_")[0]
+    m = g["masks"].bool().to(dev)
+    sn = g["step_noise"].to(dev) if pred == "naive" else None
+    for _ in range(2):   # second run replays the cached hipGraph
+        mel = diff(g["features"].to(dev), sampler_interval=int(g["interval"]), noise_predictor=pred, x_masks=m, cond_masks=m,
+                   x_init=g["x_init"].to(dev), step_noise=sn)
+        assert rel_err(mel.cpu(), g["mel"]) < MEL_REL, name
+
+
+def test_convnext_full_net_c1_and_denoiser_switching(dev):
+    """Full-size ConvNext (dim 512, 20 layers), 5 s, 20-step UniPC vs the REAL reference's mel; then a WaveNet diffusion and the
+    ConvNext one alternate on their own handles and on the same geometry without disturbing each other."""
+    g = load("convnext_sampler_full_c1")
+    sd = convnext_sd(CN_FULL, int(g["seed"]))
+    assert sha1_state(sd) == str(g["weights_sha1"])
+    diff = _convnext_diffusion(CN_FULL, sd, dev)
+    mel = diff(g["features"].to(dev), sampler_interval=int(g["interval"]), x_init=g["x_init"].to(dev))
+    err = rel_err(mel.cpu(), g["mel"])
+    print(f"convnext c1: mel rel err {err:.3e}")
+    assert err < MEL_REL
+    gw = load("sampler_full_c1")
+    wdiff = _diffusion(WN_FULL, wavenet_sd(WN_FULL, int(gw["seed"])), dev)
+    mel_w = wdiff(gw["features"].to(dev), sampler_interval=int(gw["interval"]), x_init=gw["x_init"].to(dev))
+    assert rel_err(mel_w.cpu(), gw["mel"]) < MEL_REL
+    mel2 = diff(g["features"].to(dev), sampler_interval=int(g["interval"]), x_init=g["x_init"].to(dev))
+    assert torch.equal(mel2, mel)

@@ -310,3 +310,105 @@ def test_diffsinger_frontend_state_dict_contract(lib):
         m.forward()
     with pytest.raises(RuntimeError):   # CPU tensors: no fallback
         m.forward_features(torch.tensor([1]), torch.zeros(1, 4, 256), torch.tensor([4]), 4, pitches=torch.zeros(1, 4))
+
+
+# ------------------------------------------------------------------ ConvNext denoiser: packing + arena layout, via the numpy kernel emulation
+def _cn_offsets(D, Hf, L, M, E):
+    """Mirror of cn_layout (fish_diffusion_amd/csrc/convnext.hip): arena section offsets in floats."""
+    H = D * Hf
+    r64 = lambda n: (n + 63) // 64 * 64
+
+    def plan(cur, rows, cin, RB=2):
+        mt = (rows + 32 * RB - 1) // (32 * RB)
+        w = mt * ((cin + 7) // 8) * RB * 64 * 4
+        return dict(w=cur, b=cur + w, mt=mt, cin8=(cin + 7) // 8, RB=RB, rows=rows), cur + w + r64(rows)
+    cur, out = 0, {}
+    for name, rows, cin in (("in_proj", D, M), ("emb1", H, D), ("emb3", D, H), ("cond0", H, E), ("cond2", D, H), ("dsp", L * D, D),
+                            ("cproj", L * D, D)):
+        out[name], cur = plan(cur, rows, cin)
+    for i in range(L):
+        out[f"pw1_{i}"], cur = plan(cur, H, D)
+        out[f"pw2_{i}"], cur = plan(cur, D, H, RB=1)
+        out[f"dw_w{i}"] = cur; cur += r64(D * 7)
+        for nm in ("dw_b", "ln_w", "ln_b", "gamma"):
+            out[f"{nm}{i}"] = cur; cur += r64(D)
+    out["out0"], cur = plan(cur, D, D)
+    out["out2"], cur = plan(cur, M, D)
+    out["total"] = cur
+    return out
+
+
+def test_convnext_arena_forward_emulation_matches_oracle(lib):
+    """Runs the whole ConvNext forward on the CPU *from the packed arena*, with the MFMA kernel's lane-level index math
+    (tests/helpers.emulate_convgemm) for every GEMM and numpy for the dwconv + LayerNorm kernel, and compares with the oracle:
+    checks fdx_convnext_pack, the arena layout and the hoisting algebra (per-layer slabs) without a GPU."""
+    from fish_diffusion_amd import ConvNext
+    from oracle import convnext_ref, wavenet_ref
+    cfg = dict(mel_channels=16, dim=32, mlp_factor=2, condition_dim=24, num_layers=3, dilation_cycle=2)
+    D, H, L, M, E = 32, 64, 3, 16, 24
+    sd = convnext_ref.seeded_state(5, **{k: v for k, v in cfg.items() if k != "dilation_cycle"})
+    net = ConvNext(**cfg)
+    net.load_state_dict(sd, strict=True)
+    arena = lib.pack_on_host(net._desc, net._params(), "convnext")
+    off = _cn_offsets(D, 2, L, M, E)
+    assert arena.size == off["total"]
+    T, halo = 21, 32
+
+    def gemm(name, X):   # X [cin, n] -> [rows, n] + bias
+        o = off[name]
+        n = X.shape[1]
+        Xp = np.zeros((o["cin8"] * 8, halo + (n + 63) // 64 * 64 + halo), np.float32)
+        Xp[:X.shape[0], halo:halo + n] = X
+        acc = emulate_convgemm(arena[o["w"]:o["b"]], Xp, n_mtiles=o["mt"], RB=o["RB"], cin8=o["cin8"], taps=1, shift0=0, dshift=0, T=n)
+        full = np.concatenate([acc[(mt, rb)] for mt in range(o["mt"]) for rb in range(o["RB"])])[:o["rows"]]
+        return (full + arena[o["b"]:o["b"] + o["rows"]][:, None].astype(np.float64)).astype(np.float32)
+
+    gelu = lambda a: torch.nn.functional.gelu(torch.from_numpy(a)).numpy()
+    g = torch.Generator().manual_seed(1)
+    x, cond = torch.randn(1, M, T, generator=g), torch.randn(1, E, T, generator=g)
+    t = torch.tensor([123.0])
+    mask = torch.zeros(1, T, dtype=torch.bool)
+    mask[0, 17:] = True
+    keep = (~mask[0]).numpy().astype(np.float32)[None]
+    # hoisted paths
+    c2 = gemm("cond2", gelu(gemm("cond0", cond[0].numpy()))) * keep
+    CP = gemm("cproj", c2)                                                   # [L*D, T]
+    emb = wavenet_ref.diffusion_embedding(t, D).numpy().T                     # [D, 1]
+    SB = gemm("dsp", gemm("emb3", gelu(gemm("emb1", emb))))                   # [L*D, 1]
+    # denoiser call
+    X = gelu(gemm("in_proj", x[0].numpy())) * keep
+    for i in range(L):
+        dil = 2 ** (i % 2)
+        v = (X + SB[i * D:(i + 1) * D] + CP[i * D:(i + 1) * D]) * keep
+        vp = np.pad(v, ((0, 0), (3 * dil, 3 * dil)))
+        w = arena[off[f"dw_w{i}"]:off[f"dw_w{i}"] + D * 7].reshape(D, 7)
+        u = sum(w[:, k:k + 1] * vp[:, k * dil:k * dil + T] for k in range(7)) + arena[off[f"dw_b{i}"]:off[f"dw_b{i}"] + D][:, None]
+        mu = u.mean(0, keepdims=True)
+        var = ((u - mu) ** 2).mean(0, keepdims=True)
+        n = (u - mu) / np.sqrt(var + 1e-6) * arena[off[f"ln_w{i}"]:off[f"ln_w{i}"] + D][:, None] + arena[off[f"ln_b{i}"]:off[f"ln_b{i}"] + D][:, None]
+        o2 = off[f"pw2_{i}"]
+        hid = gelu(gemm(f"pw1_{i}", n.astype(np.float32)))
+        y = gemm(f"pw2_{i}", hid)                                             # includes the bias
+        X = ((X + arena[off[f"gamma{i}"]:off[f"gamma{i}"] + D][:, None] * y) * keep).astype(np.float32)
+    out = gemm("out2", gelu(gemm("out0", X))) * keep
+    with torch.no_grad():
+        ref = convnext_ref.convnext_forward(sd, x, t, cond, mask, mask, num_layers=L, dilation_cycle=2)[0].numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_convnext_contract_and_bad_configs(lib):
+    from fish_diffusion_amd import DENOISERS, DIFFUSIONS, ConvNext
+    from oracle import convnext_ref
+    net = DENOISERS.build(dict(type="ConvNextDenoiser", mel_channels=16, dim=64, mlp_factor=2, condition_dim=24, num_layers=3))
+    assert isinstance(net, ConvNext)
+    want = [k for k, _ in convnext_ref.param_shapes(mel_channels=16, dim=64, mlp_factor=2, condition_dim=24, num_layers=3)]
+    assert list(net.state_dict().keys()) == want
+    assert float(net.state_dict()["residual_layers.0.gamma"][0]) == pytest.approx(1e-6)   # layer_scale_init_value, convnext.py:29
+    with pytest.raises(NotImplementedError):
+        ConvNext(cross_attention=True)
+    with pytest.raises(ValueError):
+        ConvNext(dim=100)                                   # not a multiple of 32: fails at construction
+    d = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="ConvNextDenoiser", dim=64, num_layers=2), spec_min=[-5], spec_max=[0]))
+    assert "denoise_fn.residual_layers.1.pwconv2.weight" in d.state_dict()
+    with pytest.raises(RuntimeError):                       # CPU tensors: no fallback
+        net(torch.zeros(1, 16, 8), torch.zeros(1), torch.zeros(1, 24, 8))

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import mel_ref, nsf_hifigan_ref, sampler_ref, wavenet_ref
-from tests.helpers import WN_FULL, WN_SMALL, load, rel_err, abs_err, sha1_state, wavenet_sd
+from tests.helpers import CN_FULL, CN_SMALL, WN_FULL, WN_SMALL, convnext_den, convnext_sd, load, rel_err, abs_err, sha1_state, wavenet_sd
 
 torch.set_num_threads(8)
 
@@ -147,3 +147,32 @@ def test_hifisinger_oracle_matches_reference():
     with torch.no_grad():
         wav = refinegan_ref.generator_forward(gsd, cfg, feats["features"].transpose(1, 2), g["f0"].transpose(1, 2), noises)
     assert abs_err(wav, g["wav"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ ConvNext denoiser
+@pytest.mark.parametrize("tag,cfg", [("small", CN_SMALL), ("full", CN_FULL)])
+def test_convnext_oracle_matches_reference(tag, cfg):
+    g = load(f"convnext_{tag}")
+    sd = convnext_sd(cfg, int(g["seed"]))
+    assert sha1_state(sd) == str(g["weights_sha1"]), "seeded weights drifted (torch RNG changed?)"
+    if tag == "small":
+        for k, v in sd.items():
+            assert torch.equal(v, g["w:" + k])
+    den = convnext_den(sd, cfg)
+    m = g["masks"].bool()
+    with torch.no_grad():
+        assert rel_err(den(g["x"], g["t"], g["cond"], None, None), g["eps"]) < 1e-5
+        assert rel_err(den(g["x"], g["t"], g["cond"], m, m), g["eps_masked"]) < 1e-5
+        assert rel_err(den(g["x"], torch.tensor([400]), g["cond"], None, None), g["eps_long"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["unipc_i50", "plms_i50", "naive_i100"])
+def test_sampler_over_convnext_oracle_matches_reference(name):
+    g = load(f"convnext_sampler_small_{name}")
+    sd = convnext_sd(CN_SMALL, 301)
+    m = g["masks"].bool()
+    with torch.no_grad():
+        mel = sampler_ref.diffusion_sample(convnext_den(sd, CN_SMALL), g["features"], x_init=g["x_init"],
+                                           sampler_interval=int(g["interval"]), predictor=name.split("_")[0],
+                                           step_noise=g["step_noise"], x_masks=m, cond_masks=m)
+    assert rel_err(mel, g["mel"]) < 1e-4
