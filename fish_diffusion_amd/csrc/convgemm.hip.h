@@ -44,7 +44,14 @@ struct ConvArgs {
   int tiles_per_item;             // ceil(T / cols_per_block)
   int n_tiles_n;                  // B * tiles_per_item
   int n_mtiles;
-  float in_slope;                 // leaky-relu slope applied to the B operand (LRELU instantiations)
+  float in_slope;                 // leaky-relu slope applied to the B operand (PRE == 1 instantiations)
+  // PRE == PRE_LN (LayerNorm over the K = channel axis folded into the GEMM, convnext.hip).  The B operand holds
+  // GROUP-centred values u - mean_g (groups of 32 channels); col_stats [item][T][2][16] = {mean_g[16], M2_g[16]} per frame;
+  // ln_R [rows][16] = per-group row sums of the weights.  result = rstd[t] * (acc + sum_g R[row][g] (mean_g[t] - mean[t])).
+  const float* __restrict__ col_stats;
+  const float* __restrict__ ln_R;
+  int n_groups;
+  float ln_eps;
 #ifdef FDX_KTRACE
   unsigned long long* trace;      // [block][wave][8] shader-clock stamps of this launch, or null (tools/ktrace.py)
 #endif
@@ -328,8 +335,12 @@ struct EpiLogMel {  // audio.py:11-18 + nsf_hifigan.py:104-105
 // Accumulator element r of a 32x32 tile sits at row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31.
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4, int MT = 1>
-__global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) {
+constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result transforms (a bool converts: false/true = none/lrelu)
+
+// (PRE_LN keeps its statistics in registers across the K loop: the second launch-bounds argument holds that instantiation to
+// the 256 VGPRs that let two workgroups share a CU, like every other instantiation already does unprompted.)
+template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1>
+__global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(ConvArgs a, Epi epi) {
   static_assert(NW == 4 || (SPLITK && NW == 8), "4 waves per workgroup, or 8 K-splitting waves (2 per SIMD)");
   static_assert(!Epi::kPaired || RB == 2, "paired epilogues need both row blocks");
   static_assert(MT == 1 || (SPLITK && MT == 2), "MT = 2 (two packed m-tiles per workgroup) is a split-K variant");
@@ -394,6 +405,54 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][nb][r] = 0.f;
 
+  // ---- PRE_LN: LayerNorm over the channel (K) axis folded into the GEMM.  The producer (convnext.hip: k_dwconv_stats) stored
+  // every channel centred by the mean of ITS group of 32 channels (exact, two-pass) plus the group means and centred sums of
+  // squares.  With delta_g = mean_g - mean:  W (u - mean) = W (u - mean_g(c)) + sum_g R[row][g] delta_g,  R = per-group row sums,
+  // and var = (sum_g M2_g + 32 sum_g delta_g^2) / K (Chan et al.) -- every term is a product of centred quantities, there is
+  // no E[u^2] - mean^2 or acc - mean*rowsum cancellation.  The K loop is untouched; the statistics' loads are issued with the
+  // epilogue prefetch and consumed after the reduction.
+  static_assert(PRE != PRE_LN || (SPLITK && !Epi::kPaired), "PRE_LN: split-K, unpaired epilogues");
+  static_assert(PRE != PRE_LN || (MT * ROWS * 4 == NW * 64 && NW == 4), "PRE_LN: one float4 of the tile's row sums per thread");
+  __shared__ float ln_rows[PRE == PRE_LN ? MT * ROWS * 16 : 1];   // this tile's rows of ln_R (weights: they come from HBM / MALL)
+  __shared__ float ln_cols[PRE == PRE_LN ? 64 * 17 : 1];          // per column of the tile: delta_g[16], rstd
+  // The statistics are combined ONCE per workgroup, 4 threads per column (thread = column tid >> 2, groups 4q .. 4q+3): two
+  // coalesced float4 loads per thread.  (Every lane loading its own two frames' 2 x 128 B -- 16 loads touching 64 different
+  // lines each -- kept the CU's L1 tag pipe busy for ~4 us per launch: 29.4 vs 24.7 us for the same GEMM without it.)
+  float4 rq{0.f, 0.f, 0.f, 0.f}, sq_mean{0.f, 0.f, 0.f, 0.f}, sq_m2{0.f, 0.f, 0.f, 0.f};
+  auto ln_prefetch = [&]() {
+    if constexpr (PRE == PRE_LN) {
+      rq = reinterpret_cast<const float4*>(a.ln_R + (long)row_base * 16)[threadIdx.x];
+      const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
+      const float4* p = reinterpret_cast<const float4*>(a.col_stats + ((long)item * a.T + min(tile_in_item * 64 + c, a.T - 1)) * 32);
+      sq_mean = p[q];
+      sq_m2 = p[4 + q];
+    }
+  };
+  auto ln_publish = [&]() {   // after the K loop, before the reduction's barrier
+    if constexpr (PRE == PRE_LN) {
+      reinterpret_cast<float4*>(ln_rows)[threadIdx.x] = rq;
+      const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
+      const float mg[4] = {sq_mean.x, sq_mean.y, sq_mean.z, sq_mean.w};
+      const float m2g[4] = {sq_m2.x, sq_m2.y, sq_m2.z, sq_m2.w};
+      float msum = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * q + k < a.n_groups) { msum += mg[k]; m2 += m2g[k]; }
+      msum += __shfl_xor(msum, 1); msum += __shfl_xor(msum, 2);
+      m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2);
+      const float mean = msum / (float)a.n_groups;
+      float dev2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = 4 * q + k < a.n_groups ? mg[k] - mean : 0.f;
+        ln_cols[c * 17 + 4 * q + k] = d;
+        dev2 += d * d;
+      }
+      dev2 += __shfl_xor(dev2, 1); dev2 += __shfl_xor(dev2, 2);
+      if (q == 0) ln_cols[c * 17 + 16] = 1.f / sqrtf((m2 + 32.f * dev2) / (float)(32 * a.n_groups) + a.ln_eps);
+    }
+  };
+
   const bool active = SPLITK ? true : (t0 < a.T);   // whole-wave overhang tiles skip the K loop
   if (active && it_begin < it_end) {
     struct Stage { float4 a[RBX]; f2 b[4]; };
@@ -433,13 +492,14 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
       tap = wrap ? 0 : tap + 1;
     };
     auto compute = [&](Stage& s) {
-      if (LRELU) {
+      if (PRE == PRE_LRELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           s.b[j].x = s.b[j].x > 0.f ? s.b[j].x : s.b[j].x * a.in_slope;
           s.b[j].y = s.b[j].y > 0.f ? s.b[j].y : s.b[j].y * a.in_slope;
         }
       }
+
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -479,6 +539,7 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
     for (int d = 0; d < D - 1; ++d) load(st[d]);
     __builtin_amdgcn_sched_barrier(0);
     prefetch_epilogue();
+    ln_prefetch();
     __builtin_amdgcn_sched_barrier(0);
     int done = 0;
     for (; done + D <= n; done += D) {
@@ -490,6 +551,7 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
       if (done + d < n) compute(st[d]);
   } else {
     prefetch_epilogue();
+    ln_prefetch();
   }
   FDX_STAMP(2);
 
@@ -510,6 +572,7 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
               f4{acc[2 * q][0][r], acc[2 * q][1][r], acc[2 * q + 1][0][r], acc[2 * q + 1][1][r]};
       }
     }
+    ln_publish();
     FDX_STAMP(3);
     __syncthreads();
     FDX_STAMP(4);
@@ -534,6 +597,33 @@ __global__ __launch_bounds__(NW * 64) void convgemm_kernel(ConvArgs a, Epi epi) 
         sum[i] = *reinterpret_cast<const f2*>(red + ridx(0, r) + 2 * blk);
 #pragma unroll
         for (int w = 1; w < NW; ++w) sum[i] += *reinterpret_cast<const f2*>(red + ridx(w, r) + 2 * blk);
+      }
+      if constexpr (PRE == PRE_LN) {
+        f2 delta[16];
+        const float* lc = ln_cols + (2 * li) * 17;   // this lane's column pair inside the tile
+#pragma unroll
+        for (int g = 0; g < 16; ++g) delta[g] = f2{lc[g], lc[17 + g]};
+        const f2 rstd{lc[16], lc[17 + 16]};
+        constexpr int HS = NS >= 4 ? NS / 2 : NS;   // two batches of row-sum reads (LDS): all NS rows at once would not fit 256 VGPRs
+#pragma unroll
+        for (int h0 = 0; h0 < NS; h0 += HS) {
+          float4 R[HS][4];
+#pragma unroll
+          for (int i = 0; i < HS; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[i][q] = reinterpret_cast<const float4*>(ln_rows + (site_row(wave * NS + h0 + i) - row_base) * 16)[q];
+#pragma unroll
+          for (int i = 0; i < HS; ++i) {
+            f2 corr{0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              corr += R[i][q].x * delta[4 * q] + R[i][q].y * delta[4 * q + 1];
+              corr += R[i][q].z * delta[4 * q + 2] + R[i][q].w * delta[4 * q + 3];
+            }
+            sum[h0 + i] = (sum[h0 + i] + corr) * rstd;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
       for (int i = 0; i < NS; ++i) epi.store(item, site_row(wave * NS + i), tc, col_two, sum[i], pre[i]);
@@ -566,10 +656,11 @@ struct ConvGeom {   // everything the launcher needs besides pointers
   int n_mtiles;     // row tiles of 32*RB logical rows (32 pairs for paired epilogues)
 };
 
-template <int RB, bool SPLITK, bool LRELU, class Epi, int NW = 4, int MT = 1>
+template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1>
 inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx,
                                   float in_slope, const Epi& epi, hipStream_t s, hipEvent_t ev_start = nullptr,
-                                  hipEvent_t ev_stop = nullptr) {
+                                  hipEvent_t ev_stop = nullptr, const float* col_stats = nullptr, const float* ln_R = nullptr,
+                                  int n_groups = 0, float ln_eps = 0.f) {
   ConvArgs a;
   a.Wp = Wp; a.X = X; a.x_bstride = x_bstride; a.ldx = ldx;
   a.n_it = g.cin8 * g.taps; a.taps = g.taps; a.shift0 = g.shift0; a.dshift = g.dshift;
@@ -579,6 +670,7 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   a.n_tiles_n = g.B * a.tiles_per_item;
   a.n_mtiles = g.n_mtiles;
   a.in_slope = in_slope;
+  a.col_stats = col_stats; a.ln_R = ln_R; a.n_groups = n_groups; a.ln_eps = ln_eps;
   if (g.n_mtiles % MT) return hipErrorInvalidValue;
   const int grid = a.n_tiles_n * (a.n_mtiles / MT);
   if (grid <= 0) return hipSuccess;
@@ -588,9 +680,9 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
-    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0, a, epi);
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0, a, epi);
   else
-    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, LRELU, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, a, epi);
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, a, epi);
   return hipGetLastError();
 }
 

@@ -5,8 +5,8 @@
 //
 // Per denoiser call (B items, T frames, D = dim, H = D * mlp_factor, L layers):
 //   1 x  input_projection      GEMM [D x M]     epilogue: +bias, GELU, mask                                   :231-239
-//   L x  dwconv + LayerNorm    VALU             u = dwconv_d(mask(x + step_l + cond_l)); n = LN_channels(u)   :66-80
-//   L x  pwconv1               GEMM [H x D]     epilogue: +bias, GELU                                         :81-82
+//   L x  dwconv + LN stats     VALU             u = dwconv_d(mask(x + step_l + cond_l)); per-frame channel statistics of u  :66-79
+//   L x  pwconv1 (LayerNorm)   GEMM [H x D]     LayerNorm folded in (PRE_LN: group-offset term, * rstd); epilogue: +bias, GELU   :80-82
 //   L x  pwconv2               GEMM [D x H]     epilogue: x = x + gamma * (. + bias), mask                    :83-92
 //   1 x  output_projection.0   GEMM [D x D]     epilogue: +bias, GELU                                         :256
 //   1 x  output_projection.2   GEMM [M x D]     epilogue: +bias, mask                                         :256-258
@@ -25,8 +25,8 @@ namespace {
 
 struct CnLayout {
   PackedW in_proj, emb1, emb3, cond0, cond2, dsp, cproj, out0, out2;   // dsp / cproj: all layers concatenated along rows
-  std::vector<PackedW> pw1, pw2;
-  std::vector<size_t> dw_w, dw_b, ln_w, ln_b, gamma;
+  std::vector<PackedW> pw1, pw2, pw2w;   // pw2: 32-row tiles (small grids), pw2w: the same weights in 64-row tiles (large grids)
+  std::vector<size_t> dw_w, dw_b, gamma, lnR;   // (norm.weight / norm.bias live folded inside pw1; lnR: [round_up(H, 64)][16] group row sums)
   std::vector<int> dil;
   size_t total_floats = 0;
 };
@@ -68,12 +68,14 @@ void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
   l.cond2 = plan64(cur, D, H);
   l.dsp = plan64(cur, L * D, D);
   l.cproj = plan64(cur, L * D, D);
-  l.pw1.clear(); l.pw2.clear(); l.dw_w.clear(); l.dw_b.clear(); l.ln_w.clear(); l.ln_b.clear(); l.gamma.clear(); l.dil.clear();
+  l.pw1.clear(); l.pw2.clear(); l.pw2w.clear(); l.dw_w.clear(); l.dw_b.clear(); l.gamma.clear(); l.lnR.clear(); l.dil.clear();
   for (int i = 0; i < L; ++i) {
     l.pw1.push_back(plan64(cur, H, D));
     l.pw2.push_back(plan32(cur, D, H));
+    l.pw2w.push_back(plan64(cur, D, H));
     l.dw_w.push_back(cur); cur += round_up(D * 7, 64);
-    for (auto* v : {&l.dw_b, &l.ln_w, &l.ln_b, &l.gamma}) { v->push_back(cur); cur += round_up(D, 64); }
+    for (auto* v : {&l.dw_b, &l.gamma}) { v->push_back(cur); cur += round_up(D, 64); }
+    l.lnR.push_back(cur); cur += (size_t)round_up(H, 64) * 16;
     l.dil.push_back(1 << (i % d.dilation_cycle));
   }
   l.out0 = plan64(cur, D, D);
@@ -96,84 +98,93 @@ void pack_lin(float* A, const PackedW& p, const float* w, int rows, int cin, con
 }
 
 // ------------------------------------------------------------------------------------------------ dwconv + LayerNorm
-// One workgroup = 16 frames x all D channels (T / 16 workgroups per item: the op is latency-, not bandwidth-bound, so it
-// wants many small workgroups); thread (tc, cg) owns channels cg*CPT .. +CPT (CPT = D / 16 <= 32) of frame t0 + tc and keeps
-// its conv outputs in registers; the LayerNorm statistics (two-pass: mean, then centred variance) are reduced over the 16
-// channel groups through LDS.  v(t') = mask(x + step + cond)(t'), zero outside [0, T): exactly the zero padding of the
-// reference's depthwise Conv1d applied after the adds and the mask (convnext.py:64-77).
-constexpr int kCnFr = 16, kCnCg = 16, kCnCpt = 32;
+// k_dwconv_stats, (T/64) x (D/32) x B workgroups (the op is latency-, not bandwidth-bound: it wants many small workgroups; one
+// workgroup owning all D channels of a frame tile ran 33.7 us per layer at T = 861):
+//   v = mask(x + step + cond) for 32 channels x (64 + 6*dil) frames staged ONCE into LDS (zero outside [0, T): exactly the zero
+//   padding of the reference's depthwise Conv1d applied after the adds and the mask, convnext.py:64-77); u = dwconv(v) + bias
+//   from LDS -> U; per frame the group's mean and centred sum of squares (two-pass, over its 32 channels) -> ST[b][t][{mean,M2}][16].
+// The LayerNorm itself is folded into the pwconv1 GEMM (convgemm.hip.h PRE_LN): U holds every channel centred by the mean of its
+// OWN group of 32 channels (exact); the GEMM's epilogue combines the D/32 group statistics of the lane's two frames (Chan et
+// al.), adds the group-offset term sum_g R[row][g] (mean_g - mean) (R = per-group row sums of the folded weights) and scales
+// by rstd[t]; the affine part (norm.weight, norm.bias) is folded into pwconv1's weights and bias at pack time:
+//   W1 (((u - mean) rstd) w + b) + b1  =  rstd (W1 diag(w)) (u - mean) + (W1 b + b1).
+constexpr int kCnCh = 32;            // channels per workgroup
+constexpr int kCnMaxW = 64 + 6 * 8;  // widest staged row (dilation 8)
 
-__global__ __launch_bounds__(256) void k_dwconv_ln(float* __restrict__ N, const float* __restrict__ X, long bs, int ld,
-                                                   const float* __restrict__ CP, long cp_bs,   // layer slab [D][ld]
-                                                   const float* __restrict__ SB, int sb_ld, int sb_bs,   // [D][sb_ld], column = step
-                                                   const uint8_t* __restrict__ mask, const float* __restrict__ dw_w,
-                                                   const float* __restrict__ dw_b, const float* __restrict__ ln_w,
-                                                   const float* __restrict__ ln_b, int D, int T, int dil, float eps) {
-  __shared__ float red[kCnCg][kCnFr];
-  const int tc = threadIdx.x & (kCnFr - 1), cg = threadIdx.x / kCnFr;
-  const int b = blockIdx.y, t = blockIdx.x * kCnFr + tc;
-  const int cpt = D / kCnCg;
-  const bool live = t < T;
-  bool ok[7];
-  int off[7];
+__global__ __launch_bounds__(256) void k_dwconv_stats(float* __restrict__ U, float* __restrict__ ST, const float* __restrict__ X, long bs,
+                                                      int ld, const float* __restrict__ CP, long cp_bs,   // layer slab [D][ld]
+                                                      const float* __restrict__ SB, int sb_ld, int sb_bs,  // [D][sb_ld], column = step
+                                                      const uint8_t* __restrict__ mask, const float* __restrict__ dw_w,
+                                                      const float* __restrict__ dw_b, int D, int T, int dil) {
+  __shared__ float v[kCnCh][kCnMaxW];
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t0 = blockIdx.x * 64, g = blockIdx.y, b = blockIdx.z;
+  const int W = 64 + 6 * dil, tl = t0 - 3 * dil;
+  // ---- stage v: wave wv loads channels wv, wv + 4, ...; lanes cover the W columns in two chunks
+  bool ok[2];
+  int col[2], tq[2];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    off[k] = (k - 3) * dil;
-    const int tt = t + off[k];
-    ok[k] = live && tt >= 0 && tt < T && !(mask && mask[(long)b * T + tt]);
-    if (!ok[k]) off[k] = 0;
+  for (int q = 0; q < 2; ++q) {
+    col[q] = lane + 64 * q;
+    const int tt = tl + col[q];
+    tq[q] = min(max(tt, 0), T - 1);   // loads are unconditional (all in flight at once) from a clamped frame, then selected
+    ok[q] = col[q] < W && tt >= 0 && tt < T && !(mask && mask[(long)b * T + tq[q]]);
   }
-  const int tl = live ? t : T - 1;   // dead lanes read a valid address and discard
-  const float* xb = X + b * bs + tl;
-  const float* cb = CP + b * cp_bs + tl;
-  float u[kCnCpt];
+  const float* xb = X + b * bs;
+  const float* cb = CP + b * cp_bs;
+  float xv[kCnCh / 4][2], cv[kCnCh / 4][2], sbv[kCnCh / 4];
+#pragma unroll
+  for (int j = 0; j < kCnCh / 4; ++j) {
+    const int c = g * kCnCh + wv + 4 * j;
+    sbv[j] = SB[(long)c * sb_ld + b * sb_bs];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      xv[j][q] = xb[(long)c * ld + tq[q]];
+      cv[j][q] = cb[(long)c * ld + tq[q]];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kCnCh / 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (col[q] < W) v[wv + 4 * j][col[q]] = ok[q] ? (xv[j][q] + sbv[j]) + cv[j][q] : 0.f;
+  __syncthreads();
+  // ---- conv from LDS: thread (lane = frame, wave = 8 channels)
+  const int t = t0 + lane;
+  float u[8];
   float s1 = 0.f;
 #pragma unroll
-  for (int ci = 0; ci < kCnCpt; ++ci) {
-    u[ci] = 0.f;
-    if (ci < cpt) {
-      const int c = cg * cpt + ci;
-      const float sb = SB[(long)c * sb_ld + b * sb_bs];
-      const float* xr = xb + (long)c * ld;
-      const float* cr = cb + (long)c * ld;
-      float acc = 0.f;
+  for (int j = 0; j < 8; ++j) {
+    const int ch = wv * 8 + j, c = g * kCnCh + ch;
+    float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const float v = (xr[off[k]] + sb) + cr[off[k]];
-        acc += dw_w[c * 7 + k] * (ok[k] ? v : 0.f);
-      }
-      u[ci] = acc + dw_b[c];
-      s1 += u[ci];
-    }
+    for (int k = 0; k < 7; ++k) acc += dw_w[c * 7 + k] * v[ch][lane + k * dil];
+    u[j] = acc + dw_b[c];
+    s1 += u[j];
   }
-  auto total = [&](float v) {
-    __syncthreads();
-    red[cg][tc] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < kCnCg; ++g) s += red[g][tc];
-    return s;
-  };
-  const float mean = total(s1) / (float)D;
+  red[wv][lane] = s1;
+  __syncthreads();
+  const float mean_g = (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) * (1.f / kCnCh);
+  __syncthreads();
   float s2 = 0.f;
 #pragma unroll
-  for (int ci = 0; ci < kCnCpt; ++ci)
-    if (ci < cpt) { const float dlt = u[ci] - mean; s2 += dlt * dlt; }
-  const float var = total(s2) / (float)D;
-  const float rstd = 1.f / sqrtf(var + eps);
-  if (!live) return;
-  float* nb = N + b * bs + t;
+  for (int j = 0; j < 8; ++j) { const float dlt = u[j] - mean_g; s2 += dlt * dlt; }
+  red[wv][lane] = s2;
+  __syncthreads();
+  if (t >= T) return;
+  if (wv == 0) {
+    float* st = ST + ((long)b * T + t) * 32 + g;
+    st[0] = mean_g;
+    st[16] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  }
+  float* ub = U + b * bs + t;
 #pragma unroll
-  for (int ci = 0; ci < kCnCpt; ++ci)
-    if (ci < cpt) {
-      const int c = cg * cpt + ci;
-      nb[(long)c * ld] = (u[ci] - mean) * rstd * ln_w[c] + ln_b[c];
-    }
+  for (int j = 0; j < 8; ++j) ub[(long)(g * kCnCh + wv * 8 + j) * ld] = u[j] - mean_g;   // group-centred (see PRE_LN)
 }
 
 struct CnBufs {
-  DevBuf X, N, G, H2, condp, c1, c2, CP;
+  DevBuf X, N, G, H2, condp, c1, c2, CP, ST;
   DevBuf c2raw, CP2;   // PLMS + cond_masks: condition / per-layer projections of the UNMASKED conditioner (diffusion.py:285)
   DevBuf E, Hm, S0, SB;
   int ldn = 0, n_emb = 0;
@@ -231,9 +242,25 @@ extern "C" int fdx_convnext_pack(const fdx_convnext_desc* d, const float* const*
   for (int i = 0; i < L; ++i) {
     memcpy(A + l.gamma[i], w[k], D * sizeof(float)); k += 1;
     memcpy(A + l.dw_w[i], w[k], (size_t)D * 7 * sizeof(float)); memcpy(A + l.dw_b[i], w[k + 1], D * sizeof(float)); k += 2;
-    memcpy(A + l.ln_w[i], w[k], D * sizeof(float)); memcpy(A + l.ln_b[i], w[k + 1], D * sizeof(float)); k += 2;
-    pack_lin(A, l.pw1[i], w[k], H, D, w[k + 1]); k += 2;
-    pack_lin(A, l.pw2[i], w[k], D, H, w[k + 1]); k += 2;
+    k += 2;   // norm.weight, norm.bias: folded into pwconv1 below
+    {  // pwconv1 with the LayerNorm affine folded in: W1' = W1 diag(norm.weight), b1' = W1 norm.bias + b1 (fp64 sums, rounded once)
+      const float* lw = w[k - 2]; const float* lb = w[k - 1]; const float* W1 = w[k]; const float* b1 = w[k + 1];
+      std::vector<float> Wf((size_t)H * D), bf(H);
+      for (int r = 0; r < H; ++r) {
+        double acc = b1[r];
+        for (int c = 0; c < D; ++c) { Wf[(size_t)r * D + c] = W1[(size_t)r * D + c] * lw[c]; acc += (double)W1[(size_t)r * D + c] * (double)lb[c]; }
+        bf[r] = (float)acc;
+      }
+      pack_lin(A, l.pw1[i], Wf.data(), H, D, bf.data()); k += 2;
+      for (int r = 0; r < H; ++r)            // R[r][g] = sum over group g's 32 channels of the folded weights
+        for (int g = 0; g < D / kCnCh; ++g) {
+          double acc = 0;
+          for (int c = g * kCnCh; c < (g + 1) * kCnCh; ++c) acc += (double)Wf[(size_t)r * D + c];
+          A[l.lnR[i] + (size_t)r * 16 + g] = (float)acc;
+        }
+    }
+    pack_lin(A, l.pw2[i], w[k], D, H, w[k + 1]);
+    pack_lin(A, l.pw2w[i], w[k], D, H, w[k + 1]); k += 2;
     pack_lin(A, l.dsp, w[k], D, D, w[k + 1], i * D); k += 2;
     pack_lin(A, l.cproj, w[k], D, D, w[k + 1], i * D); k += 2;
   }
@@ -294,6 +321,7 @@ extern "C" int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int 
   FDX_HIP(h, b.X.ensure(sz(D), geom, s)); FDX_HIP(h, b.N.ensure(sz(D), geom, s)); FDX_HIP(h, b.H2.ensure(sz(D), geom, s));
   FDX_HIP(h, b.G.ensure(sz(H), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s)); FDX_HIP(h, b.c2.ensure(sz(D), geom, s));
   FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.CP.ensure(sz(L * D), geom, s));
+  FDX_HIP(h, b.ST.ensure((size_t)B * T * 32 * sizeof(float), false, s));
   // condition = conditioner_projection(conditioner).masked_fill(cond_masks)  (convnext.py:242,247-248)
   hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, b.condp.f() + kHalo, (long)E * ld, ld, cond, (long)E * T, T, E, T,
                      1.f, (const uint8_t*)nullptr);
@@ -365,19 +393,28 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
   float* X = b.X.f() + kHalo; float* N = b.N.f() + kHalo; float* G = b.G.f() + kHalo; float* H2 = b.H2.f() + kHalo;
   const float* SB = b.SB.f() + kHalo + col0;
   const float* CP = (unmasked_cond ? b.CP2.f() : b.CP.f()) + kHalo;
+  // pwconv2 has only D rows: 32-row tiles double the workgroup count when 64-row tiles would not fill the 256 CUs (batch 1-2 at
+  // 10 s); above that the 64-row tiles' higher operand reuse wins
+  const bool wide_pw2 = (long)B * ((T + 63) / 64) * ((D + 63) / 64) >= 256;
   {  // x = gelu(input_projection(x)).masked_fill(x_masks)
     EpiBias e = bias_epi(X, bsD, ld, A + l.in_proj.b_off, D, ACT_GELU);
     e.mask = mask; e.mask_ld = T;
     FDX_HIP(h, gemm(A, l.in_proj, B, T, xin, (long)M * ld, ld, e, s));
   }
   for (int i = 0; i < L; ++i) {
-    hipLaunchKernelGGL(k_dwconv_ln, dim3((T + kCnFr - 1) / kCnFr, B), dim3(256), 0, s, N, X, bsD, ld, CP + (size_t)i * D * ld,
-                       (long)L * D * ld, SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, mask, A + l.dw_w[i], A + l.dw_b[i], A + l.ln_w[i],
-                       A + l.ln_b[i], D, T, l.dil[i], 1e-6f);
-    FDX_HIP(h, gemm(A, l.pw1[i], B, T, N, bsD, ld, bias_epi(G, bsH, ld, A + l.pw1[i].b_off, H, ACT_GELU), s));
+    const dim3 grid((T + 63) / 64, D / kCnCh, B);
+    hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, N, b.ST.f(), X, bsD, ld, CP + (size_t)i * D * ld, (long)L * D * ld,
+                       SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, mask, A + l.dw_w[i], A + l.dw_b[i], D, T, l.dil[i]);
+    {  // pwconv1 over LayerNorm(u): centring + rstd inside the GEMM, affine folded into the packed weights
+      const PackedW& p = l.pw1[i];
+      ConvGeom gg{B, T, p.cin8, 1, 0, 0, p.n_mtiles};
+      FDX_HIP(h, (launch_convgemm<2, true, PRE_LN, EpiBias>(gg, reinterpret_cast<const float4*>(A + p.w_off), N, bsD, ld, 1.f,
+                                                            bias_epi(G, bsH, ld, A + p.b_off, H, ACT_GELU), s, nullptr, nullptr,
+                                                            b.ST.f(), A + l.lnR[i], D / kCnCh, 1e-6f)));
+    }
     EpiScaleRes e{};
     e.X = X; e.bs = bsD; e.ld = ld; e.bias = A + l.pw2[i].b_off; e.gamma = A + l.gamma[i]; e.M = D; e.mask = mask; e.mask_ld = T;
-    FDX_HIP(h, gemm(A, l.pw2[i], B, T, G, bsH, ld, e, s));
+    FDX_HIP(h, gemm(A, wide_pw2 ? l.pw2w[i] : l.pw2[i], B, T, G, bsH, ld, e, s));
   }
   FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
   {

@@ -329,9 +329,11 @@ def _cn_offsets(D, Hf, L, M, E):
     for i in range(L):
         out[f"pw1_{i}"], cur = plan(cur, H, D)
         out[f"pw2_{i}"], cur = plan(cur, D, H, RB=1)
+        out[f"pw2w_{i}"], cur = plan(cur, D, H, RB=2)
         out[f"dw_w{i}"] = cur; cur += r64(D * 7)
-        for nm in ("dw_b", "ln_w", "ln_b", "gamma"):
+        for nm in ("dw_b", "gamma"):
             out[f"{nm}{i}"] = cur; cur += r64(D)
+        out[f"lnR{i}"] = cur; cur += r64(H) * 16
     out["out0"], cur = plan(cur, D, D)
     out["out2"], cur = plan(cur, M, D)
     out["total"] = cur
@@ -354,13 +356,15 @@ def test_convnext_arena_forward_emulation_matches_oracle(lib):
     assert arena.size == off["total"]
     T, halo = 21, 32
 
-    def gemm(name, X):   # X [cin, n] -> [rows, n] + bias
+    def gemm(name, X, bias=True):   # X [cin, n] -> [rows, n] (+ bias)
         o = off[name]
         n = X.shape[1]
         Xp = np.zeros((o["cin8"] * 8, halo + (n + 63) // 64 * 64 + halo), np.float32)
         Xp[:X.shape[0], halo:halo + n] = X
         acc = emulate_convgemm(arena[o["w"]:o["b"]], Xp, n_mtiles=o["mt"], RB=o["RB"], cin8=o["cin8"], taps=1, shift0=0, dshift=0, T=n)
         full = np.concatenate([acc[(mt, rb)] for mt in range(o["mt"]) for rb in range(o["RB"])])[:o["rows"]]
+        if not bias:
+            return full
         return (full + arena[o["b"]:o["b"] + o["rows"]][:, None].astype(np.float64)).astype(np.float32)
 
     gelu = lambda a: torch.nn.functional.gelu(torch.from_numpy(a)).numpy()
@@ -385,10 +389,20 @@ def test_convnext_arena_forward_emulation_matches_oracle(lib):
         u = sum(w[:, k:k + 1] * vp[:, k * dil:k * dil + T] for k in range(7)) + arena[off[f"dw_b{i}"]:off[f"dw_b{i}"] + D][:, None]
         mu = u.mean(0, keepdims=True)
         var = ((u - mu) ** 2).mean(0, keepdims=True)
-        n = (u - mu) / np.sqrt(var + 1e-6) * arena[off[f"ln_w{i}"]:off[f"ln_w{i}"] + D][:, None] + arena[off[f"ln_b{i}"]:off[f"ln_b{i}"] + D][:, None]
-        o2 = off[f"pw2_{i}"]
-        hid = gelu(gemm(f"pw1_{i}", n.astype(np.float32)))
+        # LayerNorm folded into pwconv1 (PRE_LN): the B operand is centred per group of 32 channels, the epilogue adds the
+        # group-offset term R (mean_g - mean) and scales by rstd; the affine part lives inside the packed weights / bias
+        o1 = off[f"pw1_{i}"]
+        ug = u.reshape(D // 32, 32, T)
+        mean_g = ug.mean(1)                                                    # [G, T]
+        m2_g = ((ug - mean_g[:, None]) ** 2).sum(1)
+        delta = mean_g - mean_g.mean(0, keepdims=True)
+        var2 = (m2_g.sum(0) + 32 * (delta ** 2).sum(0)) / D
+        np.testing.assert_allclose(var2, var[0], rtol=1e-5)
+        R = arena[off[f"lnR{i}"]:off[f"lnR{i}"] + H * 16].reshape(H, 16)[:, :D // 32]
+        acc = gemm(f"pw1_{i}", (ug - mean_g[:, None]).reshape(D, T).astype(np.float32), bias=False) + R @ delta
+        hid = gelu((acc / np.sqrt(var2 + 1e-6) + arena[o1["b"]:o1["b"] + H][:, None]).astype(np.float32))
         y = gemm(f"pw2_{i}", hid)                                             # includes the bias
+        np.testing.assert_allclose(gemm(f"pw2w_{i}", hid), y, rtol=1e-5, atol=1e-6)   # the 64-row-tile packing of the same weights
         X = ((X + arena[off[f"gamma{i}"]:off[f"gamma{i}"] + D][:, None] * y) * keep).astype(np.float32)
     out = gemm("out2", gelu(gemm("out0", X))) * keep
     with torch.no_grad():
