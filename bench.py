@@ -259,7 +259,9 @@ def main():
             traffic, traffic_src = pmc_traffic(args.batch, T)
             C_, M_ = WN_CFG["residual_channels"], args.batch * T
             alg_bytes = 4 * (2 * C_ * 3 * C_ + C_ * M_ + 2 * C_ * M_ + C_ * M_)   # weights + Y in + conditioner slab in + Z out
-            roofline = {"bound": "mfma", "kernel": "convgemm_kernel<2,splitK,EpiGate> (dilated conv k=3 + gate, residual block)",
+            kname = ("convgemm_kernel<2,splitK,EpiGate> (v_mfma_f32_32x32x2_f32)" if os.environ.get("FDX_RESBLOCK_MFMA") == "32"
+                     else "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)")
+            roofline = {"bound": "mfma", "kernel": kname + ": dilated conv k=3 + gate of the residual block",
                         "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                         "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch of the first timed step", "avg_launch_us": round(avg_ms * 1e3, 2),
