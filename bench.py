@@ -264,7 +264,8 @@ def main():
             roofline = {"bound": "mfma", "kernel": kname + ": dilated conv k=3 + gate of the residual block",
                         "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                        "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes, "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch of the first timed step", "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
+                        "hbm_fraction": (round(traffic / (avg_ms * 1e-3) / 8.0e12, 4) if traffic else None), "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch of the first timed step", "avg_launch_us": round(avg_ms * 1e3, 2),
                         "timing": "hipExtLaunchKernel start/stop events on the launch stream, timed region",
                         "flops_per_launch": fl.value}
 

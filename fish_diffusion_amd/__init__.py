@@ -7,9 +7,10 @@ from .convnext import ConvNext  # noqa: F401
 from .diffusion import GaussianDiffusion  # noqa: F401
 from .nsf_hifigan import NsfHifiGAN, Generator  # noqa: F401
 from .mel import PitchAdjustableMelSpectrogram  # noqa: F401
-from .diffsinger import ENCODERS, DiffSinger, NaiveProjectionEncoder, pitch_to_scale  # noqa: F401
+from .diffsinger import ENCODERS, DiffSinger, NaiveProjectionEncoder, pitch_to_scale, repeat_expand  # noqa: F401
 from .refinegan import RefineGAN, RefineGANGenerator  # noqa: F401
 from .hifisinger import HiFiSinger  # noqa: F401
+from . import segments  # noqa: F401
 
 __all__ = ["DENOISERS", "DIFFUSIONS", "VOCODERS", "install", "WaveNet", "ConvNext", "GaussianDiffusion", "NsfHifiGAN", "Generator",
-           "PitchAdjustableMelSpectrogram", "ENCODERS", "DiffSinger", "NaiveProjectionEncoder", "pitch_to_scale", "RefineGAN", "RefineGANGenerator", "HiFiSinger"]
+           "PitchAdjustableMelSpectrogram", "ENCODERS", "DiffSinger", "NaiveProjectionEncoder", "pitch_to_scale", "repeat_expand", "RefineGAN", "RefineGANGenerator", "HiFiSinger"]

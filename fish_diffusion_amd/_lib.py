@@ -45,7 +45,7 @@ class RefineGanDesc(C.Structure):
 
 
 class FeatureTerm(C.Structure):
-    _fields_ = [("kind", C.c_int), ("per_frame", C.c_int), ("preproc", C.c_int), ("_pad", C.c_int), ("values", C.c_void_p),
+    _fields_ = [("kind", C.c_int), ("per_frame", C.c_int), ("preproc", C.c_int), ("src_frames", C.c_int), ("values", C.c_void_p),
                 ("w", C.c_void_p), ("b", C.c_void_p), ("p0", C.c_float), ("p1", C.c_float)]
 
 
@@ -101,6 +101,9 @@ _SIGS = {
     "fdx_features_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm), C.c_int, _P, _P]),
     "fdx_features_forward_ex": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm), C.c_int, C.c_int, _P,
                                            C.c_int, _P, _P]),
+    "fdx_features_forward_src": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm),
+                                            C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "fdx_repeat_expand": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, _P, _P]),
     "fdx_debug_conv1d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, _P, _P]),
     "fdx_prof_enable": (C.c_int, [_P, C.c_int]),
@@ -166,6 +169,17 @@ class Handle:
         self.h = C.c_void_p()
         self.lock = threading.RLock()
         check(lib().fdx_create(self.device.index, C.byref(self.h)))
+
+    _shared = {}
+
+    @classmethod
+    def shared(cls, device: torch.device) -> "Handle":
+        """A per-device handle for stateless helpers (repeat_expand, ...) that own no weights."""
+        device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        hnd = cls._shared.get(device.index)
+        if hnd is None:
+            hnd = cls._shared[device.index] = cls(device)
+        return hnd
 
     def __del__(self):
         try:

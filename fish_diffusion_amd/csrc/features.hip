@@ -26,8 +26,14 @@ struct FeatArgs {
   float* out;                                           // [B][T][E], or [B][E][T] when channel_first
   const uint8_t* mask;                                  // [B][T] bytes (1 = padding -> output 0) or null
   int B, T, Din, E, n_terms, act, channel_first;
+  int S, x_channel_first;                               // contents frames / layout (see fdx_features_forward_src)
+  float x_scale;                                        // (float)S / T, the scale F.interpolate(mode="nearest") uses
   fdx_feature_term terms[FDX_MAX_FEATURE_TERMS];
+  float term_scale[FDX_MAX_FEATURE_TERMS];              // (float)src_frames / T per term
 };
+
+// F.interpolate(mode="nearest") source index (ATen nearest_neighbor_compute_source_index): fp32 product, floor, clamp
+__device__ __forceinline__ int nearest_src(int t, float scale, int S) { return min((int)floorf((float)t * scale), S - 1); }
 
 __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
   __shared__ float xs[kTT][kTC + 1];
@@ -42,7 +48,12 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
     for (int i = tid; i < kTT * kTC; i += 256) {
       const int r = i / kTC, c = i - r * kTC;
       const int t = t0 + r;
-      xs[r][c] = (t < a.T && c0 + c < a.Din) ? a.x[((long)b * a.T + t) * a.Din + c0 + c] : 0.f;
+      float xv = 0.f;
+      if (t < a.T && c0 + c < a.Din) {
+        const int ts = a.S == a.T ? t : nearest_src(t, a.x_scale, a.S);
+        xv = a.x_channel_first ? a.x[((long)b * a.Din + c0 + c) * a.S + ts] : a.x[((long)b * a.S + ts) * a.Din + c0 + c];
+      }
+      xs[r][c] = xv;
     }
     for (int i = tid; i < kTE * kTC; i += 256) {
       const int r = i / kTC, c = i - r * kTC;
@@ -68,15 +79,17 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
     if (a.bias) v += a.bias[e];
     for (int k = 0; k < a.n_terms; ++k) {
       const fdx_feature_term& m = a.terms[k];
+      const int Sk = m.src_frames > 0 ? m.src_frames : a.T;
+      const int tk = Sk == a.T ? t : nearest_src(t, a.term_scale[k], Sk);
       if (m.kind == FDX_TERM_VECTOR) {            // [B][E] or [B][T][E] float embedding (speaker mix)
         const float* p = static_cast<const float*>(m.values);
-        v += m.per_frame ? p[((long)b * a.T + t) * a.E + e] : p[(long)b * a.E + e];
+        v += m.per_frame ? p[((long)b * Sk + tk) * a.E + e] : p[(long)b * a.E + e];
       } else if (m.kind == FDX_TERM_EMBEDDING) {  // nn.Embedding lookup, ids [B] int64
         const long id = static_cast<const long long*>(m.values)[b];
         v += m.w[id * a.E + e];
       } else {                                    // Linear(1 -> E) on a scalar channel
         const float* p = static_cast<const float*>(m.values);
-        float s = m.per_frame ? p[(long)b * a.T + t] : p[b];
+        float s = m.per_frame ? p[(long)b * Sk + tk] : p[b];
         if (m.preproc == FDX_PRE_PITCH_TO_SCALE) {  // utils/pitch.py:12-22
           s = (s - m.p0) / (m.p1 - m.p0);
           s = s < 0.f ? 0.f : s;
@@ -94,7 +107,23 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
   }
 }
 
+__global__ void k_repeat_expand(float* __restrict__ dst, const float* __restrict__ src, int S, int T, float scale) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const long r = blockIdx.y;
+  dst[r * T + t] = src[r * S + nearest_src(t, scale, S)];
+}
+
 }  // namespace
+
+extern "C" int fdx_repeat_expand(fdx_handle h, const float* src, long rows, int S, int T, float* dst, fdx_stream st) {
+  if (!h) return FDX_E_ARG;
+  if (!src || !dst || rows <= 0 || S <= 0 || T <= 0 || rows > 65535) return fail(h, FDX_E_ARG, "fdx_repeat_expand: bad arguments");
+  FDX_HIP(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_repeat_expand, dim3((T + 255) / 256, (unsigned)rows), dim3(256), 0, as_stream(st), dst, src, S, T, (float)S / (float)T);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
 
 extern "C" int fdx_features_forward(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
                                     const float* b_text, const fdx_feature_term* terms, int n_terms, float* features,
@@ -105,7 +134,15 @@ extern "C" int fdx_features_forward(fdx_handle h, const float* contents, int B, 
 extern "C" int fdx_features_forward_ex(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
                                        const float* b_text, const fdx_feature_term* terms, int n_terms, int act,
                                        const uint8_t* mask, int channel_first, float* features, fdx_stream st) {
+  return fdx_features_forward_src(h, contents, B, T, 0, T, Din, E, w_text, b_text, terms, n_terms, act, mask, channel_first, features, st);
+}
+
+extern "C" int fdx_features_forward_src(fdx_handle h, const float* contents, int B, int S, int contents_channel_first, int T,
+                                        int Din, int E, const float* w_text, const float* b_text, const fdx_feature_term* terms,
+                                        int n_terms, int act, const uint8_t* mask, int channel_first, float* features,
+                                        fdx_stream st) {
   if (!h) return FDX_E_ARG;
+  if (S <= 0) return fail(h, FDX_E_ARG, "fdx_features_forward: contents has no frames");
   if (act != FDX_ACT_NONE && act != FDX_ACT_SILU) return fail(h, FDX_E_ARG, "fdx_features_forward_ex: unknown activation %d", act);
   if (!contents || !w_text || !features || B <= 0 || T <= 0 || Din <= 0 || E <= 0)
     return fail(h, FDX_E_ARG, "fdx_features_forward: bad arguments");
@@ -115,6 +152,7 @@ extern "C" int fdx_features_forward_ex(fdx_handle h, const float* contents, int 
   a.x = contents; a.w = w_text; a.bias = b_text; a.out = features;
   a.B = B; a.T = T; a.Din = Din; a.E = E; a.n_terms = n_terms;
   a.act = act; a.mask = mask; a.channel_first = channel_first;
+  a.S = S; a.x_channel_first = contents_channel_first; a.x_scale = (float)S / (float)T;
   for (int k = 0; k < n_terms; ++k) {
     const fdx_feature_term& m = terms[k];
     if (m.kind < FDX_TERM_VECTOR || m.kind > FDX_TERM_SCALAR_LINEAR || !m.values)
@@ -122,7 +160,9 @@ extern "C" int fdx_features_forward_ex(fdx_handle h, const float* contents, int 
     if (m.kind != FDX_TERM_VECTOR && !m.w) return fail(h, FDX_E_ARG, "fdx_features_forward: term %d has no weights", k);
     if (m.kind == FDX_TERM_SCALAR_LINEAR && m.preproc == FDX_PRE_PITCH_TO_SCALE && m.p1 == m.p0)
       return fail(h, FDX_E_ARG, "fdx_features_forward: term %d: f0_max == f0_min", k);
+    if (m.src_frames < 0) return fail(h, FDX_E_ARG, "fdx_features_forward: term %d: negative src_frames", k);
     a.terms[k] = m;
+    a.term_scale[k] = (float)(m.src_frames > 0 ? m.src_frames : T) / (float)T;
   }
   FDX_HIP(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(k_features, dim3((T + kTT - 1) / kTT, (E + kTE - 1) / kTE, B), dim3(256), 0, as_stream(st), a);

@@ -35,6 +35,27 @@ def pitch_to_scale(f0, f0_min=F0_MIN, f0_max=F0_MAX):
     return f0_scale.unsqueeze(-1) if f0.ndim == 2 else f0_scale
 
 
+@torch.no_grad()
+def repeat_expand(content: torch.Tensor, target_len: int, mode: str = "nearest") -> torch.Tensor:
+    """`fish_diffusion.utils.tensor.repeat_expand` (utils/tensor.py:7-43) for device tensors: `[S]`, `[C, S]` or `[B, C, S]` ->
+    the same rank with `target_len` frames, F.interpolate(mode="nearest") index semantics.  (Inside the inference chain the
+    expansion is fused into the front-end launch instead -- `DiffSinger.forward_features(..., mel_max_len=T)`.)"""
+    if mode != "nearest":
+        raise NotImplementedError(f"repeat_expand mode {mode!r}: only 'nearest' (the reference's default and only use) is built")
+    if not torch.is_tensor(content):
+        raise TypeError("repeat_expand on the MI355X path takes device tensors (the numpy branch of the reference is host preprocessing)")
+    assert content.ndim in (1, 2, 3)
+    _lib.require_gpu(content, "repeat_expand input")
+    src = content.to(torch.float32).contiguous()
+    S = src.shape[-1]
+    rows = src.numel() // S
+    out = torch.empty(src.shape[:-1] + (int(target_len),), device=src.device, dtype=torch.float32)
+    h = _lib.Handle.shared(src.device)
+    with h.lock:
+        _lib.check(_lib.lib().fdx_repeat_expand(h.h, _lib.ptr(src), rows, S, int(target_len), _lib.ptr(out), _lib.stream_ptr(src.device)), h.h)
+    return out.to(content.dtype) if content.dtype != torch.float32 and torch.is_floating_point(content) else out
+
+
 def _is_pitch_to_scale(fn) -> bool:
     return fn is not None and getattr(fn, "__name__", "") == "pitch_to_scale"
 
@@ -121,7 +142,8 @@ class DiffSinger(nn.Module):
         return self._handle
 
     @staticmethod
-    def _scalar_term(enc: NaiveProjectionEncoder, values: torch.Tensor, B: int, T: int, keep: list) -> _lib.FeatureTerm:
+    def _scalar_term(enc: NaiveProjectionEncoder, values: torch.Tensor, B: int, T: int, keep: list,
+                     allow_expand: bool = False) -> _lib.FeatureTerm:
         if enc.use_embedding or enc.input_size != 1:
             raise NotImplementedError("only Linear(1 -> hidden) scalar encoders are fused")
         pre = _lib.PRE_NONE
@@ -132,10 +154,13 @@ class DiffSinger(nn.Module):
         v = values.to(torch.float32)
         if v.ndim == 3 and v.shape[-1] == 1:
             v = v[..., 0]
+        src_frames = 0
         if v.ndim == 2 and v.shape == (B, 1) and T != 1:
             v, per_frame = v[:, 0], 0
         elif v.ndim == 2 and v.shape == (B, T):
             per_frame = 1
+        elif v.ndim == 2 and v.shape[0] == B and allow_expand:   # a track at another frame rate: fused repeat_expand
+            per_frame, src_frames = 1, int(v.shape[1])
         elif v.ndim == 1 and v.shape[0] == B:
             per_frame = 0
         else:
@@ -144,18 +169,30 @@ class DiffSinger(nn.Module):
         w = enc.projection.weight.detach().to(torch.float32).reshape(-1).contiguous()
         b = enc.projection.bias.detach().to(torch.float32).contiguous()
         keep += [v, w, b]
-        return _lib.FeatureTerm(_lib.TERM_SCALAR_LINEAR, per_frame, pre, 0, v.data_ptr(), w.data_ptr(), b.data_ptr(), F0_MIN, F0_MAX)
+        return _lib.FeatureTerm(_lib.TERM_SCALAR_LINEAR, per_frame, pre, src_frames, v.data_ptr(), w.data_ptr(), b.data_ptr(), F0_MIN, F0_MAX)
 
     @torch.no_grad()
     def forward_features(self, speakers, contents, contents_lens, contents_max_len, mel_lens=None, mel_max_len=None,
-                         pitches=None, pitch_shift=None, phones2mel=None, energy=None):
+                         pitches=None, pitch_shift=None, phones2mel=None, energy=None, *, contents_channel_first=False,
+                         expand_to: Optional[int] = None):
+        """Reference signature (diffsinger.py:57-68) plus two keyword-only extensions that fuse the step before it in
+        SVCInference.forward -- `repeat_expand(text_features, mel_len).T` (tools/diffusion/inference.py:113-114): with
+        `expand_to=T` the contents (and a per-frame pitch track of another length) are read at their own frame rate and
+        nearest-expanded to T frames inside the launch; `contents_channel_first` takes the extractor's `[B, Din, S]` layout."""
         if phones2mel is not None:
             raise NotImplementedError("phones2mel (SVS duration gather, diffsinger.py:85-90) is outside the SVC hot path")
         if not isinstance(self.text_encoder, NaiveProjectionEncoder) or self.text_encoder.use_embedding:
             raise NotImplementedError("only the NaiveProjectionEncoder (Linear) text encoder is fused")
         _lib.require_gpu(contents, "contents")
         mel_masks = self.get_mask_from_lengths(mel_lens, mel_max_len) if mel_lens is not None else None
-        B, T, Din = contents.shape
+        if contents_channel_first:
+            B, Din, S = contents.shape
+        else:
+            B, S, Din = contents.shape
+        T = int(expand_to) if expand_to is not None else S
+        if T <= 0:
+            raise ValueError("expand_to must be positive")
+        expand = expand_to is not None
         E = self.text_encoder.output_size
         keep, terms = [], []
         # speaker: float embedding [B,E] / [B,T,E] given directly, or ids through speaker_encoder (diffsinger.py:92-108)
@@ -179,11 +216,11 @@ class DiffSinger(nn.Module):
             keep += [ids, tab]
             terms.append(_lib.FeatureTerm(_lib.TERM_EMBEDDING, 0, 0, 0, ids.data_ptr(), tab.data_ptr(), None, 0.0, 0.0))
         if hasattr(self, "pitch_encoder"):
-            terms.append(self._scalar_term(self.pitch_encoder, pitches, B, T, keep))
+            terms.append(self._scalar_term(self.pitch_encoder, pitches, B, T, keep, allow_expand=expand))
         if pitch_shift is not None and hasattr(self, "pitch_shift_encoder"):
             terms.append(self._scalar_term(self.pitch_shift_encoder, pitch_shift, B, T, keep))
         if energy is not None and hasattr(self, "energy_encoder"):
-            terms.append(self._scalar_term(self.energy_encoder, energy, B, T, keep))
+            terms.append(self._scalar_term(self.energy_encoder, energy, B, T, keep, allow_expand=expand))
         if len(terms) > _lib.MAX_FEATURE_TERMS:
             raise ValueError("too many additive terms")
 
@@ -194,8 +231,9 @@ class DiffSinger(nn.Module):
         arr = (_lib.FeatureTerm * max(1, len(terms)))(*terms)
         eng = self._engine(contents.device)
         with eng.lock:
-            _lib.check(_lib.lib().fdx_features_forward(eng.h, _lib.ptr(x), B, T, Din, E, _lib.ptr(w), _lib.ptr(b), arr, len(terms),
-                                                       _lib.ptr(out), _lib.stream_ptr(contents.device)), eng.h)
+            _lib.check(_lib.lib().fdx_features_forward_src(eng.h, _lib.ptr(x), B, S, int(bool(contents_channel_first)), T, Din, E,
+                                                           _lib.ptr(w), _lib.ptr(b), arr, len(terms), _lib.ACT_NONE, None, 0,
+                                                           _lib.ptr(out), _lib.stream_ptr(contents.device)), eng.h)
         del keep
         return dict(features=out, x_masks=mel_masks, x_lens=mel_lens, cond_masks=mel_masks)
 
@@ -205,13 +243,20 @@ class DiffSinger(nn.Module):
 
     @torch.no_grad()
     def infer(self, speakers, contents, pitches, *, sampler_interval=None, noise_predictor=None, skip_steps=0,
-              original_mel=None, pitch_shift=None, energy=None, mel_lens=None, **diffusion_kwargs):
-        """The call chain of SVCInference.forward (tools/diffusion/inference.py:131-159) for a batch: features -> mel."""
-        B, T, _ = contents.shape
+              original_mel=None, pitch_shift=None, energy=None, mel_lens=None, mel_len: Optional[int] = None,
+              contents_channel_first: bool = False, **diffusion_kwargs):
+        """The call chain of SVCInference.forward (tools/diffusion/inference.py:104-159) for a batch: extractor output -> mel.
+        `contents` [B, T, Din]; or, with `mel_len=T` (`audio.shape[-1] // 512`, :104), the extractor's own frames `[B, S, Din]` /
+        `[B, Din, S]` (`contents_channel_first`) nearest-expanded to T inside the front-end launch (:113-114), as is a pitch
+        track given at another length (:108-109)."""
+        B = contents.shape[0]
+        S = contents.shape[2 if contents_channel_first else 1]
+        T = int(mel_len) if mel_len is not None else S
         lens = mel_lens if mel_lens is not None else torch.full((B,), T, device=contents.device, dtype=torch.long)
         f = self.forward_features(speakers=speakers, contents=contents, contents_lens=lens, contents_max_len=T, mel_lens=mel_lens,
                                   mel_max_len=T if mel_lens is not None else None, pitches=pitches, pitch_shift=pitch_shift,
-                                  energy=energy)
+                                  energy=energy, contents_channel_first=contents_channel_first,
+                                  expand_to=T if (mel_len is not None or contents_channel_first) else None)
         return self.diffusion(f["features"], sampler_interval=sampler_interval, noise_predictor=noise_predictor,
                               skip_steps=skip_steps, original_mel=original_mel, x_masks=f["x_masks"], cond_masks=f["cond_masks"],
                               **diffusion_kwargs)

@@ -265,7 +265,9 @@ enum { FDX_TERM_VECTOR = 0,        /* values: float [B][E] (per_frame = 0) or [B
 enum { FDX_PRE_NONE = 0, FDX_PRE_PITCH_TO_SCALE = 1 /* clamp((f0 - p0) / (p1 - p0), 0, 1), p0 = f0_min, p1 = f0_max */ };
 #define FDX_MAX_FEATURE_TERMS 6
 typedef struct {
-  int kind, per_frame, preproc, _pad;
+  int kind, per_frame, preproc;
+  int src_frames;   /* per_frame terms: frames the values tensor holds; 0 = T.  Otherwise frame t reads source frame
+                       min(floor(t * (float)src_frames / T), src_frames - 1) -- repeat_expand, utils/tensor.py:7-43 */
   const void* values;
   const float* w;
   const float* b;   /* may be NULL */
@@ -281,6 +283,17 @@ enum { FDX_ACT_NONE = 0, FDX_ACT_SILU = 1 };
 int fdx_features_forward_ex(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
                             const float* b_text, const fdx_feature_term* terms, int n_terms, int act,
                             const uint8_t* mask, int channel_first, float* features, fdx_stream s);
+
+/* The same launch reading `contents` at the feature extractor's own frame rate and layout: contents is dev [B][S][Din], or
+ * [B][Din][S] when contents_channel_first (what the extractors return, tools/diffusion/inference.py:113-114), and output
+ * frame t uses source frame min(floor(t * (float)S / T), S - 1): `repeat_expand(text_features, mel_len).T`
+ * (F.interpolate(mode="nearest"), utils/tensor.py:7-43) fused into the projection instead of materialising [T][Din]. */
+int fdx_features_forward_src(fdx_handle h, const float* contents, int B, int S, int contents_channel_first, int T, int Din,
+                             int E, const float* w_text, const float* b_text, const fdx_feature_term* terms, int n_terms,
+                             int act, const uint8_t* mask, int channel_first, float* features, fdx_stream s);
+/* dst[r][t] = src[r][min(floor(t * (float)S / T), S - 1)] for r < rows: fish_diffusion.utils.tensor.repeat_expand
+ * (mode "nearest") on its own, e.g. for a pitch track given at another frame rate (inference.py:108-109). */
+int fdx_repeat_expand(fdx_handle h, const float* src, long rows, int S, int T, float* dst, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level test / profiling hooks (used by tests/ and bench.py only)

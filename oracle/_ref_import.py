@@ -162,11 +162,13 @@ def load():
     enc_builder = by_path("fish_diffusion.modules.encoders.builder", "fish_diffusion/modules/encoders/builder.py")
     naive = by_path("fish_diffusion.modules.encoders.naive_projection", "fish_diffusion/modules/encoders/naive_projection.py")
     pitch = by_path("fish_diffusion.utils.pitch", "fish_diffusion/utils/pitch.py")
+    tensor_utils = by_path("fish_diffusion.utils.tensor", "fish_diffusion/utils/tensor.py")
 
     _loaded.update(
         ENCODERS=enc_builder.ENCODERS,
         NaiveProjectionEncoder=naive.NaiveProjectionEncoder,
         pitch_to_scale=pitch.pitch_to_scale,
+        repeat_expand=tensor_utils.repeat_expand,
         diffsinger_methods=_diffsinger_methods,
         hifisinger_methods=_hifisinger_methods,
         WaveNet=wavenet.WaveNet,

@@ -29,6 +29,14 @@ def pitch_to_scale(f0: torch.Tensor, f0_min=F0_MIN, f0_max=F0_MAX) -> torch.Tens
     return s.unsqueeze(-1) if f0.ndim == 2 else s
 
 
+def repeat_expand(content: torch.Tensor, target_len: int) -> torch.Tensor:
+    """utils/tensor.py:7-43 (mode "nearest"): [S] / [C, S] / [B, C, S] -> target_len frames."""
+    nd = content.ndim
+    x = content[None, None] if nd == 1 else content[None] if nd == 2 else content
+    y = torch.nn.functional.interpolate(x, size=target_len, mode="nearest")
+    return y[0, 0] if nd == 1 else y[0] if nd == 2 else y
+
+
 def mask_from_lengths(lengths: torch.Tensor, max_len: Optional[int] = None) -> torch.Tensor:
     """diffsinger.py:42-55: True = padding."""
     if max_len is None:

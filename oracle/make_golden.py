@@ -154,6 +154,53 @@ def golden_convnext(R):
 
 
 @torch.no_grad()
+def golden_frontend_expand(R):
+    """The step before forward_features in SVCInference.forward: repeat_expand(text_features, mel_len).T and
+    repeat_expand(pitches, mel_len) (tools/diffusion/inference.py:108-114), then forward_features -- reference functions."""
+    print("front end: repeat_expand + forward_features")
+    rexp = R["repeat_expand"]
+    get_mask, fwd_features = R["diffsinger_methods"]()
+    Enc = R["NaiveProjectionEncoder"]
+
+    class RefFrontEnd(torch.nn.Module):
+        forward_features = fwd_features
+
+        def __init__(self, sd):
+            super().__init__()
+            self.get_mask_from_lengths = get_mask.__func__ if hasattr(get_mask, "__func__") else get_mask
+            self.text_encoder = Enc(256, 256)
+            self.speaker_encoder = Enc(10, 256, use_embedding=True)
+            self.pitch_encoder = Enc(1, 256, preprocessing=R["pitch_to_scale"])
+            self.load_state_dict(sd, strict=True)
+
+    g = torch.Generator().manual_seed(77)
+    arrays = {}
+    # raw index semantics: up- and down-sampling, 1-D / 2-D
+    for S, T in ((31, 70), (215, 430), (430, 215), (7, 7), (1, 9), (1000, 861)):
+        x = torch.randn(3, S, generator=g)
+        ref = rexp(x, T)                      # (the reference returns None for 3-D input: it falls off the end, tensor.py:38-43)
+        assert torch.equal(features_ref.repeat_expand(x, T), ref)
+        assert torch.equal(rexp(x[0], T), ref[0]) and torch.equal(features_ref.repeat_expand(x[None], T)[0], ref)
+        arrays[f"x_{S}_{T}"], arrays[f"y_{S}_{T}"] = x, ref
+    # the chain: extractor layout [Din, S] at its own frame rate, a pitch track of another length
+    B, S, Sp, T = 2, 31, 50, 70
+    contents_cf = torch.randn(B, 256, S, generator=g)
+    f0_src = 80.0 + 600.0 * torch.rand(B, Sp, generator=g)
+    ids = torch.tensor([4, 7])
+    sd = features_ref.seeded_frontend_state(11)
+    lens = torch.tensor([T, T])
+    text = torch.stack([rexp(c, T).T for c in contents_cf])            # inference.py:113-114
+    f0 = torch.stack([rexp(p, T) for p in f0_src])                      # :108-109
+    ref = RefFrontEnd(sd).forward_features(ids, text, lens, T, mel_lens=lens, mel_max_len=T, pitches=f0.clone())
+    mine = features_ref.forward_features(sd, torch.stack([features_ref.repeat_expand(c, T).T for c in contents_cf]), ids,
+                                         torch.stack([features_ref.repeat_expand(p, T) for p in f0_src]), None, None, lens, T)
+    assert torch.equal(mine["features"], ref["features"])
+    arrays.update(contents_cf=contents_cf, f0_src=f0_src, ids=ids, features=ref["features"], T=np.int64(T),
+                  sha1=np.array(state_sha1(sd)))
+    save("frontend_expand", **arrays)
+
+
+@torch.no_grad()
 def main():
     os.makedirs(GOLD, exist_ok=True)
     R = _ref_import.load()
@@ -452,6 +499,7 @@ def main():
          sha1_frontend=np.array(state_sha1(hsd1)), sha1_generator=np.array(state_sha1(gsd1)), config=np.array(json.dumps(h1)))
 
     golden_convnext(R)
+    golden_frontend_expand(R)
 
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
@@ -459,9 +507,10 @@ def main():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["convnext"]:   # regenerate one section only
+    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand}
+    if len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(os.cpu_count())
-        golden_convnext(_ref_import.load())
+        SECTIONS[sys.argv[1]](_ref_import.load())
     else:
         main()

@@ -504,6 +504,36 @@ def test_forward_features_matches_reference_golden(dev):
         ma.forward_features(ids, c, lens, T, pitches=f0, phones2mel=torch.zeros(3, T, dtype=torch.long, device=dev))
 
 
+def test_repeat_expand_and_fused_expansion_match_reference_golden(dev):
+    """utils/tensor.py:7-43 on the device, alone and fused into the front-end launch (inference.py:108-114)."""
+    from fish_diffusion_amd import repeat_expand
+    from oracle import features_ref
+    g = load("frontend_expand")
+    for key in [k for k in g if k.startswith("x_")]:
+        _, S, T = key.split("_")
+        x = g[key].to(dev)
+        y = repeat_expand(x, int(T))
+        assert torch.equal(y.cpu(), g[f"y_{S}_{T}"]), key                                   # pure gather: bit-exact
+        assert torch.equal(repeat_expand(x[0], int(T)).cpu(), g[f"y_{S}_{T}"][0])
+        assert torch.equal(repeat_expand(x[None], int(T))[0].cpu(), g[f"y_{S}_{T}"])
+    with pytest.raises(NotImplementedError):
+        repeat_expand(x, 5, mode="linear")
+    T = int(g["T"])
+    m = _frontend(dev, features_ref.seeded_frontend_state(11))
+    ccf, f0s, ids = g["contents_cf"].to(dev), g["f0_src"].to(dev), torch.as_tensor(g["ids"]).to(dev)
+    lens = torch.full((ccf.shape[0],), T, device=dev)
+    out = m.forward_features(ids, ccf, lens, T, pitches=f0s, contents_channel_first=True, expand_to=T)["features"]
+    assert out.shape == g["features"].shape and rel_err(out.cpu(), g["features"]) < 1e-5
+    # frames-first source layout, and the unfused route through repeat_expand
+    out2 = m.forward_features(ids, ccf.transpose(1, 2).contiguous(), lens, T, pitches=f0s, expand_to=T)["features"]
+    assert torch.equal(out2, out)
+    text = repeat_expand(ccf, T).transpose(1, 2).contiguous()
+    out3 = m.forward_features(ids, text, lens, T, pitches=repeat_expand(f0s, T))["features"]
+    assert torch.equal(out3, out)
+    with pytest.raises(ValueError):   # without expand_to a pitch track of another length is a shape error, as in the reference
+        m.forward_features(ids, text, lens, T, pitches=f0s)
+
+
 def test_svc_inference_chain_features_to_mel(dev):
     """tools/diffusion/inference.py:131-159 as one call: forward_features -> diffusion, vs the oracle chain on CPU."""
     from oracle import features_ref, sampler_ref
@@ -580,6 +610,58 @@ def test_pipeline_ragged_utterances_sharded_and_batched(dev):
                     wref = nsf_hifigan_ref.spec2wav(gsd, h, ref[b, :n].T.contiguous(), f0s[i], ri_all[i:i + 1], sn_all[i:i + 1, :n * 256],
                                                     use_natural_log=False)
                     assert abs_err(seen[i][1], wref) < 5e-4, i   # vocoder fed with the HIP mel (<=1e-3 rel off the oracle's)
+
+
+def test_segment_loop_of_the_caller_extractor_frames_to_pasted_waveform(dev):
+    """SVCInference.inference's segment loop (tools/diffusion/inference.py:336-376) via segments.convert_segments: extractor-rate
+    contents + f0 per segment -> fused expand + front end -> sampler -> vocoder -> paste.  Oracle: the same chain one segment
+    at a time with the CPU restatements, pasted with the reference's slice assignment."""
+    from fish_diffusion_amd import segments as S
+    from oracle import features_ref, nsf_hifigan_ref, sampler_ref
+    sd_f, sd_w = features_ref.seeded_frontend_state(11), wavenet_sd(WN_SMALL, 101)
+    m = _frontend(dev, sd_f)
+    m.diffusion.denoise_fn.load_state_dict(sd_w, strict=True)
+    h = dict(nsf_hifigan_ref.CONFIG_V1)
+    gsd = nsf_hifigan_ref.seeded_generator_state(78, h)
+    voc = _vocoder(h, gsd, dev, use_natural_log=False)
+    total = 40000
+    segs = [(1000, 1000 + 512 * 20 + 100), (15000, 15000 + 512 * 13), (30000, 30000 + 512 * 20 + 7), (38000, 38000 + 300)]   # last: < 1 frame
+    g = torch.Generator().manual_seed(21)
+    S_ext = [10, 7, 11, 1]                                           # extractor frames per segment (50 Hz-like)
+    contents = [torch.randn(256, n, generator=g) for n in S_ext]     # [Din, S], inference.py:113
+    f0 = [100 + 300 * torch.rand(n, generator=g) for n in (20, 5, 20, 1)]
+    f0[1][:] = 0.0                                                   # all-unvoiced segment: stays silent (:108-109)
+    spk = torch.tensor([3])
+    mel_lens = [(e - s) // 512 for s, e in segs]
+    x_all = torch.randn(4, 128, max(mel_lens), generator=g)
+    ri_all = torch.rand(4, 9, generator=g)
+    ri_all[:, 0] = 0
+    sn_all = torch.randn(4, max(mel_lens) * 512, 9, generator=g)
+    live = [0, 2]                                                    # segments that reach the sampler (convert_segments' own indexing)
+
+    def x_init_fn(idx, M, T):
+        return torch.stack([x_all[live[i], :, :T] for i in idx]).to(dev)
+
+    def noise_fn(idx, L):
+        return torch.stack([ri_all[live[i]] for i in idx]).to(dev), torch.stack([sn_all[live[i], :L] for i in idx]).to(dev)
+
+    out = S.convert_segments(m, voc, total, segs, [c.to(dev) for c in contents], [p.to(dev) for p in f0], spk.to(dev), pitch_adjust=2.0,
+                             max_batch=1, sampler_interval=200, x_init_fn=x_init_fn, source_noise_fn=noise_fn)
+    assert out.shape == (total,)
+    ref = np.zeros(total, np.float32)
+    den = _oracle_den(sd_w, WN_SMALL)
+    for i in live:
+        T = mel_lens[i]
+        with torch.no_grad():
+            text = features_ref.repeat_expand(contents[i], T).T[None]
+            p = features_ref.repeat_expand(f0[i], T)[None] * 2 ** (2.0 / 12)
+            feats = features_ref.forward_features(sd_f, text, spk, p)["features"]
+            mel = sampler_ref.diffusion_sample(den, feats, x_init=x_all[i:i + 1, :, :T], sampler_interval=200)
+            wav = nsf_hifigan_ref.spec2wav(gsd, h, mel[0].T.contiguous(), p[0], ri_all[i:i + 1], sn_all[i:i + 1, :T * 512],
+                                           use_natural_log=False).numpy()
+        ref[segs[i][0]:segs[i][0] + wav.shape[-1]] = wav[:total - segs[i][0]]
+    assert abs_err(out.cpu(), torch.from_numpy(ref)) < 5e-4
+    assert float(out[segs[1][0]:segs[1][1]].abs().max()) == 0.0 and float(out[:1000].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ RefineGAN (8f row 2)

@@ -176,3 +176,18 @@ def test_sampler_over_convnext_oracle_matches_reference(name):
                                            sampler_interval=int(g["interval"]), predictor=name.split("_")[0],
                                            step_noise=g["step_noise"], x_masks=m, cond_masks=m)
     assert rel_err(mel, g["mel"]) < 1e-4
+
+
+def test_repeat_expand_and_expanded_frontend_oracle_matches_reference():
+    from oracle import features_ref
+    g = load("frontend_expand")
+    for key in [k for k in g if k.startswith("x_")]:
+        _, S, T = key.split("_")
+        assert torch.equal(features_ref.repeat_expand(g[key], int(T)), g[f"y_{S}_{T}"])
+    T = int(g["T"])
+    sd = features_ref.seeded_frontend_state(11)
+    assert sha1_state(sd) == str(g["sha1"])
+    text = torch.stack([features_ref.repeat_expand(c, T).T for c in g["contents_cf"]])
+    f0 = torch.stack([features_ref.repeat_expand(p, T) for p in g["f0_src"]])
+    out = features_ref.forward_features(sd, text, torch.as_tensor(g["ids"]), f0)["features"]
+    assert rel_err(out, g["features"]) < 1e-6
