@@ -29,6 +29,10 @@ class ConvNextDesc(C.Structure):
                                        "cross_attention")]
 
 
+class TfdecDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("mel_channels", "dim", "mlp_factor", "condition_dim", "num_layers", "n_positions")]
+
+
 class NsfDesc(C.Structure):
     _fields_ = [("num_mels", C.c_int), ("upsample_initial_channel", C.c_int), ("n_stages", C.c_int),
                 ("upsample_rates", C.c_int * MAX_STAGES), ("upsample_kernel_sizes", C.c_int * MAX_STAGES),
@@ -79,6 +83,12 @@ _SIGS = {
     "fdx_convnext_attach": (C.c_int, [_P, C.POINTER(ConvNextDesc), _P, C.c_size_t]),
     "fdx_convnext_prepare": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "fdx_convnext_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
+    "fdx_tfdec_num_weights": (C.c_int, [C.POINTER(TfdecDesc)]),
+    "fdx_tfdec_packed_bytes": (C.c_int, [C.POINTER(TfdecDesc), C.POINTER(C.c_size_t)]),
+    "fdx_tfdec_pack": (C.c_int, [C.POINTER(TfdecDesc), C.POINTER(_P), C.c_int, _P, C.c_size_t]),
+    "fdx_tfdec_attach": (C.c_int, [_P, C.POINTER(TfdecDesc), _P, C.c_size_t]),
+    "fdx_tfdec_prepare": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "fdx_tfdec_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
     "fdx_sampler_run": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_uint64, _P, _P]),
     "fdx_denorm_spec": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "fdx_randn": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P]),

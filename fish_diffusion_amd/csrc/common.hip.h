@@ -124,7 +124,8 @@ struct fdx_ctx {
   void* rg = nullptr;
   // ---- convnext denoiser (opaque: convnext.hip owns the type); den_kind says which denoiser the sampler loop drives
   void* cn = nullptr;
-  int den_kind = 0;      // 0 = WaveNet (wavenet.hip), 1 = ConvNext (convnext.hip)
+  void* td = nullptr;    // transformer-decoder denoiser (tfdec.hip)
+  int den_kind = 0;      // 0 = WaveNet (wavenet.hip), 1 = ConvNext (convnext.hip), 2 = TransformerDecoder (tfdec.hip)
   int den_M = 0;         // mel channels of the prepared denoiser
 
   // ---- mel
@@ -146,6 +147,10 @@ int fdx_cn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s);
 int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
                         hipStream_t s, bool unmasked_cond);
 int fdx_cn_plms_setup(fdx_ctx* h, hipStream_t s);   // PLMS + cond_masks: projections of the unmasked condition
+void fdx_td_free(void* p);   // tfdec.hip, same hooks
+int fdx_td_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s);
+int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
+                        hipStream_t s, bool unmasked_cond);
 
 namespace fdx {
 

@@ -234,7 +234,7 @@ struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) +
     Pre p{f2{0.f, 0.f}, 0.f, 0.f, false, false};
     if (row >= M) return p;
     p.old = ld2(X + b * bs + (long)row * ld + t, two);
-    p.bias = bias[row]; p.gamma = gamma[row];
+    p.bias = bias[row]; p.gamma = gamma ? gamma[row] : 1.f;   // gamma == null: plain residual add x + (v + bias)
     if (mask) { p.m0 = mask[(long)b * mask_ld + t] != 0; p.m1 = two && mask[(long)b * mask_ld + t + 1] != 0; }
     return p;
   }

@@ -44,6 +44,7 @@ extern "C" int fdx_destroy(fdx_handle h) {
   (void)hipSetDevice(h->device);
   if (h->rg) fdx_rg_free(h->rg);
   if (h->cn) fdx_cn_free(h->cn);
+  if (h->td) fdx_td_free(h->td);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   for (auto e : h->prof.start) (void)hipEventDestroy(e);

@@ -424,6 +424,7 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
   auto model = [&](const float* xin, int col, bool masked) {
     // the one unmasked call of PLMS uses the conditioner slab of the UNMASKED conditioner (built in the set-up phase)
     if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked);
+    if (h->den_kind == 2) return fdx_td_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked);
     const float* P = (!masked && h->cond_masked) ? h->P2.f() : nullptr;
     return wn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, P);
   };
@@ -524,7 +525,10 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   if (kind == FDX_SAMPLER_PLMS) ts.push_back(tab[1]);   // t_prev of the first step (diffusion.py:285)
   FDX_HIP(h, h->tdev.ensure(ts.size() * 4, false, s));
   FDX_HIP(h, hipMemcpyAsync(h->tdev.p, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, s));
-  if (int rc = (h->den_kind == 1 ? fdx_cn_embed(h, h->tdev.f(), (int)ts.size(), s) : wn_embed(h, h->tdev.f(), (int)ts.size(), s))) return rc;
+  if (int rc = (h->den_kind == 1   ? fdx_cn_embed(h, h->tdev.f(), (int)ts.size(), s)
+                : h->den_kind == 2 ? fdx_td_embed(h, h->tdev.f(), (int)ts.size(), s)
+                                   : wn_embed(h, h->tdev.f(), (int)ts.size(), s)))
+    return rc;
 
   FDX_HIP(h, h->sx.ensure(bytes, true, s));
   if (kind == FDX_SAMPLER_UNIPC) {
@@ -565,7 +569,7 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
     uint64_t key = fnv1a(tab, (size_t)n_rows * FDX_ROW * sizeof(float));
     const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
                               (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, g_alloc_generation,
-                              (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn};
+                              (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn, (uint64_t)(uintptr_t)h->td};
     key = fnv1a(parts, sizeof parts, key);
     fdx_ctx::GraphEntry* hit = nullptr;
     for (auto& g : h->graphs) if (g.key == key) hit = &g;

@@ -53,6 +53,7 @@ def install(override: bool = True) -> bool:
     from .diffusion import GaussianDiffusion
     from .nsf_hifigan import NsfHifiGAN
     from .convnext import ConvNext
+    from .tfdec import TransformerDecoderDenoiser
     from .wavenet import WaveNet
 
     try:  # pragma: no cover - needs the reference package + mmengine
@@ -60,7 +61,8 @@ def install(override: bool = True) -> bool:
         from fish_diffusion.modules.vocoders.builder import VOCODERS as R_VOC
     except Exception:
         return False
-    for reg, base, cls in ((R_DEN, "WaveNetDenoiser", WaveNet), (R_DEN, "ConvNextDenoiser", ConvNext), (R_DIF, "GaussianDiffusion", GaussianDiffusion),
+    for reg, base, cls in ((R_DEN, "WaveNetDenoiser", WaveNet), (R_DEN, "ConvNextDenoiser", ConvNext),
+                           (R_DEN, "TransformerDecoderDenoiser", TransformerDecoderDenoiser), (R_DIF, "GaussianDiffusion", GaussianDiffusion),
                            (R_VOC, "NsfHifiGAN", NsfHifiGAN)):
         reg.register_module(name=base + "MI355X", module=cls, force=True)
         if override:

@@ -86,6 +86,7 @@ class HipDenoiser(nn.Module):
     # ------------------------------------------------------------------ weights
     def _params(self):
         sd = dict(self.named_parameters())
+        sd.update(self.named_buffers())          # e.g. the transformer denoiser's positional_embedding
         return [sd[k] for k in self._keys]
 
     def _signature(self):

@@ -123,6 +123,31 @@ int fdx_convnext_forward(fdx_handle h, const float* x, const float* t, int n_t, 
                          float* eps, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Transformer-decoder denoiser -- replaces fish_diffusion/modules/convnext.py:263-379
+ * (class TransformerDecoderDenoiser: 1x1-conv projections around num_layers x nn.TransformerDecoderLayer,
+ * 8 heads, post-norm, GELU), DENOISERS "TransformerDecoderDenoiser" (diffusions/builder.py:13).
+ * Same call contract; the conditioner must have as many frames as the mel (how GaussianDiffusion calls it).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fdx_tfdec_desc {
+  int mel_channels;   /* 128; multiple of 8 */
+  int dim;            /* 512 (also 256, 128): 8 heads of dim/8 channels */
+  int mlp_factor;     /* 4 */
+  int condition_dim;  /* 256; multiple of 8 */
+  int num_layers;     /* 12 */
+  int n_positions;    /* 4096: rows of the positional_embedding buffer (convnext.py:317) */
+} fdx_tfdec_desc;
+/* Canonical tensor order = the module's state_dict order: position_scale_query, position_scale_key, positional_embedding,
+ * input_projection.{0,2}.*, diffusion_embedding.{1,3}.*, condition_projection.{0,2}.*, per layer self_attn.{in_proj_weight,
+ * in_proj_bias, out_proj.weight, out_proj.bias}, multihead_attn.(same), linear1.*, linear2.*, norm1.*, norm2.*, norm3.*;
+ * output_projection.{0,2}.*. */
+int fdx_tfdec_num_weights(const fdx_tfdec_desc* d);
+int fdx_tfdec_packed_bytes(const fdx_tfdec_desc* d, size_t* bytes);
+int fdx_tfdec_pack(const fdx_tfdec_desc* d, const float* const* host_weights, int n_weights, void* host_packed, size_t bytes);
+int fdx_tfdec_attach(fdx_handle h, const fdx_tfdec_desc* d, const void* dev_packed, size_t bytes);
+int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask, fdx_stream s);
+int fdx_tfdec_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask, float* eps, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Sampler loop -- replaces GaussianDiffusion.forward's loop, diffusion.py:234-311, and the three
  * predictors (noise_predictor.py:19-222, uni_pc.py:583-818).  The per-step scalars are computed by
  * the host (fish_diffusion_amd/schedule.py mirrors the reference's fp32 arithmetic) and passed as a

@@ -173,6 +173,7 @@ def load():
         hifisinger_methods=_hifisinger_methods,
         WaveNet=wavenet.WaveNet,
         ConvNext=convnext.ConvNext,
+        TransformerDecoderDenoiser=convnext.TransformerDecoderDenoiser,
         GaussianDiffusion=diffusion.GaussianDiffusion,
         DENOISERS=diffusion.DENOISERS,
         DIFFUSIONS=diffusion.DIFFUSIONS,

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
-from oracle import _ref_import, convnext_ref, features_ref, mel_ref, nsf_hifigan_ref, refinegan_ref, sampler_ref, wavenet_ref  # noqa: E402
+from oracle import _ref_import, convnext_ref, features_ref, tfdec_ref, mel_ref, nsf_hifigan_ref, refinegan_ref, sampler_ref, wavenet_ref  # noqa: E402
 
 
 def sha1_of(tensors) -> str:
@@ -198,6 +198,66 @@ def golden_frontend_expand(R):
     arrays.update(contents_cf=contents_cf, f0_src=f0_src, ids=ids, features=ref["features"], T=np.int64(T),
                   sha1=np.array(state_sha1(sd)))
     save("frontend_expand", **arrays)
+
+
+TD_SMALL = dict(mel_channels=128, dim=128, mlp_factor=2, condition_dim=256, num_layers=2)
+TD_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=12)   # convnext.py:264-271 defaults
+
+
+@torch.no_grad()
+def golden_tfdec(R):
+    """TransformerDecoderDenoiser: forward + the sampler loop driving it, outputs from the real reference
+    classes.  The restatement is asserted CLOSE (3e-6 abs), not equal: torch's fused attention groups its sums differently."""
+    print("transformer-decoder denoiser")
+    close = lambda a, b: float((a - b).abs().max()) <= 3e-6 * max(1.0, float(b.abs().max()))
+
+    def oracle_den(sd, cfg):
+        return lambda x, t, c, xm, cm: tfdec_ref.tfdec_forward(sd, x, t, c, xm, cm, num_layers=cfg["num_layers"])
+
+    for tag, cfg, seed, (B, T) in (("small", TD_SMALL, 501, (2, 50)), ("full", TD_FULL, 5432, (2, 96))):
+        sd = tfdec_ref.seeded_state(seed, **cfg)
+        net = R["TransformerDecoderDenoiser"](**cfg).eval()
+        net.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(B, 128, T, generator=g)
+        cond = torch.randn(B, 256, T, generator=g)
+        t = torch.tensor([37.0, 912.5])[:B]
+        masks = torch.zeros(B, T, dtype=torch.bool)
+        masks[1, T - T // 4:] = True
+        eps = net(x, t, cond)
+        eps_masked = net(x, t, cond, x_masks=masks, cond_masks=masks)
+        eps_long = net(x, torch.tensor([400], dtype=torch.long), cond)
+        den = oracle_den(sd, cfg)
+        assert close(den(x, t, cond, None, None), eps), "oracle TransformerDecoderDenoiser != reference"
+        assert close(den(x, t, cond, masks, masks), eps_masked), "oracle TransformerDecoderDenoiser (masked) != reference"
+        # (the sin/cos table is recomputed by whoever regenerates the weights: a different host CPU's vectorised sin / cos may
+        # differ in the last bit, so it is left out of the fingerprint)
+        arrays = dict(x=x, cond=cond, t=t, masks=masks, eps=eps, eps_masked=eps_masked, eps_long=eps_long, seed=np.int64(seed),
+                      weights_sha1=np.array(state_sha1({k: v for k, v in sd.items() if k != "positional_embedding"})))
+        save(f"tfdec_{tag}", **arrays)
+
+    sd = tfdec_ref.seeded_state(501, **TD_SMALL)
+    diff = R["GaussianDiffusion"](denoiser=dict(type="TransformerDecoderDenoiser", **TD_SMALL), spec_min=[-5], spec_max=[0]).eval()
+    diff.denoise_fn.load_state_dict(sd, strict=True)
+    den = oracle_den(sd, TD_SMALL)
+    B, T = 2, 40
+    g = torch.Generator().manual_seed(19)
+    feats = torch.randn(B, T, 256, generator=g)
+    masks = torch.zeros(B, T, dtype=torch.bool)
+    masks[1, 30:] = True
+    for pred, interval in (("unipc", 50), ("plms", 50), ("naive", 100)):
+        seed = 5000 + interval
+        torch.manual_seed(seed)
+        ref = diff(feats, sampler_interval=interval, noise_predictor=pred, x_masks=masks, cond_masks=masks)
+        torch.manual_seed(seed)
+        x_init = torch.randn(B, 128, T)
+        n = len(range(0, 1000, interval))
+        step_noise = torch.stack([torch.randn(B, 128, T) for _ in range(n)]) if pred == "naive" else torch.zeros(0)
+        mine = sampler_ref.diffusion_sample(den, feats, x_init=x_init, sampler_interval=interval, predictor=pred,
+                                            step_noise=step_noise, x_masks=masks, cond_masks=masks)
+        assert float((mine - ref).abs().max()) < 1e-3 * float(ref.abs().max()), f"oracle sampler over tfdec {pred} != reference"
+        save(f"tfdec_sampler_small_{pred}_i{interval}", features=feats, masks=masks, x_init=x_init, step_noise=step_noise, mel=ref,
+             interval=np.int64(interval))
 
 
 @torch.no_grad()
@@ -500,6 +560,7 @@ def main():
 
     golden_convnext(R)
     golden_frontend_expand(R)
+    golden_tfdec(R)
 
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
@@ -507,7 +568,7 @@ def main():
 
 
 if __name__ == "__main__":
-    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand}
+    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec}
     if len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(os.cpu_count())

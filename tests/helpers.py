@@ -17,6 +17,8 @@ WN_SMALL = dict(mel_channels=128, d_encoder=256, residual_channels=64, residual_
 WN_FULL = dict(mel_channels=128, d_encoder=256, residual_channels=512, residual_layers=20, dilation_cycle=4, use_linear_bias=True)
 CN_SMALL = dict(mel_channels=128, dim=64, mlp_factor=2, condition_dim=256, num_layers=4, dilation_cycle=4)
 CN_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=20, dilation_cycle=4)
+TD_SMALL = dict(mel_channels=128, dim=128, mlp_factor=2, condition_dim=256, num_layers=2)
+TD_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=12)
 
 
 def load(name):
@@ -55,6 +57,16 @@ def convnext_den(sd, cfg):
     from oracle import convnext_ref
     return lambda x, t, c, xm, cm: convnext_ref.convnext_forward(sd, x, t, c, xm, cm, num_layers=cfg["num_layers"],
                                                                  dilation_cycle=cfg["dilation_cycle"])
+
+
+def tfdec_sd(cfg, seed):
+    from oracle import tfdec_ref
+    return tfdec_ref.seeded_state(seed, **cfg)
+
+
+def tfdec_den(sd, cfg):
+    from oracle import tfdec_ref
+    return lambda x, t, c, xm, cm: tfdec_ref.tfdec_forward(sd, x, t, c, xm, cm, num_layers=cfg["num_layers"])
 
 
 def synth_f0(T, frame_rate=44100 / 512):

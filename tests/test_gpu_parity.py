@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import CN_FULL, CN_SMALL, WN_FULL, WN_SMALL, abs_err, convnext_den, convnext_sd, load, rel_err, sha1_state, synth_f0, wavenet_sd
+from tests.helpers import CN_FULL, CN_SMALL, TD_FULL, TD_SMALL, tfdec_den, tfdec_sd, WN_FULL, WN_SMALL, abs_err, convnext_den, convnext_sd, load, rel_err, sha1_state, synth_f0, wavenet_sd
 
 pytestmark = pytest.mark.gpu
 
@@ -874,3 +874,70 @@ def test_convnext_full_net_c1_and_denoiser_switching(dev):
     assert rel_err(mel_w.cpu(), gw["mel"]) < MEL_REL
     mel2 = diff(g["features"].to(dev), sampler_interval=int(g["interval"]), x_init=g["x_init"].to(dev))
     assert torch.equal(mel2, mel)
+
+
+# ------------------------------------------------------------------------------------------------ TransformerDecoderDenoiser
+def _tfdec(cfg, sd, dev):
+    from fish_diffusion_amd import DENOISERS
+    net = DENOISERS.build(dict(type="TransformerDecoderDenoiser", **cfg))
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag,cfg", [("small", TD_SMALL), ("full", TD_FULL)])
+def test_tfdec_forward_matches_reference_golden(dev, tag, cfg):
+    g = load(f"tfdec_{tag}")
+    sd = tfdec_sd(cfg, int(g["seed"]))
+    assert sha1_state({k: v for k, v in sd.items() if k != "positional_embedding"}) == str(g["weights_sha1"])
+    net = _tfdec(cfg, sd, dev)
+    x, cond, t, m = g["x"].to(dev), g["cond"].to(dev), g["t"].to(dev), g["masks"].bool().to(dev)
+    eps = net(x, t, cond)
+    print(f"tfdec {tag}: eps rel err {rel_err(eps.cpu(), g['eps']):.3e}")
+    assert rel_err(eps.cpu(), g["eps"]) < 2e-5
+    eps_m = net(x, t, cond, x_masks=m, cond_masks=m)
+    assert rel_err(eps_m.cpu(), g["eps_masked"]) < 2e-5
+    assert (eps_m[1, :, g["masks"][1].bool()] == 0).all()
+    assert rel_err(net(x, torch.tensor([400], device=dev), cond).cpu(), g["eps_long"]) < 2e-5
+    with pytest.raises(AssertionError):
+        net(x[:, None], t, cond)                                   # no 4-D form in this denoiser (convnext.py:341)
+
+
+def test_tfdec_ragged_lengths_and_head_sizes_vs_oracle(dev):
+    """Key tiles that do not fill 64, fewer key tiles than waves, more than 4 key tiles, heads of 16 / 32 / 64 channels, masks on one
+    side only."""
+    for cfg, seed in ((TD_SMALL, 501), (dict(mel_channels=128, dim=256, mlp_factor=2, condition_dim=256, num_layers=2), 502),
+                      (dict(mel_channels=128, dim=512, mlp_factor=1, condition_dim=256, num_layers=1), 503)):
+        sd = tfdec_sd(cfg, seed)
+        net = _tfdec(cfg, sd, dev)
+        den = tfdec_den(sd, cfg)
+        for B, T in ((1, 1), (3, 7), (2, 65), (1, 300), (2, 700)):
+            g = torch.Generator().manual_seed(T)
+            x, cond = torch.randn(B, 128, T, generator=g), torch.randn(B, 256, T, generator=g)
+            t = torch.rand(B, generator=g) * 999
+            xm = torch.zeros(B, T, dtype=torch.bool)
+            xm[-1, T - T // 3:] = True
+            with torch.no_grad():
+                ref = den(x, t, cond, None, None)
+                ref_x = den(x, t, cond, xm, None)
+                ref_c = den(x, t, cond, None, xm)
+            dx, dt, dc = x.to(dev), t.to(dev), cond.to(dev)
+            assert rel_err(net(dx, dt, dc).cpu(), ref) < 2e-5, (cfg["dim"], B, T)
+            assert rel_err(net(dx, dt, dc, x_masks=xm.to(dev)).cpu(), ref_x) < 2e-5, (cfg["dim"], B, T)
+            assert rel_err(net(dx, dt, dc, cond_masks=xm.to(dev)).cpu(), ref_c) < 2e-5, (cfg["dim"], B, T)
+
+
+@pytest.mark.parametrize("name", ["unipc_i50", "plms_i50", "naive_i100"])
+def test_sampler_over_tfdec_matches_reference_golden(dev, name):
+    from fish_diffusion_amd import DIFFUSIONS
+    g = load(f"tfdec_sampler_small_{name}")
+    diff = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="TransformerDecoderDenoiser", **TD_SMALL), spec_min=[-5],
+                                 spec_max=[0]))
+    diff.denoise_fn.load_state_dict(tfdec_sd(TD_SMALL, 501), strict=True)
+    diff = diff.to(dev).eval()
+    pred = name.split("_")[0]
+    m = g["masks"].bool().to(dev)
+    sn = g["step_noise"].to(dev) if pred == "naive" else None
+    for _ in range(2):   # second run replays the cached hipGraph
+        mel = diff(g["features"].to(dev), sampler_interval=int(g["interval"]), noise_predictor=pred, x_masks=m, cond_masks=m,
+                   x_init=g["x_init"].to(dev), step_noise=sn)
+        assert rel_err(mel.cpu(), g["mel"]) < MEL_REL, name

@@ -426,3 +426,56 @@ def test_convnext_contract_and_bad_configs(lib):
     assert "denoise_fn.residual_layers.1.pwconv2.weight" in d.state_dict()
     with pytest.raises(RuntimeError):                       # CPU tensors: no fallback
         net(torch.zeros(1, 16, 8), torch.zeros(1), torch.zeros(1, 24, 8))
+
+
+def test_tfdec_contract_and_packing(lib):
+    """State-dict contract of the TransformerDecoderDenoiser mirror, bad configs, and the packed arena: the cross-attention
+    in_proj is split into the query rows and the key/value rows; checked through the MFMA lane-level emulation."""
+    from fish_diffusion_amd import DENOISERS, DIFFUSIONS, TransformerDecoderDenoiser
+    from oracle import tfdec_ref
+    cfg = dict(mel_channels=16, dim=128, mlp_factor=2, condition_dim=24, num_layers=2)
+    net = DENOISERS.build(dict(type="TransformerDecoderDenoiser", **cfg))
+    assert isinstance(net, TransformerDecoderDenoiser)
+    assert list(net.state_dict().keys()) == [k for k, _ in tfdec_ref.param_shapes(**cfg)]
+    assert torch.equal(net.positional_embedding, tfdec_ref.positional_embedding(128))
+    with pytest.raises(ValueError):
+        TransformerDecoderDenoiser(dim=96)                  # 8 heads of 12: not built (16 / 32 / 64 only)
+    d = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="TransformerDecoderDenoiser", dim=128, num_layers=1),
+                              spec_min=[-5], spec_max=[0]))
+    assert "denoise_fn.layers.0.multihead_attn.in_proj_weight" in d.state_dict()
+    with pytest.raises(RuntimeError):                       # CPU tensors: no fallback
+        net(torch.zeros(1, 16, 8), torch.zeros(1), torch.zeros(1, 24, 8))
+    sd = tfdec_ref.seeded_state(3, **cfg)
+    net.load_state_dict(sd, strict=True)
+    arena = lib.pack_on_host(net._desc, net._params(), "tfdec")
+    D, H, M, E = 128, 256, 16, 24
+    r64 = lambda n: (n + 63) // 64 * 64
+    cur = 128 + r64(4096 * D)
+    assert arena[0] == sd["position_scale_query"][0] and arena[64] == sd["position_scale_key"][0]
+    np.testing.assert_array_equal(arena[128:128 + 4096 * D].reshape(4096, D), sd["positional_embedding"].numpy())
+
+    def plan(rows, cin, RB):
+        nonlocal cur
+        mt = (rows + 32 * RB - 1) // (32 * RB)
+        w = mt * ((cin + 7) // 8) * RB * 64 * 4
+        o = dict(w=cur, b=cur + w, mt=mt, cin8=(cin + 7) // 8, RB=RB, rows=rows)
+        cur += w + r64(rows)
+        return o
+    for rows, cin, RB in ((H, M, 2), (D, H, 1), (H, D, 2), (D, H, 2), (H, E, 2), (D, H, 1)):   # in0 in2 emb1 emb3 cond0 cond2
+        plan(rows, cin, RB)
+    sa_in, sa_out, ca_q, ca_kv = plan(3 * D, D, 2), plan(D, D, 1), plan(D, D, 1), plan(2 * D, D, 2)
+    g = torch.Generator().manual_seed(0)
+    T, halo = 9, 32
+    xv = torch.randn(D, T, generator=g)
+    Xp = np.zeros((D, halo + 64 + halo), np.float32)
+    Xp[:, halo:halo + T] = xv.numpy()
+
+    def run(o):
+        acc = emulate_convgemm(arena[o["w"]:o["b"]], Xp, n_mtiles=o["mt"], RB=o["RB"], cin8=o["cin8"], taps=1, shift0=0, dshift=0, T=T)
+        full = np.concatenate([acc[(mt, rb)] for mt in range(o["mt"]) for rb in range(o["RB"])])[:o["rows"]]
+        return full + arena[o["b"]:o["b"] + o["rows"]][:, None]
+    W, b = sd["layers.0.multihead_attn.in_proj_weight"], sd["layers.0.multihead_attn.in_proj_bias"]
+    np.testing.assert_allclose(run(ca_q), (W[:D] @ xv + b[:D, None]).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(run(ca_kv), (W[D:] @ xv + b[D:, None]).numpy(), rtol=1e-4, atol=1e-5)
+    Ws, bs = sd["layers.0.self_attn.in_proj_weight"], sd["layers.0.self_attn.in_proj_bias"]
+    np.testing.assert_allclose(run(sa_in), (Ws @ xv + bs[:, None]).numpy(), rtol=1e-4, atol=1e-5)

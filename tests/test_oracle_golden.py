@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import mel_ref, nsf_hifigan_ref, sampler_ref, wavenet_ref
-from tests.helpers import CN_FULL, CN_SMALL, WN_FULL, WN_SMALL, convnext_den, convnext_sd, load, rel_err, abs_err, sha1_state, wavenet_sd
+from tests.helpers import CN_FULL, CN_SMALL, TD_FULL, TD_SMALL, tfdec_den, tfdec_sd, WN_FULL, WN_SMALL, convnext_den, convnext_sd, load, rel_err, abs_err, sha1_state, wavenet_sd
 
 torch.set_num_threads(8)
 
@@ -191,3 +191,29 @@ def test_repeat_expand_and_expanded_frontend_oracle_matches_reference():
     f0 = torch.stack([features_ref.repeat_expand(p, T) for p in g["f0_src"]])
     out = features_ref.forward_features(sd, text, torch.as_tensor(g["ids"]), f0)["features"]
     assert rel_err(out, g["features"]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ TransformerDecoderDenoiser
+@pytest.mark.parametrize("tag,cfg", [("small", TD_SMALL), ("full", TD_FULL)])
+def test_tfdec_oracle_matches_reference(tag, cfg):
+    g = load(f"tfdec_{tag}")
+    sd = tfdec_sd(cfg, int(g["seed"]))
+    assert sha1_state({k: v for k, v in sd.items() if k != "positional_embedding"}) == str(g["weights_sha1"]), "seeded weights drifted"
+    den = tfdec_den(sd, cfg)
+    m = g["masks"].bool()
+    with torch.no_grad():
+        assert rel_err(den(g["x"], g["t"], g["cond"], None, None), g["eps"]) < 1e-5
+        assert rel_err(den(g["x"], g["t"], g["cond"], m, m), g["eps_masked"]) < 1e-5
+        assert rel_err(den(g["x"], torch.tensor([400]), g["cond"], None, None), g["eps_long"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["unipc_i50", "plms_i50", "naive_i100"])
+def test_sampler_over_tfdec_oracle_matches_reference(name):
+    g = load(f"tfdec_sampler_small_{name}")
+    sd = tfdec_sd(TD_SMALL, 501)
+    m = g["masks"].bool()
+    with torch.no_grad():
+        mel = sampler_ref.diffusion_sample(tfdec_den(sd, TD_SMALL), g["features"], x_init=g["x_init"],
+                                           sampler_interval=int(g["interval"]), predictor=name.split("_")[0],
+                                           step_noise=g["step_noise"], x_masks=m, cond_masks=m)
+    assert rel_err(mel, g["mel"]) < 1e-4
