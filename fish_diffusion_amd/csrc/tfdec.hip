@@ -99,8 +99,9 @@ __global__ void k_td_mem(float* __restrict__ mem, const float* __restrict__ C0, 
   mem[o] = (mask && mask[(long)b * T + t]) ? 0.f : v;
 }
 
-// LayerNorm over channels, in place: 16 frames x 16 channel groups per workgroup, values in registers, two-pass statistics
-constexpr int kLnFr = 16, kLnCg = 16, kLnCpt = 32;
+// LayerNorm over channels, in place: 8 frames x 32 channel groups per workgroup (T/8 workgroups: latency-bound, wants many),
+// values in registers, two-pass statistics
+constexpr int kLnFr = 8, kLnCg = 32, kLnCpt = 16;
 __global__ __launch_bounds__(256) void k_td_layernorm(float* __restrict__ X, long bs, int ld, const float* __restrict__ w,
                                                       const float* __restrict__ bia, int D, int T, float eps) {
   __shared__ float red[kLnCg][kLnFr];
@@ -148,37 +149,40 @@ struct AttnArgs {
   float scale;                            // 1 / sqrt(DH)
 };
 
-template <int DH>
+// NQ = 32-query blocks per workgroup: 2 (64 queries) when that already fills the chip, 1 to double the workgroup count
+template <int DH, int NQ>
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   constexpr int KS = DH / 2;                 // MFMA k-steps of the score product
   constexpr int RBD = (DH + 31) / 32;        // 32-row blocks of O^T
   constexpr int VLD = 65;                    // padded row of the staged V tile
-  constexpr int NBLK = RBD * 2;
-  constexpr int LDS_F = (4 * DH * VLD > 4 * NBLK * 16 * 64 + 4 * 2 * 2 * 64) ? 4 * DH * VLD : 4 * NBLK * 16 * 64 + 4 * 2 * 2 * 64;
+  constexpr int NBLK = RBD * NQ;
+  constexpr int LDS_F = (4 * DH * VLD > 4 * NBLK * 16 * 64 + 4 * 2 * NQ * 64) ? 4 * DH * VLD : 4 * NBLK * 16 * 64 + 4 * 2 * NQ * 64;
   __shared__ float lds[LDS_F];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, n = lane & 31;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (32 * NQ), h = blockIdx.y, b = blockIdx.z;
   const float* Qh = a.Q + b * a.q_bs + (long)h * DH * a.ldq;
   const float* Kh = a.K + b * a.k_bs + (long)h * DH * a.ldk;
   const float* Vh = a.V + b * a.v_bs + (long)h * DH * a.ldv;
   const float NEG = -__builtin_inff();
 
   // B operand of the score product: this lane's slice of Q, for the whole launch
-  float qreg[KS][2];
+  float qreg[KS][NQ];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) qreg[ks][nb] = Qh[(long)(2 * ks + half) * a.ldq + min(q0 + nb * 32 + n, a.Tq - 1)];
+    for (int nb = 0; nb < NQ; ++nb) qreg[ks][nb] = Qh[(long)(2 * ks + half) * a.ldq + min(q0 + nb * 32 + n, a.Tq - 1)];
 
-  f32x16 o[RBD][2];
+  f32x16 o[RBD][NQ];
 #pragma unroll
   for (int x = 0; x < RBD; ++x)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NQ; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[x][nb][r] = 0.f;
-  float m[2] = {NEG, NEG}, l[2] = {0.f, 0.f};
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int nb = 0; nb < NQ; ++nb) { m[nb] = NEG; l[nb] = 0.f; }
   float* vt = lds + wave * DH * VLD;
 
   const int n_kt = (a.Tk + 63) / 64;
@@ -188,11 +192,11 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 #pragma unroll 8
     for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
     // ---- S^T = K^T Q
-    f32x16 s[2][2];
+    f32x16 s[2][NQ];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int nb = 0; nb < NQ; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[rb][nb][r] = 0.f;
 #pragma unroll
@@ -203,10 +207,12 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) s[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rb], qreg[ks][nb], s[rb][nb], 0, 0, 0);
+        for (int nb = 0; nb < NQ; ++nb) s[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rb], qreg[ks][nb], s[rb][nb], 0, 0, 0);
     }
     // ---- scale, key mask (padding keys and the tile overhang), online softmax over the key axis
-    float mx[2] = {NEG, NEG};
+    float mx[NQ];
+#pragma unroll
+    for (int nb = 0; nb < NQ; ++nb) mx[nb] = NEG;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -214,14 +220,14 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         const int key = k0 + rb * 32 + acc_row(r, half);
         const bool ok = key < a.Tk && !(a.kmask && a.kmask[(long)b * a.Tk + min(key, a.Tk - 1)]);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NQ; ++nb) {
           const float v = ok ? s[rb][nb][r] * a.scale : NEG;
           s[rb][nb][r] = v;
           mx[nb] = fmaxf(mx[nb], v);
         }
       }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NQ; ++nb) {
       mx[nb] = fmaxf(mx[nb], __shfl_xor(mx[nb], 32));
       const float m_new = fmaxf(m[nb], mx[nb]);
       const float m_use = m_new == NEG ? 0.f : m_new;      // every key so far masked: keep exp() finite, all weights 0
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
           const int d = x * 32 + n;
           const float av = d < DH ? vt[d * VLD + kl] : 0.f;
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) o[x][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[rb][nb][r], o[x][nb], 0, 0, 0);
+          for (int nb = 0; nb < NQ; ++nb) o[x][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[rb][nb][r], o[x][nb], 0, 0, 0);
         }
       }
   }
@@ -266,23 +272,23 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 #pragma unroll
   for (int x = 0; x < RBD; ++x)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NQ; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ob[((wave * NBLK + x * 2 + nb) * 16 + r) * 64 + lane] = o[x][nb][r];
+      for (int r = 0; r < 16; ++r) ob[((wave * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] = o[x][nb][r];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    ml[((wave * 2 + 0) * 2 + nb) * 64 + lane] = m[nb];
-    ml[((wave * 2 + 1) * 2 + nb) * 64 + lane] = l[nb];
+  for (int nb = 0; nb < NQ; ++nb) {
+    ml[((wave * 2 + 0) * NQ + nb) * 64 + lane] = m[nb];
+    ml[((wave * 2 + 1) * NQ + nb) * 64 + lane] = l[nb];
   }
   __syncthreads();
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
+  for (int nb = 0; nb < NQ; ++nb) {
     float mw[4], M = NEG, L = 0.f, wg[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { mw[w] = ml[((w * 2 + 0) * 2 + nb) * 64 + lane]; M = fmaxf(M, mw[w]); }
+    for (int w = 0; w < 4; ++w) { mw[w] = ml[((w * 2 + 0) * NQ + nb) * 64 + lane]; M = fmaxf(M, mw[w]); }
     const float M_use = M == NEG ? 0.f : M;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { wg[w] = expf(mw[w] - M_use); L += ml[((w * 2 + 1) * 2 + nb) * 64 + lane] * wg[w]; }
+    for (int w = 0; w < 4; ++w) { wg[w] = expf(mw[w] - M_use); L += ml[((w * 2 + 1) * NQ + nb) * 64 + lane] * wg[w]; }
     const int q = q0 + nb * 32 + n;
     if (q >= a.Tq) continue;
 #pragma unroll
@@ -294,18 +300,24 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         if (d >= DH) continue;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += ob[((w * NBLK + x * 2 + nb) * 16 + r) * 64 + lane] * wg[w];
+        for (int w = 0; w < 4; ++w) acc += ob[((w * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] * wg[w];
         a.O[b * a.o_bs + (long)(h * DH + d) * a.ldo + q] = acc / L;
       }
   }
 }
 
-hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s) {
-  const dim3 grid((a.Tq + 63) / 64, kHeads, B), blk(256);
-  if (DH == 64) hipLaunchKernelGGL(k_attn<64>, grid, blk, 0, s, a);
-  else if (DH == 32) hipLaunchKernelGGL(k_attn<32>, grid, blk, 0, s, a);
-  else hipLaunchKernelGGL(k_attn<16>, grid, blk, 0, s, a);
+template <int NQ>
+hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s) {
+  const dim3 grid((a.Tq + 32 * NQ - 1) / (32 * NQ), kHeads, B), blk(256);
+  if (DH == 64) hipLaunchKernelGGL((k_attn<64, NQ>), grid, blk, 0, s, a);
+  else if (DH == 32) hipLaunchKernelGGL((k_attn<32, NQ>), grid, blk, 0, s, a);
+  else hipLaunchKernelGGL((k_attn<16, NQ>), grid, blk, 0, s, a);
   return hipGetLastError();
+}
+hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s) {
+  // 64-query workgroups only when they already give every CU one (B * heads * T/64 >= 256); else 32-query ones
+  if ((long)B * kHeads * ((a.Tq + 63) / 64) >= 256) return launch_attn_nq<2>(DH, a, B, s);
+  return launch_attn_nq<1>(DH, a, B, s);
 }
 
 struct TdBufs {
