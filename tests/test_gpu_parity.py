@@ -136,6 +136,30 @@ def test_sampler_matches_reference_golden(dev, name):
     assert rel_err(mel.cpu(), g["mel"]) < MEL_REL, name
 
 
+def test_config4_in_miniature_1000_step_ddpm_multi_speaker_fp32(dev):
+    """BASELINE configs[4] as SURVEY F4 reads it (DDPM sampler, sampler_interval = 1 => 1000 denoiser calls, speaker-embedding
+    front end) on the small net, in fp32, against the oracle chain with the same injected noise: the error after 1000 ancestral
+    steps must still be inside the mel bar.  (The config's bf16 storage mode is not built; tools/c5bench.py times this shape.)"""
+    from oracle import features_ref, sampler_ref
+    sd_f, sd_w = features_ref.seeded_frontend_state(11), wavenet_sd(WN_SMALL, 101)
+    m = _frontend(dev, sd_f)
+    m.diffusion.denoise_fn.load_state_dict(sd_w, strict=True)
+    g = torch.Generator().manual_seed(31)
+    B, T = 2, 24
+    c, f0 = torch.randn(B, T, 256, generator=g), 100 + 400 * torch.rand(B, T, generator=g)
+    spk, x0 = torch.tensor([2, 9]), torch.randn(B, 128, T, generator=g)
+    noise = torch.randn(1000, B, 128, T, generator=g)
+    with torch.no_grad():
+        feats = features_ref.forward_features(sd_f, c, spk, f0)["features"]
+        ref = sampler_ref.diffusion_sample(_oracle_den(sd_w, WN_SMALL), feats, x_init=x0, sampler_interval=1, predictor="naive",
+                                           step_noise=noise)
+    mel = m.infer(spk.to(dev), c.to(dev), f0.to(dev), sampler_interval=1, noise_predictor="naive", x_init=x0.to(dev),
+                  step_noise=noise.to(dev))
+    err = rel_err(mel.cpu(), ref)
+    print(f"1000-step DDPM: mel rel err {err:.3e}")
+    assert err < MEL_REL
+
+
 @pytest.mark.parametrize("tag", ["c1", "c2"])
 def test_baseline_configs_full_net_match_reference_golden(dev, tag):
     """BASELINE configs[0] (5 s, 20-step UniPC) and configs[1] (10 s, 100-step UniPC, the metric's config):
