@@ -57,6 +57,32 @@ struct ConvArgs {
 #endif
 };
 
+// Kernel-argument passing: the fields every workgroup needs before it can issue its first operand load travel as the kernel's
+// first 14 scalar dwords, which `-mllvm -amdgpu-kernarg-preload-count=14` (fish_diffusion_amd/_build.py) has the dispatcher place
+// in SGPRs at wave launch; by-value structs are never preloaded, they are fetched with s_load from the kernarg segment -- a
+// cold read from beyond the L2 on every launch of a replayed graph, i.e. a fabric round trip before the first address can be
+// formed.  The rest (ConvArgsCold, the epilogue) is only needed behind the pipeline prologue.
+struct ConvArgsCold {
+  int n_mtiles;
+  float in_slope;
+  const float* __restrict__ col_stats;
+  const float* __restrict__ ln_R;
+  int n_groups;
+  float ln_eps;
+#ifdef FDX_KTRACE
+  unsigned long long* trace;
+#endif
+};
+#define FDX_CONV_HOT_PARAMS                                                                                                   \
+  const float4 *__restrict__ h_Wp, const float *__restrict__ h_X, long h_xbs, int h_ldx, int h_n_it, int h_taps, int h_shift0, \
+      int h_dshift, int h_T, int h_tpi, int h_ntn
+#define FDX_CONV_HOT_ARGS(a) (a).Wp, (a).X, (a).x_bstride, (a).ldx, (a).n_it, (a).taps, (a).shift0, (a).dshift, (a).T, (a).tiles_per_item, (a).n_tiles_n
+#define FDX_CONV_ARGS_FROM_HOT(cold)                                                                                   \
+  ConvArgs a;                                                                                                          \
+  a.Wp = h_Wp; a.X = h_X; a.x_bstride = h_xbs; a.ldx = h_ldx; a.n_it = h_n_it; a.taps = h_taps; a.shift0 = h_shift0;   \
+  a.dshift = h_dshift; a.T = h_T; a.tiles_per_item = h_tpi; a.n_tiles_n = h_ntn;                                       \
+  conv_args_cold(a, cold)
+
 #ifdef FDX_KTRACE
 #define FDX_STAMP(k) do { if (a.trace && lane == 0) a.trace[((long)blockIdx.x * (blockDim.x >> 6) + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 struct TraceState { unsigned long long* buf = nullptr; int max_launches = 0, n = 0, blocks_cap = 0; };
@@ -64,6 +90,21 @@ inline TraceState g_trace;
 #else
 #define FDX_STAMP(k) do { } while (0)
 #endif
+
+__device__ __forceinline__ void conv_args_cold(ConvArgs& a, const ConvArgsCold& c) {
+  a.n_mtiles = c.n_mtiles; a.in_slope = c.in_slope; a.col_stats = c.col_stats; a.ln_R = c.ln_R; a.n_groups = c.n_groups; a.ln_eps = c.ln_eps;
+#ifdef FDX_KTRACE
+  a.trace = c.trace;
+#endif
+}
+inline ConvArgsCold conv_cold_of(const ConvArgs& a) {
+  ConvArgsCold c{};
+  c.n_mtiles = a.n_mtiles; c.in_slope = a.in_slope; c.col_stats = a.col_stats; c.ln_R = a.ln_R; c.n_groups = a.n_groups; c.ln_eps = a.ln_eps;
+#ifdef FDX_KTRACE
+  c.trace = a.trace;
+#endif
+  return c;
+}
 
 // ------------------------------------------------------------------------------------------ epilogues
 // Column mapping: lane li of MFMA column block nb (0/1) owns output column t0 + 2*li + nb, i.e. every lane owns an
@@ -340,7 +381,8 @@ constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result tra
 // (PRE_LN keeps its statistics in registers across the K loop: the second launch-bounds argument holds that instantiation to
 // the 256 VGPRs that let two workgroups share a CU, like every other instantiation already does unprompted.)
 template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1>
-__global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(ConvArgs a, Epi epi) {
+__global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
+  FDX_CONV_ARGS_FROM_HOT(cold);
   static_assert(NW == 4 || (SPLITK && NW == 8), "4 waves per workgroup, or 8 K-splitting waves (2 per SIMD)");
   static_assert(!Epi::kPaired || RB == 2, "paired epilogues need both row blocks");
   static_assert(MT == 1 || (SPLITK && MT == 2), "MT = 2 (two packed m-tiles per workgroup) is a split-K variant");
@@ -680,9 +722,10 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
-    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0, a, epi);
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0,
+                          FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, a, epi);
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 

@@ -92,7 +92,8 @@ struct EpiResSkip16 {  // wavenet.py:117-120 + the skip sum of :228
 
 // ------------------------------------------------------------------------------------------ kernel
 template <class Epi>
-__global__ __launch_bounds__(256) void convgemm16_kernel(ConvArgs a, Epi epi) {
+__global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
+  FDX_CONV_ARGS_FROM_HOT(cold);
   constexpr int NW = 4;
   __shared__ float red[NW * 16 * kWave * 4];          // [wave][rbk*4 + reg][lane][m]   (64 KB)
 
@@ -245,6 +246,7 @@ inline hipError_t launch_convgemm16(const ConvGeom& g, const float4* Wp, const f
   a.n_tiles_n = g.B * a.tiles_per_item;
   a.n_mtiles = g.n_mtiles;
   a.in_slope = 1.f;
+  a.col_stats = nullptr; a.ln_R = nullptr; a.n_groups = 0; a.ln_eps = 0.f;
   const int grid = a.n_tiles_n * a.n_mtiles;
   if (grid <= 0) return hipSuccess;
 #ifdef FDX_KTRACE
@@ -253,9 +255,9 @@ inline hipError_t launch_convgemm16(const ConvGeom& g, const float4* Wp, const f
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)
-    hipExtLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, a, epi);
+    hipExtLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, a, epi);
+    hipLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 
