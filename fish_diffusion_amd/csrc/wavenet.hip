@@ -55,13 +55,13 @@ static int wn_validate(const fdx_wavenet_desc* d) {
   return FDX_OK;
 }
 
-static PackedW plan_w(size_t& cur, int rows, int cin, int taps, bool paired) {
+static PackedW plan_w(size_t& cur, int rows, int cin, int taps, bool paired, int RB = 2) {
   PackedW p;
-  p.RB = 2;
+  p.RB = RB;
   p.rows = rows;
   p.cin8 = (cin + 7) / 8;
   p.taps = taps;
-  p.n_mtiles = paired ? (rows / 2 + 31) / 32 : (rows + 63) / 64;
+  p.n_mtiles = paired ? (rows / 2 + 31) / 32 : (rows + 32 * RB - 1) / (32 * RB);
   p.w_off = cur;
   cur += packed_floats(p.n_mtiles, p.RB, p.cin8, p.taps);
   p.b_off = cur;
@@ -83,8 +83,10 @@ static void wn_layout(const fdx_wavenet_desc& d, WavenetLayout& l) {
     l.outp.push_back(plan_w(cur, 2 * C, C, 1, false));
     l.dil.push_back(d.dilation_cycle ? 1 << (i % d.dilation_cycle) : 1);
   }
-  l.skip_proj = plan_w(cur, C, C, 1, false);
-  l.out_proj = plan_w(cur, d.mel_channels, C, 1, false);
+  // the two once-per-call projections have few rows (C and mel_channels): 32-row tiles double their workgroup count
+  // (skip 112 -> 224, out 28 -> 56 at T = 861) where 64-row tiles leave most CUs idle
+  l.skip_proj = plan_w(cur, C, C, 1, false, 1);
+  l.out_proj = plan_w(cur, d.mel_channels, C, 1, false, 1);
   l.total_floats = cur;
 }
 
@@ -105,7 +107,7 @@ extern "C" int fdx_wavenet_packed_bytes(const fdx_wavenet_desc* d, size_t* bytes
 // plain (unpaired) conv/linear weight [rows][cin][taps] -> fragment order; rows/cin beyond the tensor are 0
 static void pack_plain(float* arena, const PackedW& p, const float* w, int rows, int cin, const float* bias) {
   pack_convgemm(arena + p.w_off, p.n_mtiles, p.RB, p.cin8, p.taps, [&](int mt, int rb, int i, int c, int tap) -> float {
-    const int row = mt * 64 + rb * 32 + i;
+    const int row = mt * 32 * p.RB + rb * 32 + i;
     if (row >= rows || c >= cin) return 0.f;
     return w[((size_t)row * cin + c) * p.taps + tap];
   });
@@ -213,6 +215,8 @@ static hipError_t run_gemm(const float* arena, const PackedW& p, int B, int T, c
   // Measured on MI355X (100-step UniPC, 10 s utterances): batch 2: 171.6 vs 173.9 ms (+1 %), batch 8: 632.5 vs 571.8 ms
   // (-10 %): two co-resident 64-row workgroups hide each other's epilogues and operand waits better than one big one.
   // Off by default (FDX_MT2_MIN_TILES=<n> enables it for launches with at least n 128-row tiles).
+  if constexpr (!Epi::kPaired)
+    if (p.RB == 1) return launch_convgemm<1, SPLITK, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s, ev0, ev1);
   const long tiles2 = (long)B * ((T + 63) / 64) * (p.n_mtiles / 2);
   if (SPLITK && p.n_mtiles % 2 == 0 && tiles2 >= kMinTilesMT2)
     return launch_convgemm<2, SPLITK, LRELU, Epi, 4, SPLITK ? 2 : 1>(g, Wp, X, x_bs, ldx, slope, e, s, ev0, ev1);

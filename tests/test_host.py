@@ -78,9 +78,9 @@ def test_state_dict_keys_match_reference_contract(lib):
 # ------------------------------------------------------------------ packing, via the numpy kernel emulation
 def _wn_offsets(C_, L, M, E):
     """Mirror of wn_layout (fish_diffusion_amd/csrc/wavenet.hip): arena section offsets in floats."""
-    def plan(cur, rows, cin, taps, paired):
-        mt = (rows // 2 + 31) // 32 if paired else (rows + 63) // 64
-        w = mt * ((cin + 7) // 8) * taps * 2 * 64 * 4
+    def plan(cur, rows, cin, taps, paired, RB=2):
+        mt = (rows // 2 + 31) // 32 if paired else (rows + 32 * RB - 1) // (32 * RB)
+        w = mt * ((cin + 7) // 8) * taps * RB * 64 * 4
         return dict(w=cur, b=cur + w, mt=mt, cin8=(cin + 7) // 8, taps=taps), cur + w + (rows + 63) // 64 * 64
     cur, out = 0, {}
     for name, rows, cin in (("in_proj", C_, M), ("mlp0", 4 * C_, C_), ("mlp2", C_, 4 * C_), ("dproj", L * C_, C_), ("cond", L * 2 * C_, E)):
@@ -88,8 +88,8 @@ def _wn_offsets(C_, L, M, E):
     for i in range(L):
         out[f"conv{i}"], cur = plan(cur, 2 * C_, C_, 3, True)
         out[f"outp{i}"], cur = plan(cur, 2 * C_, C_, 1, False)
-    out["skip_proj"], cur = plan(cur, C_, C_, 1, False)
-    out["out_proj"], cur = plan(cur, M, C_, 1, False)
+    out["skip_proj"], cur = plan(cur, C_, C_, 1, False, RB=1)
+    out["out_proj"], cur = plan(cur, M, C_, 1, False, RB=1)
     out["total"] = cur
     return out
 
@@ -137,6 +137,14 @@ def test_wavenet_packing_matches_kernel_index_math(lib):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
     bias = arena[o["b"]:o["b"] + 256]
     np.testing.assert_array_equal(bias, torch.cat([sd[f"residual_layers.{i}.diffusion_projection.linear.bias"] for i in range(4)]).numpy())
+    # ---- final projection: 32-row tiles (RB = 1)
+    hx = torch.randn(64, T, generator=g)
+    X = np.zeros((64, ld), np.float32)
+    X[:, halo:halo + T] = hx.numpy()
+    o = off["out_proj"]
+    acc = emulate_convgemm(arena[o["w"]:o["b"]], X, n_mtiles=o["mt"], RB=1, cin8=o["cin8"], taps=1, shift0=0, dshift=0, T=T)
+    got = np.concatenate([acc[(mt, 0)] for mt in range(o["mt"])])
+    np.testing.assert_allclose(got, (sd["output_projection.conv.weight"][:, :, 0] @ hx).numpy(), rtol=1e-4, atol=1e-5)
     # ---- conditioner slab bias absorbs the conv bias
     o = off["cond"]
     want = torch.cat([sd[f"residual_layers.{i}.conditioner_projection.conv.bias"] + sd[f"residual_layers.{i}.conv_layer.conv.bias"]
