@@ -72,7 +72,7 @@ static PackedW plan_w(size_t& cur, int rows, int cin, int taps, bool paired, int
 static void wn_layout(const fdx_wavenet_desc& d, WavenetLayout& l) {
   const int C = d.residual_channels, L = d.residual_layers;
   size_t cur = 0;
-  l.in_proj = plan_w(cur, C, d.mel_channels, 1, false);
+  l.in_proj = plan_w(cur, C, d.mel_channels, 1, false, 1);   // (32-row tiles: see skip_proj below)
   l.mlp0 = plan_w(cur, 4 * C, C, 1, false);
   l.mlp2 = plan_w(cur, C, 4 * C, 1, false);
   l.dproj = plan_w(cur, L * C, C, 1, false);

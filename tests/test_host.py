@@ -84,7 +84,7 @@ def _wn_offsets(C_, L, M, E):
         return dict(w=cur, b=cur + w, mt=mt, cin8=(cin + 7) // 8, taps=taps), cur + w + (rows + 63) // 64 * 64
     cur, out = 0, {}
     for name, rows, cin in (("in_proj", C_, M), ("mlp0", 4 * C_, C_), ("mlp2", C_, 4 * C_), ("dproj", L * C_, C_), ("cond", L * 2 * C_, E)):
-        out[name], cur = plan(cur, rows, cin, 1, False)
+        out[name], cur = plan(cur, rows, cin, 1, False, RB=1 if name == "in_proj" else 2)
     for i in range(L):
         out[f"conv{i}"], cur = plan(cur, 2 * C_, C_, 3, True)
         out[f"outp{i}"], cur = plan(cur, 2 * C_, C_, 1, False)
