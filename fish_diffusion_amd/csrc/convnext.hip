@@ -47,7 +47,7 @@ int cn_validate(const fdx_convnext_desc* d) {
 void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
   const int D = d.dim, H = d.dim * d.mlp_factor, L = d.num_layers;
   size_t cur = 0;
-  l.in_proj = plan64(cur, D, d.mel_channels);
+  l.in_proj = plan32(cur, D, d.mel_channels);   // D- and M-row GEMMs: 32-row tiles (twice the workgroups)
   l.emb1 = plan64(cur, H, D);
   l.emb3 = plan64(cur, D, H);
   l.cond0 = plan64(cur, H, d.condition_dim);
@@ -64,8 +64,8 @@ void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
     l.lnR.push_back(cur); cur += (size_t)round_up(H, 64) * 16;
     l.dil.push_back(1 << (i % d.dilation_cycle));
   }
-  l.out0 = plan64(cur, D, D);
-  l.out2 = plan64(cur, d.mel_channels, D);
+  l.out0 = plan32(cur, D, D);
+  l.out2 = plan32(cur, d.mel_channels, D);
   l.total_floats = cur;
 }
 

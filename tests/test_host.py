@@ -333,7 +333,7 @@ def _cn_offsets(D, Hf, L, M, E):
     cur, out = 0, {}
     for name, rows, cin in (("in_proj", D, M), ("emb1", H, D), ("emb3", D, H), ("cond0", H, E), ("cond2", D, H), ("dsp", L * D, D),
                             ("cproj", L * D, D)):
-        out[name], cur = plan(cur, rows, cin)
+        out[name], cur = plan(cur, rows, cin, RB=1 if name == "in_proj" else 2)
     for i in range(L):
         out[f"pw1_{i}"], cur = plan(cur, H, D)
         out[f"pw2_{i}"], cur = plan(cur, D, H, RB=1)
@@ -342,8 +342,8 @@ def _cn_offsets(D, Hf, L, M, E):
         for nm in ("dw_b", "gamma"):
             out[f"{nm}{i}"] = cur; cur += r64(D)
         out[f"lnR{i}"] = cur; cur += r64(H) * 16
-    out["out0"], cur = plan(cur, D, D)
-    out["out2"], cur = plan(cur, M, D)
+    out["out0"], cur = plan(cur, D, D, RB=1)
+    out["out2"], cur = plan(cur, M, D, RB=1)
     out["total"] = cur
     return out
 
