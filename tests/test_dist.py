@@ -35,6 +35,12 @@ def _worker(rank, world, port, out_dir):
     if rank == 0:
         local = torch.from_numpy(_lib.pack_on_host(net._desc, net._params(), "wavenet").view(np.uint8))
         assert torch.equal(local, arena)
+    # the other denoisers ride the same broadcast (dist.broadcast_model_weights keys on the module's `_KIND`)
+    from fish_diffusion_amd import ConvNext, TransformerDecoderDenoiser
+    for j, den in enumerate((ConvNext(mel_channels=16, dim=64, mlp_factor=2, condition_dim=24, num_layers=2),
+                             TransformerDecoderDenoiser(mel_channels=16, dim=128, mlp_factor=1, condition_dim=24, num_layers=1))):
+        a = fdist.broadcast_arena(den._desc, den._KIND, den._params() if rank == 0 else None, cpu)
+        np.save(os.path.join(out_dir, f"darena{j}_{rank}.npy"), a.numpy())
     np.save(os.path.join(out_dir, f"arena{rank}.npy"), arena.numpy())
     np.save(os.path.join(out_dir, f"garena{rank}.npy"), garena.numpy())
     # per-rank stats gather + max-over-ranks timing
@@ -56,6 +62,9 @@ def test_broadcast_and_sharding_world2(tmp_path, lib_built):
     assert a0.size > 0 and np.array_equal(a0, a1)
     g0, g1 = np.load(tmp_path / "garena0.npy"), np.load(tmp_path / "garena1.npy")
     assert g0.size > 0 and np.array_equal(g0, g1)
+    for j in range(2):
+        d0, d1 = np.load(tmp_path / f"darena{j}_0.npy"), np.load(tmp_path / f"darena{j}_1.npy")
+        assert d0.size > 0 and np.array_equal(d0, d1)
     s0, s1 = np.load(tmp_path / "shard0.npy").tolist(), np.load(tmp_path / "shard1.npy").tolist()
     assert sorted(s0 + s1) == list(range(7)) and not set(s0) & set(s1)
     lengths = [516, 861, 700, 861, 600, 530, 800]
