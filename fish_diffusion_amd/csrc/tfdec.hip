@@ -185,12 +185,32 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   for (int nb = 0; nb < NQ; ++nb) { m[nb] = NEG; l[nb] = 0.f; }
   float* vt = lds + wave * DH * VLD;
 
+  // The K and V operands of a tile are fetched into registers one tile ahead: right after the score MFMAs have consumed the
+  // current ones, so that their fabric latency runs behind the softmax and the second product instead of in front of the first.
   const int n_kt = (a.Tk + 63) / 64;
+  float kreg[KS][2], vreg[DH];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) kreg[ks][rb] = Kh[(long)(2 * ks + half) * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) vreg[d] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
+  };
+  // (not for 64-query x 64-channel workgroups: their accumulators leave no room for a second operand set in 512 VGPRs)
+  constexpr bool PF = !(DH == 64 && NQ == 2);
+  if (PF && wave < n_kt) fetch(wave);
   for (int kt = wave; kt < n_kt; kt += 4) {
     const int k0 = kt * 64;
     // ---- stage this tile of V (coalesced rows) for the second product
+    if constexpr (PF) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = vreg[d];
+    } else {
 #pragma unroll 8
-    for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
+      for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
+    }
     // ---- S^T = K^T Q
     f32x16 s[2][NQ];
 #pragma unroll
@@ -203,12 +223,14 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     for (int ks = 0; ks < KS; ++ks) {
       float ak[2];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) ak[rb] = Kh[(long)(2 * ks + half) * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)];
+      for (int rb = 0; rb < 2; ++rb)
+        ak[rb] = PF ? kreg[ks][rb] : Kh[(long)(2 * ks + half) * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int nb = 0; nb < NQ; ++nb) s[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rb], qreg[ks][nb], s[rb][nb], 0, 0, 0);
     }
+    if (PF && kt + 4 < n_kt) fetch(kt + 4);
     // ---- scale, key mask (padding keys and the tile overhang), online softmax over the key axis
     float mx[NQ];
 #pragma unroll
