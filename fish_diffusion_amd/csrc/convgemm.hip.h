@@ -61,9 +61,10 @@ struct ConvArgs {
 // first 14 scalar dwords, which `-mllvm -amdgpu-kernarg-preload-count=14` (fish_diffusion_amd/_build.py) has the dispatcher place
 // in SGPRs at wave launch; by-value structs are never preloaded, they are fetched with s_load from the kernarg segment -- a
 // cold read from beyond the L2 on every launch of a replayed graph, i.e. a fabric round trip before the first address can be
-// formed.  The rest (ConvArgsCold, the epilogue) is only needed behind the pipeline prologue.
+// formed.  The rest (ConvArgsCold, the epilogue) is only needed behind the pipeline prologue.  For the same reason the kernels
+// never read gridDim (a hidden kernel argument, i.e. another kernarg-segment load): the grid size is n_tiles_n * n_mtiles / MT
+// and tiles_per_item is recomputed from T.
 struct ConvArgsCold {
-  int n_mtiles;
   float in_slope;
   const float* __restrict__ col_stats;
   const float* __restrict__ ln_R;
@@ -75,12 +76,12 @@ struct ConvArgsCold {
 };
 #define FDX_CONV_HOT_PARAMS                                                                                                   \
   const float4 *__restrict__ h_Wp, const float *__restrict__ h_X, long h_xbs, int h_ldx, int h_n_it, int h_taps, int h_shift0, \
-      int h_dshift, int h_T, int h_tpi, int h_ntn
-#define FDX_CONV_HOT_ARGS(a) (a).Wp, (a).X, (a).x_bstride, (a).ldx, (a).n_it, (a).taps, (a).shift0, (a).dshift, (a).T, (a).tiles_per_item, (a).n_tiles_n
+      int h_dshift, int h_T, int h_ntn, int h_nmt
+#define FDX_CONV_HOT_ARGS(a) (a).Wp, (a).X, (a).x_bstride, (a).ldx, (a).n_it, (a).taps, (a).shift0, (a).dshift, (a).T, (a).n_tiles_n, (a).n_mtiles
 #define FDX_CONV_ARGS_FROM_HOT(cold)                                                                                   \
   ConvArgs a;                                                                                                          \
   a.Wp = h_Wp; a.X = h_X; a.x_bstride = h_xbs; a.ldx = h_ldx; a.n_it = h_n_it; a.taps = h_taps; a.shift0 = h_shift0;   \
-  a.dshift = h_dshift; a.T = h_T; a.tiles_per_item = h_tpi; a.n_tiles_n = h_ntn;                                       \
+  a.dshift = h_dshift; a.T = h_T; a.n_tiles_n = h_ntn; a.n_mtiles = h_nmt;                                            \
   conv_args_cold(a, cold)
 
 #ifdef FDX_KTRACE
@@ -92,14 +93,14 @@ inline TraceState g_trace;
 #endif
 
 __device__ __forceinline__ void conv_args_cold(ConvArgs& a, const ConvArgsCold& c) {
-  a.n_mtiles = c.n_mtiles; a.in_slope = c.in_slope; a.col_stats = c.col_stats; a.ln_R = c.ln_R; a.n_groups = c.n_groups; a.ln_eps = c.ln_eps;
+  a.in_slope = c.in_slope; a.col_stats = c.col_stats; a.ln_R = c.ln_R; a.n_groups = c.n_groups; a.ln_eps = c.ln_eps;
 #ifdef FDX_KTRACE
   a.trace = c.trace;
 #endif
 }
 inline ConvArgsCold conv_cold_of(const ConvArgs& a) {
   ConvArgsCold c{};
-  c.n_mtiles = a.n_mtiles; c.in_slope = a.in_slope; c.col_stats = a.col_stats; c.ln_R = a.ln_R; c.n_groups = a.n_groups; c.ln_eps = a.ln_eps;
+  c.in_slope = a.in_slope; c.col_stats = a.col_stats; c.ln_R = a.ln_R; c.n_groups = a.n_groups; c.ln_eps = a.ln_eps;
 #ifdef FDX_KTRACE
   c.trace = a.trace;
 #endif
@@ -383,6 +384,7 @@ constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result tra
 template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1>
 __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
+  a.tiles_per_item = (a.T + (SPLITK ? 63 : 255)) / (SPLITK ? 64 : 256);
   static_assert(NW == 4 || (SPLITK && NW == 8), "4 waves per workgroup, or 8 K-splitting waves (2 per SIMD)");
   static_assert(!Epi::kPaired || RB == 2, "paired epilogues need both row blocks");
   static_assert(MT == 1 || (SPLITK && MT == 2), "MT = 2 (two packed m-tiles per workgroup) is a split-K variant");
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
   FDX_STAMP(0);
 
   // ---- XCD-aware logical tile id (block b runs on XCD b % 8; give each XCD a contiguous chunk)
-  const int G = gridDim.x, bid = blockIdx.x;
+  const int G = a.n_tiles_n * (a.n_mtiles / MT), bid = blockIdx.x;   // == gridDim.x, from preloaded arguments
   const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
   const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int mtg = L / a.n_tiles_n;            // group of MT consecutive packed m-tiles

@@ -94,6 +94,7 @@ struct EpiResSkip16 {  // wavenet.py:117-120 + the skip sum of :228
 template <class Epi>
 __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
+  a.tiles_per_item = (a.T + 63) / 64;
   constexpr int NW = 4;
   __shared__ float red[NW * 16 * kWave * 4];          // [wave][rbk*4 + reg][lane][m]   (64 KB)
 
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
   const int lj = lane & 15, lk = lane >> 4;           // B: column group / k-row;  A: row-in-block / k;  D: column group / row quad
   FDX_STAMP(0);
 
-  const int G = gridDim.x, bid = blockIdx.x;
+  const int G = a.n_tiles_n * a.n_mtiles, bid = blockIdx.x;   // == gridDim.x, from preloaded arguments
   const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
   const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int mt = L / a.n_tiles_n;
