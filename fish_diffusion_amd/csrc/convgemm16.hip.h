@@ -31,7 +31,9 @@ __device__ __forceinline__ f4 ld4(const float* p) {   // sources are the library
 __device__ __forceinline__ void st4p(float* p, f4 v, int nvalid) {
   f4u u;
   u.x = v.x; u.y = nvalid > 1 ? v.y : 0.f; u.z = nvalid > 2 ? v.z : 0.f; u.w = nvalid > 3 ? v.w : 0.f;
-  *reinterpret_cast<f4u*>(p) = u;
+  // non-temporal: the tile is read next by OTHER XCDs (through the fabric, not this L2) -- see st2p in convgemm.hip.h
+  typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
+  __builtin_nontemporal_store(f4nt{u.x, u.y, u.z, u.w}, reinterpret_cast<f4nt*>(p));
 }
 
 struct EpiGate16 {  // wavenet.py:112-115
