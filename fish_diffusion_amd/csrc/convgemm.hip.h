@@ -141,6 +141,12 @@ __device__ __forceinline__ void st2p(float* p, f2 v, bool two) {
   __builtin_nontemporal_store(f2nt{u.x, u.y}, reinterpret_cast<f2nt*>(p));
 }
 
+// same store, cached normally: for tensors the SAME tile (hence the same XCD) reads back in the next layer (residual x, skip sum)
+__device__ __forceinline__ void st2p_keep(float* p, f2 v, bool two) {
+  f2u u; u.x = v.x; u.y = two ? v.y : 0.f;
+  *reinterpret_cast<f2u*>(p) = u;
+}
+
 // x / c for a wave-uniform constant c with rc = RN(1/c): Markstein's sequence q = RN(x*rc); r = x - q*c (exact, fused);
 // q' = RN(q + r*rc) returns the correctly rounded quotient (checked bit-identical to IEEE division on 8e7 random x for
 // c = sqrt(2)) in 3 dependent VALU ops instead of the ~12-op v_div_scale / v_rcp / v_div_fixup expansion.
@@ -258,14 +264,14 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
     if (is_res(row)) {
       const long o = b * bs + (long)row * ld + t;
       const f2 xn = div_const(p.old + v, 1.41421356237309504880f, 0.70710678118654752440f);
-      st2p(X + o, xn, two);
+      st2p_keep(X + o, xn, two);
       if (Y) st2p(Y + o, xn + p.sb, two);
     } else {
       const long o = b * bs + (long)(row - C) * ld + t;
       f2 s = v;
       if (skip_mode == 1 || skip_mode == 2) s = p.old + v;
       if (skip_mode >= 2) s = div_const(s, inv_div, r_inv_div);
-      st2p(SK + o, s, two);
+      st2p_keep(SK + o, s, two);
     }
   }
 };
