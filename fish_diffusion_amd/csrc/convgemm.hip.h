@@ -295,7 +295,7 @@ struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) +
     v = p.old + p.gamma * (v + p.bias);
     if (p.m0) v.x = 0.f;
     if (p.m1) v.y = 0.f;
-    st2p(X + b * bs + (long)row * ld + t, v, two);
+    st2p_keep(X + b * bs + (long)row * ld + t, v, two);
   }
 };
 
