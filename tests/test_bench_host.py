@@ -41,7 +41,11 @@ def test_usable_cores_and_traffic_file():
 
 def test_make_batches_rules():
     from fish_diffusion_amd.pipeline import make_batches
-    assert make_batches([10, 9, 8, 3], 2) == [[0, 1], [2], [3]]              # full, then padding ratio
+    assert make_batches([10, 9, 8, 3], 2) == [[0, 1], [2], [3]]              # pairing 8 with 3 would pad 3 -> 8: cheaper apart
+    assert make_batches([10, 9, 8, 3], 2, max_pad_ratio=0.25) == [[0, 1], [2], [3]]
+    assert make_batches([861, 850, 800, 790, 740, 700, 690, 640], 8) == [[0, 1, 2, 3, 4, 5, 6, 7]]   # a full batch beats [6, 2]
+    assert make_batches([861, 800, 700, 650, 600, 560, 540, 520], 8) == [[0, 1], [2, 3], [4, 5, 6, 7]]   # ... unless the spread is wide
+    assert make_batches([861, 800, 700, 650, 600, 560, 540, 520], 8, max_pad_ratio=0.25) == [[0, 1], [2, 3], [4, 5, 6, 7]]   # no member padded > 25 %
     assert make_batches([5, 5, 5], 8) == [[0, 1, 2]]
     assert make_batches([], 4) == []
     flat = sorted(i for b in make_batches([7, 100, 90, 95, 20, 21, 60], 3) for i in b)
