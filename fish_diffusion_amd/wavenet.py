@@ -79,6 +79,7 @@ class HipDenoiser(nn.Module):
         self._arena: Optional[torch.Tensor] = None
         self._packed_sig = None
         self._prep_sig = None
+        self._prep_keep = None
 
     def _fn(self, name):
         return getattr(_lib.lib(), f"fdx_{self._KIND}_{name}")
@@ -123,8 +124,12 @@ class HipDenoiser(nn.Module):
         """Hoisted conditioner projections of all layers (wavenet.py:108 is step-invariant)."""
         _lib.require_gpu(conditioner, "denoiser conditioner")
         eng = self.engine(conditioner.device)
-        sig = (conditioner.data_ptr(), conditioner._version, tuple(conditioner.shape),
-               None if cond_masks is None else (cond_masks.data_ptr(), cond_masks._version), self._packed_sig)
+        # The hoisted work is cached on the identity of its inputs (address, version counter, geometry).  The module keeps the two
+        # tensors alive while the cache entry is: otherwise the allocator could hand their addresses to a NEW conditioner
+        # (version 0 again) and the stale slab would be reused silently.
+        def ident(t):
+            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype)
+        sig = (ident(conditioner), ident(cond_masks), self._packed_sig)
         if sig != self._prep_sig:
             B, E, T = conditioner.shape
             if E != self._cond_channels:
@@ -135,6 +140,7 @@ class HipDenoiser(nn.Module):
                 _lib.check(self._fn("prepare")(eng.h, _lib.ptr(cond), B, T, _lib.ptr(cm),
                                                           _lib.stream_ptr(cond.device)), eng.h)
             self._prep_sig = sig
+            self._prep_keep = (conditioner, cond_masks)
         return eng
 
     # ------------------------------------------------------------------ forward

@@ -104,6 +104,27 @@ def test_wavenet_rejects_bad_input_like_the_reference(dev):
         net(torch.zeros(1, 128, 8), torch.zeros(1), torch.zeros(1, 256, 8))   # CPU tensors: no fallback
 
 
+def test_prepare_cache_is_not_fooled_by_recycled_addresses(dev):
+    """The hoisted conditioner slab is cached on the conditioner's identity.  A NEW conditioner that the caching allocator places
+    at the address of a freed one (same shape, version counter 0 again) must not hit that cache."""
+    cfg = WN_SMALL
+    sd = wavenet_sd(cfg, 101)
+    net = _wavenet(cfg, sd, dev)
+    den = _oracle_den(sd, cfg)
+    g = torch.Generator().manual_seed(5)
+    x, t = torch.randn(1, 128, 33, generator=g), torch.tensor([123.0])
+    conds = [torch.randn(1, 256, 33, generator=g) for _ in range(3)]
+    ptrs = []
+    for c in conds:
+        cd = c.to(dev)                      # a fresh device tensor per call, dropped right after: the usual caller pattern
+        ptrs.append(cd.data_ptr())
+        out = net(x.to(dev), t.to(dev), cd).cpu()
+        del cd
+        with torch.no_grad():
+            assert rel_err(out, den(x, t, c, None, None)) < 2e-5
+    print("conditioner addresses:", [hex(p) for p in ptrs])
+
+
 def test_wavenet_ragged_lengths_vs_oracle(dev):
     """T not a multiple of any tile size, T smaller than the receptive field, B > 1 with per-item timesteps."""
     cfg = WN_SMALL
