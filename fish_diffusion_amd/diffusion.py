@@ -142,13 +142,14 @@ class GaussianDiffusion(nn.Module):
         xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if step_noise is None else 0
 
-        eng = self.denoise_fn.prepare(cond, cond_masks)
         table = np.ascontiguousarray(table, dtype=np.float32)
         mel = torch.empty((B, T, M), device=device, dtype=torch.float32)
         smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         smax = self.spec_max.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         st = _lib.stream_ptr(device)
-        with eng.lock:
+        eng = self.denoise_fn.engine(device)
+        with eng.lock:   # prepare + sampler run as one critical section (the reference's flask server calls from several threads)
+            self.denoise_fn.prepare(cond, cond_masks)
             _lib.check(_lib.lib().fdx_sampler_run(eng.h, kind, C.c_void_p(table.ctypes.data), n_rows, _lib.ptr(x),
                                                   _lib.ptr(step_noise), seed, _lib.ptr(xm), st), eng.h)
             _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x), B, M, T, C.c_void_p(smin.data_ptr()),

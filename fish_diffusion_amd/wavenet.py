@@ -129,18 +129,17 @@ class HipDenoiser(nn.Module):
         # (version 0 again) and the stale slab would be reused silently.
         def ident(t):
             return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype)
-        sig = (ident(conditioner), ident(cond_masks), self._packed_sig)
-        if sig != self._prep_sig:
-            B, E, T = conditioner.shape
-            if E != self._cond_channels:
-                raise ValueError(f"conditioner has {E} channels, expected {self._cond_channels}")
-            cond = conditioner.to(torch.float32).contiguous()
-            cm = None if cond_masks is None else cond_masks.to(torch.uint8).contiguous()
-            with eng.lock:
-                _lib.check(self._fn("prepare")(eng.h, _lib.ptr(cond), B, T, _lib.ptr(cm),
-                                                          _lib.stream_ptr(cond.device)), eng.h)
-            self._prep_sig = sig
-            self._prep_keep = (conditioner, cond_masks)
+        with eng.lock:   # callers that go on to use the prepared state hold the same (re-entrant) lock across both steps
+            sig = (ident(conditioner), ident(cond_masks), self._packed_sig)
+            if sig != self._prep_sig:
+                B, E, T = conditioner.shape
+                if E != self._cond_channels:
+                    raise ValueError(f"conditioner has {E} channels, expected {self._cond_channels}")
+                cond = conditioner.to(torch.float32).contiguous()
+                cm = None if cond_masks is None else cond_masks.to(torch.uint8).contiguous()
+                _lib.check(self._fn("prepare")(eng.h, _lib.ptr(cond), B, T, _lib.ptr(cm), _lib.stream_ptr(cond.device)), eng.h)
+                self._prep_sig = sig
+                self._prep_keep = (conditioner, cond_masks)
         return eng
 
     # ------------------------------------------------------------------ forward
@@ -153,7 +152,6 @@ class HipDenoiser(nn.Module):
             use_4_dim = True
         assert x.dim() == 3, f"mel must be 3 dim tensor, but got {x.dim()}"
         _lib.require_gpu(x, "denoiser input")
-        eng = self.prepare(conditioner, cond_masks)
         B, M, T = x.shape
         if M != self.mel_channels or conditioner.shape[0] != B or conditioner.shape[2] != T:
             raise ValueError(f"x {tuple(x.shape)} does not match conditioner {tuple(conditioner.shape)}")
@@ -161,7 +159,9 @@ class HipDenoiser(nn.Module):
         t = diffusion_step.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()
         out = torch.empty_like(xin)
-        with eng.lock:
+        eng = self.engine(x.device)
+        with eng.lock:   # prepare + forward as one critical section: another thread must not re-prepare the handle in between
+            self.prepare(conditioner, cond_masks)
             _lib.check(self._fn("forward")(eng.h, _lib.ptr(xin), _lib.ptr(t), t.numel(), _lib.ptr(xm),
                                                       _lib.ptr(out), _lib.stream_ptr(x.device)), eng.h)
         return out[:, None] if use_4_dim else out

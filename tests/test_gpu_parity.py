@@ -125,6 +125,29 @@ def test_prepare_cache_is_not_fooled_by_recycled_addresses(dev):
     print("conditioner addresses:", [hex(p) for p in ptrs])
 
 
+def test_concurrent_callers_on_one_module(dev):
+    """The reference's flask server is threaded (tools/diffusion/flask_api.py:86): two threads driving ONE diffusion module with
+    different conditioners must each get their own result (prepare + sampler run are one critical section per handle)."""
+    import threading
+    diff = _diffusion(WN_SMALL, wavenet_sd(WN_SMALL, 101), dev)
+    g = torch.Generator().manual_seed(8)
+    jobs = [(torch.randn(1, 30 + 7 * k, 256, generator=g).to(dev), torch.randn(1, 128, 30 + 7 * k, generator=g).to(dev)) for k in range(4)]
+    want = [diff(f, sampler_interval=100, x_init=x0).cpu() for f, x0 in jobs]
+    got = [[None] * len(jobs) for _ in range(2)]
+
+    def worker(w):
+        for rep in range(3):
+            for k in (range(len(jobs)) if w == 0 else reversed(range(len(jobs)))):
+                f, x0 = jobs[k]
+                got[w][k] = diff(f, sampler_interval=100, x_init=x0).cpu()
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for w in range(2):
+        for k in range(len(jobs)):
+            assert torch.equal(got[w][k], want[k]), (w, k)
+
+
 def test_wavenet_ragged_lengths_vs_oracle(dev):
     """T not a multiple of any tile size, T smaller than the receptive field, B > 1 with per-item timesteps."""
     cfg = WN_SMALL
