@@ -218,6 +218,33 @@ def test_baseline_configs_full_net_match_reference_golden(dev, tag):
     assert err < MEL_REL
 
 
+@pytest.mark.parametrize("pred", ["unipc", "plms", "naive"])
+def test_sampler_odd_step_counts_vs_oracle(dev, pred):
+    """Schedules that do not divide 1000, and the shortest ones: 2 / 3 / 4 / 143 model evaluations (UniPC's warm-up order, its
+    corrector-free last step, PLMS' growing history all hit their corner cases); a 1-step UniPC asserts like the reference
+    (uni_pc.py:726).  The oracle is bit-identical to the real reference on every one of these (checked when this test was written)."""
+    from oracle import sampler_ref
+    sd = wavenet_sd(WN_SMALL, 101)
+    diff = _diffusion(WN_SMALL, sd, dev)
+    den = _oracle_den(sd, WN_SMALL)
+    g = torch.Generator().manual_seed(3)
+    B, T = 1, 24
+    feats = torch.randn(B, T, 256, generator=g)
+    x0 = torch.randn(B, 128, T, generator=g)
+    for interval in (500, 334, 333, 250, 7) + ((1000,) if pred != "unipc" else ()):
+        n = len(range(0, 1000, interval))
+        sn = torch.randn(n, B, 128, T, generator=g) if pred == "naive" else None
+        with torch.no_grad():
+            ref = sampler_ref.diffusion_sample(den, feats, x_init=x0, sampler_interval=interval, predictor=pred,
+                                               step_noise=sn if sn is not None else torch.zeros(0))
+        mel = diff(feats.to(dev), sampler_interval=interval, noise_predictor=pred, x_init=x0.to(dev),
+                   step_noise=None if sn is None else sn.to(dev))
+        assert rel_err(mel.cpu(), ref) < MEL_REL, (pred, interval)
+    if pred == "unipc":
+        with pytest.raises(AssertionError):
+            diff(feats.to(dev), sampler_interval=1000, noise_predictor="unipc", x_init=x0.to(dev))
+
+
 def test_sampler_unknown_predictor_raises(dev):
     diff = _diffusion(WN_SMALL, wavenet_sd(WN_SMALL, 101), dev)
     with pytest.raises(NotImplementedError):
