@@ -823,6 +823,27 @@ def test_refinegan_interfaces_and_device_rng(dev):
         voc.model(mel.to(dev)[None], f0d[None, :-1])
 
 
+def test_refinegan_geometry_sequence_on_one_instance_vs_oracle(dev):
+    """One generator instance across changing (B, T): the per-stage buffers (skip connections, concatenation slices, zero halos)
+    must be re-established on every geometry change -- shrinking, growing, batch changes, a 1-frame input."""
+    from oracle import refinegan_ref
+    cfg = dict(refinegan_ref.CONFIG)
+    cfg.update(start_channels=8)                                    # small net: the geometry handling is what is under test
+    sd = refinegan_ref.seeded_state(33, cfg)
+    gen = _refinegan(cfg, sd, dev)
+    g = torch.Generator().manual_seed(4)
+    for B, T in ((1, 12), (2, 5), (1, 40), (3, 1), (1, 12), (2, 33)):
+        mel = torch.randn(B, cfg.get("num_mels", 128), T, generator=g) * 0.5 - 2.0
+        f0 = torch.stack([synth_f0(T, 44100 / 256) * (1.0 + 0.2 * b) for b in range(B)])
+        if B > 1:
+            f0[-1] = 0.0                                            # an unvoiced item
+        noises = [torch.randn(s, generator=g) for s in gen.noise_shapes(B, T)]
+        with torch.no_grad():
+            ref = refinegan_ref.generator_forward(sd, cfg, mel, f0[:, None], noises)
+        wav = gen(mel.to(dev), f0.to(dev), noises=[n.to(dev) for n in noises])
+        assert wav.shape == ref.shape and abs_err(wav.cpu(), ref) < WAV_ABS, (B, T)
+
+
 def test_hifisinger_end_to_end_matches_reference_golden(dev):
     """svc_hifisinger_v2's model (archs/hifisinger/core.py): encoders -> feature_fuser -> RefineGAN generator, features and
     waveform vs the reference's own code on real encoder / generator instances (oracle/make_golden.py)."""
