@@ -360,6 +360,26 @@ def test_generator_batch_and_resblock2_vs_oracle(dev):
         assert abs_err(wav.cpu(), ref) < WAV_ABS, h["resblock"]
 
 
+def test_generator_geometry_sequence_on_one_instance_vs_oracle(dev):
+    """One NSF-HiFiGAN generator across changing (B, T): per-stage buffers, zero halos and the blocked fp64 scans must be
+    re-established on every geometry change (grow, shrink, batch change, a single frame)."""
+    from oracle import nsf_hifigan_ref
+    h = dict(nsf_hifigan_ref.CONFIG_V1)
+    gsd = nsf_hifigan_ref.seeded_generator_state(79, h)
+    voc = _vocoder(h, gsd, dev)
+    g = torch.Generator().manual_seed(10)
+    for B, T in ((1, 9), (2, 3), (1, 30), (3, 1), (1, 9), (2, 17)):
+        mel = torch.randn(B, 128, T, generator=g) * 0.5 - 2.0
+        f0 = torch.stack([synth_f0(T) * (1 + 0.3 * i) for i in range(B)])
+        ri = torch.rand(B, 9, generator=g)
+        ri[:, 0] = 0
+        sn = torch.randn(B, T * 512, 9, generator=g)
+        with torch.no_grad():
+            ref = nsf_hifigan_ref.generator_forward(gsd, h, mel, f0, ri, sn)
+        wav = voc.model(mel.to(dev), f0.to(dev), rand_ini=ri.to(dev), src_noise=sn.to(dev))
+        assert wav.shape == ref.shape and abs_err(wav.cpu(), ref) < WAV_ABS, (B, T)
+
+
 # ------------------------------------------------------------------------------------------------ STFT / mel
 def test_mel_matches_reference_golden(dev):
     from fish_diffusion_amd import PitchAdjustableMelSpectrogram, _lib
