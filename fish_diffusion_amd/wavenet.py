@@ -130,7 +130,8 @@ class HipDenoiser(nn.Module):
         def ident(t):
             return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype)
         with eng.lock:   # callers that go on to use the prepared state hold the same (re-entrant) lock across both steps
-            sig = (ident(conditioner), ident(cond_masks), self._packed_sig)
+            # (the stream is part of the identity: work hoisted on one stream is not ordered before a run on another)
+            sig = (ident(conditioner), ident(cond_masks), self._packed_sig, torch.cuda.current_stream(conditioner.device).cuda_stream)
             if sig != self._prep_sig:
                 B, E, T = conditioner.shape
                 if E != self._cond_channels:
