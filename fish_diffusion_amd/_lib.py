@@ -75,6 +75,9 @@ _SIGS = {
     "fdx_wavenet_packed_bytes": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(C.c_size_t)]),
     "fdx_wavenet_pack": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(_P), C.c_int, _P, C.c_size_t]),
     "fdx_wavenet_attach": (C.c_int, [_P, C.POINTER(WavenetDesc), _P, C.c_size_t]),
+    "fdx_wavenet_bf16_packed_bytes": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(C.c_size_t)]),
+    "fdx_wavenet_bf16_pack": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(_P), C.c_int, _P, C.c_size_t]),
+    "fdx_wavenet_bf16_attach": (C.c_int, [_P, _P, C.c_size_t]),
     "fdx_wavenet_prepare": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "fdx_wavenet_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
     "fdx_convnext_num_weights": (C.c_int, [C.POINTER(ConvNextDesc)]),

@@ -276,6 +276,56 @@ struct EpiResSkip {  // wavenet.py:117-120 + the skip sum of :228
   }
 };
 
+// ------------------------------------------------------------------------------------------ bf16 storage mode (opt-in)
+// Activations of the two residual-block GEMMs in "C8-blocked" bf16: element (channel c, column t) of an item lives at
+// ((c >> 3) * ld + t) * 8 + (c & 7), i.e. one 16-byte group holds 8 consecutive channels of one column -- exactly the B operand
+// of v_mfma_f32_32x32x16_bf16 (lane = column, 8 consecutive k).  Accumulation, gates, residual stream and skip sum stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void stb2(__bf16* base, int ld, int c, int t, f2 v, bool two) {
+  __bf16* p = base + ((long)(c >> 3) * ld + t) * 8 + (c & 7);
+  p[0] = (__bf16)v.x;
+  p[8] = (__bf16)(two ? v.y : 0.f);      // next column, same channel (column T of an odd-length row gets its zero)
+}
+
+struct EpiGateB : EpiGate {  // as EpiGate, the gated output goes to the blocked bf16 operand of the out-projection
+  __bf16* outb; long ob_bs;   // [B][C/8][ld][8], item stride in bf16 elements
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 g, f2 f, const Pre& p) const {
+    if (row >= C) return;
+    g += p.pg; f += p.pf;
+    stb2(outb + b * ob_bs, ldo, row, t, f2{gate1(g.x, f.x), gate1(g.y, f.y)}, two);
+  }
+};
+
+struct EpiResSkipB : EpiResSkip {  // as EpiResSkip; the next conv's input Y = X + step goes out as blocked bf16
+  __bf16* Yb; long yb_bs;
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p{f2{0.f, 0.f}, 0.f, 0.f};
+    p.bias = bias[row];
+    if (is_res(row)) {
+      p.old = ld2(X + b * bs + (long)row * ld + t, two);
+      if (Yb) p.sb = sb[(long)row * sb_ld + b * sb_bs];
+    } else if (skip_mode == 1 || skip_mode == 2) {
+      p.old = ld2(SK + b * bs + (long)(row - C) * ld + t, two);
+    }
+    return p;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
+    v += p.bias;
+    if (is_res(row)) {
+      const long o = b * bs + (long)row * ld + t;
+      const f2 xn = div_const(p.old + v, 1.41421356237309504880f, 0.70710678118654752440f);
+      st2p_keep(X + o, xn, two);
+      if (Yb) stb2(Yb + b * yb_bs, ld, row, t, xn + p.sb, two);
+    } else {
+      const long o = b * bs + (long)(row - C) * ld + t;
+      f2 s = v;
+      if (skip_mode == 1 || skip_mode == 2) s = p.old + v;
+      if (skip_mode >= 2) s = div_const(s, inv_div, r_inv_div);
+      st2p_keep(SK + o, s, two);
+    }
+  }
+};
+
 struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) + bias); masked_fill(x_masks)
   static constexpr bool kPaired = false;
   float* X; long bs; int ld;                 // residual in, result out (in place), padded rows
@@ -387,11 +437,12 @@ struct EpiLogMel {  // audio.py:11-18 + nsf_hifigan.py:104-105
 // Accumulator element r of a 32x32 tile sits at row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31.
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+constexpr int OPK_F32 = 0, OPK_BF16 = 1;   // operand kind: fp32 rows (32x32x2 MFMA) / C8-blocked bf16 (32x32x16 MFMA)
 constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result transforms (a bool converts: false/true = none/lrelu)
 
 // (PRE_LN keeps its statistics in registers across the K loop: the second launch-bounds argument holds that instantiation to
 // the 256 VGPRs that let two workgroups share a CU, like every other instantiation already does unprompted.)
-template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1>
+template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32>
 __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
   a.tiles_per_item = (a.T + (SPLITK ? 63 : 255)) / (SPLITK ? 64 : 256);
@@ -508,6 +559,68 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
   };
 
   const bool active = SPLITK ? true : (t0 < a.T);   // whole-wave overhang tiles skip the K loop
+  if constexpr (OPK == OPK_BF16) {
+    // ---- bf16 operands: one K iteration = 16 channels of one tap = ONE v_mfma_f32_32x32x16_bf16 per accumulator block.
+    // A: packed [m_tile][it][rb][lane] 16 B = 8 bf16 (k = 8*half .. +7 of row li); B: the lane's column, channel block
+    // 2*cb16 + half, one 16-byte group.  Same register ring and saturating cursors as the fp32 loop below.
+    static_assert(PRE == PRE_NONE && MT == 1, "bf16 operands: plain contraction only");
+    if (active && it_begin < it_end) {
+      struct StageB { bf16x8 a[RBX]; bf16x8 b[NB]; };
+      const int n = it_end - it_begin;
+      const int cb0 = it_begin / a.taps, tap0 = it_begin - cb0 * a.taps;
+      const char* Abase = reinterpret_cast<const char*>(a.Wp + ((long)mtg * a.n_it + it_begin) * (RB * 64));
+      const char* Xbase = reinterpret_cast<const char*>(a.X + item * a.x_bstride) + (long)(a.shift0 + t0) * 16;
+      const unsigned rs = (unsigned)a.ldx * 16u;                 // bytes between 8-channel blocks
+      const unsigned d_tap = (unsigned)a.dshift * 16u;
+      const unsigned d_wrap = 2u * rs - (unsigned)(a.taps - 1) * d_tap;
+      const int itl = it_end - 1, cbl = itl / a.taps, tapl = itl - cbl * a.taps;
+      const unsigned a_last = (unsigned)(n - 1) * (RB * 1024u);
+      const unsigned x_last = (unsigned)cbl * 2u * rs + (unsigned)tapl * d_tap;
+      unsigned a_off = 0, x_off = (unsigned)cb0 * 2u * rs + (unsigned)tap0 * d_tap;
+      int tap = tap0;
+      const unsigned a_lane = lane * 16u;
+      unsigned x_lane[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) x_lane[nb] = (unsigned)half * rs + (unsigned)(2 * li + nb) * 16u;
+      auto load = [&](StageB& s) {
+#pragma unroll
+        for (int x = 0; x < RBX; ++x) s.a[x] = *reinterpret_cast<const bf16x8*>(Abase + (a_off + a_lane + x * 1024u));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) s.b[nb] = *reinterpret_cast<const bf16x8*>(Xbase + (x_off + x_lane[nb]));
+        const bool wrap = tap + 1 == a.taps;
+        a_off = min(a_off + RB * 1024u, a_last);
+        x_off = min(x_off + (wrap ? d_wrap : d_tap), x_last);
+        tap = wrap ? 0 : tap + 1;
+      };
+      auto compute = [&](StageB& s) {
+#pragma unroll
+        for (int x = 0; x < RBX; ++x)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s.a[x], s.b[nb], acc[x][nb], 0, 0, 0);
+      };
+      constexpr int D = 4;
+      StageB st[D];
+#pragma unroll
+      for (int d = 0; d < D - 1; ++d) load(st[d]);
+      __builtin_amdgcn_sched_barrier(0);
+      prefetch_epilogue();
+      __builtin_amdgcn_sched_barrier(0);
+      int done = 0;
+      for (; done + D <= n; done += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          load(st[(d + D - 1) % D]);
+          compute(st[d]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < D - 1; ++d)
+        if (done + d < n) compute(st[d]);
+    } else {
+      prefetch_epilogue();
+    }
+  } else
   if (active && it_begin < it_end) {
     struct Stage { float4 a[RBX]; f2 b[4]; };
     // Wave-uniform bases (SGPR pairs) + 32-bit byte cursors (SGPR) + per-lane 32-bit byte offsets (VGPR).  The cursors
@@ -710,7 +823,7 @@ struct ConvGeom {   // everything the launcher needs besides pointers
   int n_mtiles;     // row tiles of 32*RB logical rows (32 pairs for paired epilogues)
 };
 
-template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1>
+template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32>
 inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx,
                                   float in_slope, const Epi& epi, hipStream_t s, hipEvent_t ev_start = nullptr,
                                   hipEvent_t ev_stop = nullptr, const float* col_stats = nullptr, const float* ln_R = nullptr,
@@ -734,10 +847,10 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
-    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0,
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0,
                           FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT>), dim3(grid), dim3(NW * 64), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK>), dim3(grid), dim3(NW * 64), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 

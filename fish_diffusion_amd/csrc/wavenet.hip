@@ -200,6 +200,111 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
   return FDX_OK;
 }
 
+// ================================================================================================ bf16 storage mode (opt-in)
+// BASELINE configs[4] ("bf16, 1000-step schedule, batch 128") as SURVEY F4 reads it: bf16 storage, fp32 accumulation.  Only the two
+// residual-block GEMMs (94 % of the FLOPs) change: their weights are packed as bf16 fragments of v_mfma_f32_32x32x16_bf16 and
+// their activation operands (conv input Y = x + step, gated output Z) are stored C8-blocked bf16; the residual stream, the skip
+// sum, the conditioner slab, gates and every accumulation stay fp32.  It cannot meet the fp32 parity bars (bf16 has 8 mantissa
+// bits); its error is measured and reported separately (tests) -- never the headline.
+struct WnBf16Layout {
+  std::vector<size_t> conv, outp;   // offsets in 16-byte units
+  size_t total16 = 0;
+  int conv_mt = 0, outp_mt = 0, conv_it = 0, outp_it = 0;
+};
+static void wn_bf16_layout(const fdx_wavenet_desc& d, WnBf16Layout& l) {
+  const int C = d.residual_channels, L = d.residual_layers;
+  l.conv_mt = C / 32; l.outp_mt = 2 * C / 64; l.conv_it = (C / 16) * 3; l.outp_it = C / 16;
+  size_t cur = 0;
+  l.conv.clear(); l.outp.clear();
+  for (int i = 0; i < L; ++i) {
+    l.conv.push_back(cur); cur += (size_t)l.conv_mt * l.conv_it * 2 * 64;
+    l.outp.push_back(cur); cur += (size_t)l.outp_mt * l.outp_it * 2 * 64;
+  }
+  l.total16 = cur;
+}
+static uint16_t f32_to_bf16(float f) {   // round to nearest even
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));   // inf / nan
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+extern "C" int fdx_wavenet_bf16_packed_bytes(const fdx_wavenet_desc* d, size_t* bytes) {
+  if (wn_validate(d) || !bytes) return FDX_E_ARG;
+  if (d->residual_channels % 64) return fail(nullptr, FDX_E_ARG, "bf16 mode: residual_channels must be a multiple of 64");
+  WnBf16Layout l;
+  wn_bf16_layout(*d, l);
+  *bytes = l.total16 * 16;
+  return FDX_OK;
+}
+
+// Same tensor list as fdx_wavenet_pack; only conv_layer.conv.weight and output_projection.conv.weight of each layer are read.
+extern "C" int fdx_wavenet_bf16_pack(const fdx_wavenet_desc* d, const float* const* w, int n, void* out, size_t bytes) {
+  size_t want = 0;
+  if (int rc = fdx_wavenet_bf16_packed_bytes(d, &want)) return rc;
+  if (!w || !out || n != fdx_wavenet_num_weights(d) || bytes != want) return fail(nullptr, FDX_E_ARG, "fdx_wavenet_bf16_pack: bad arguments");
+  WnBf16Layout l;
+  wn_bf16_layout(*d, l);
+  uint16_t* A = static_cast<uint16_t*>(out);
+  const int C = d->residual_channels, L = d->residual_layers, lb = d->use_linear_bias ? 1 : 0;
+  int k = 2 + 2 * (1 + lb);
+  for (int i = 0; i < L; ++i) {
+    const float* conv_w = w[k];            // [2C][C][3]
+    const float* op_w = w[k + 2 + 1 + lb + 2];   // conv(w,b), dproj(w[,b]), cond(w,b), outp(w,b)
+    k += 6 + 1 + lb;
+    for (int mt = 0; mt < l.conv_mt; ++mt)
+      for (int it = 0; it < l.conv_it; ++it) {
+        const int cb = it / 3, tap = it % 3;
+        for (int rb = 0; rb < 2; ++rb)
+          for (int lane = 0; lane < 64; ++lane) {
+            uint16_t* dst = A + (l.conv[i] + (((size_t)mt * l.conv_it + it) * 2 + rb) * 64 + lane) * 8;
+            const int row = rb * C + mt * 32 + (lane & 31);   // rb 0: gate half, rb 1: filter half of channel mt*32 + i
+            for (int j = 0; j < 8; ++j) {
+              const int c = cb * 16 + 8 * (lane >> 5) + j;
+              dst[j] = f32_to_bf16(conv_w[((size_t)row * C + c) * 3 + tap]);
+            }
+          }
+      }
+    for (int mt = 0; mt < l.outp_mt; ++mt)
+      for (int it = 0; it < l.outp_it; ++it)
+        for (int rb = 0; rb < 2; ++rb)
+          for (int lane = 0; lane < 64; ++lane) {
+            uint16_t* dst = A + (l.outp[i] + (((size_t)mt * l.outp_it + it) * 2 + rb) * 64 + lane) * 8;
+            const int row = mt * 64 + rb * 32 + (lane & 31);
+            for (int j = 0; j < 8; ++j) dst[j] = f32_to_bf16(op_w[(size_t)row * C + it * 16 + 8 * (lane >> 5) + j]);
+          }
+  }
+  return FDX_OK;
+}
+
+// dev_packed == NULL switches the handle back to fp32.  fdx_wavenet_attach must have been called first (biases, the other
+// projections and the conditioner slab GEMM come from the fp32 arena).
+extern "C" int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev, size_t bytes) {
+  if (!h) return FDX_E_ARG;
+  if (!h->wn_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_bf16_attach: attach the fp32 arena first");
+  if (dev) {
+    size_t want = 0;
+    if (int rc = fdx_wavenet_bf16_packed_bytes(&h->wd, &want)) { h->err = g_last_error; return rc; }
+    if (bytes != want) return fail(h, FDX_E_ARG, "bf16 arena size mismatch");
+  }
+  h->wn_arena_bf16 = dev;
+  h->prepared = false;    // the blocked operand buffers are sized in prepare
+  ++g_alloc_generation;   // recorded sampler graphs bake the kernel choice in
+  return FDX_OK;
+}
+
+// Y [B][C][ld] fp32 -> C8-blocked bf16 (the input projection's second output, once per denoiser call)
+static __global__ void k_to_blocked_bf16(__bf16* __restrict__ dst, long d_bs, const float* __restrict__ src, long s_bs, int ld, int C, int T) {
+  const int t = blockIdx.x * kEwBlock + threadIdx.x;
+  if (t >= T) return;
+  const int b = blockIdx.y / (C / 8), cb = blockIdx.y - b * (C / 8);
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (__bf16)src[b * s_bs + (long)(cb * 8 + j) * ld + t];
+  *reinterpret_cast<bf16x8*>(dst + b * d_bs + ((long)cb * ld + t) * 8) = v;
+}
+
 // ================================================================================================ launch helpers
 // (An 8-wave variant -- 2 K-splitting waves per SIMD, convgemm_kernel<..., NW = 8> -- was measured on the batch-1
 // denoiser: 2 % SLOWER than 4 waves.  The K loop's residual stall is per-CU operand throughput, not latency, so a second
@@ -247,6 +352,11 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
   FDX_HIP(h, h->condp.ensure(sz(E), geom, s));
   FDX_HIP(h, h->P.ensure(sz(L * 2 * C), geom, s));
+  if (h->wn_arena_bf16) {   // blocked bf16 operands: same columns (and zero halos) as the fp32 rows, 2 bytes per element
+    const bool gb = geom || h->Yb.cap < sz(C) / 2;
+    FDX_HIP(h, h->Yb.ensure(sz(C) / 2, gb, s));
+    FDX_HIP(h, h->Zb.ensure(sz(C) / 2, gb, s));
+  }
   return FDX_OK;
 }
 
@@ -330,6 +440,9 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     e.out2 = Y; e.o2_bs = bsC; e.ldo2 = ld; e.sb = S; e.sb_ld = ldn; e.sb_bs = sb_bs;
     FDX_HIP(h, (run_gemm<true, false>(A, l.in_proj, B, T, xin, (long)M * ld, ld, 0, 0, 1.f, e, s)));
   }
+  if (h->wn_arena_bf16)
+    hipLaunchKernelGGL(k_to_blocked_bf16, ew_grid(T, B * (C / 8)), dim3(kEwBlock), 0, s, reinterpret_cast<__bf16*>(h->Yb.p) + (size_t)kHalo * 8,
+                       (long)C * ld, Y, bsC, ld, C, T);
   const float sqrtL = (float)std::sqrt((double)L);
   for (int i = 0; i < L; ++i) {
     const int dil = l.dil[i];
@@ -348,6 +461,29 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     const long p_bs = (long)L * 2 * C * ld;
     const float* sbn = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn;
     const int skip_mode = (L == 1) ? 3 : (i == 0 ? 0 : (i + 1 == L ? 2 : 1));
+    if (h->wn_arena_bf16) {   // bf16 storage mode: both GEMMs on v_mfma_f32_32x32x16_bf16
+      WnBf16Layout bl;
+      wn_bf16_layout(d, bl);
+      const float4* WB = static_cast<const float4*>(h->wn_arena_bf16);
+      __bf16* Yb = reinterpret_cast<__bf16*>(h->Yb.p) + (size_t)kHalo * 8;
+      __bf16* Zb = reinterpret_cast<__bf16*>(h->Zb.p) + (size_t)kHalo * 8;
+      const long bsB = (long)C * ld;               // bf16 elements per item
+      EpiGateB g{};
+      g.out = Z; g.o_bs = bsC; g.ldo = ld; g.P = Pl; g.p_bs = p_bs; g.ldp = ld; g.C = C;
+      g.outb = Zb; g.ob_bs = bsB;
+      const ConvGeom gc{B, T, C / 16, 3, -dil, dil, bl.conv_mt};
+      FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiGateB, 4, 1, OPK_BF16>(gc, WB + bl.conv[i], reinterpret_cast<const float*>(Yb),
+                                                                              bsB / 2, ld, 1.f, g, s)));
+      EpiResSkipB r{};
+      r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
+      r.Y = nullptr; r.sb = sbn; r.sb_ld = ldn; r.sb_bs = sb_bs;
+      r.skip_mode = skip_mode; r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
+      r.Yb = (i + 1 < L) ? Yb : nullptr; r.yb_bs = bsB;
+      const ConvGeom go{B, T, C / 16, 1, 0, 0, bl.outp_mt};
+      FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkipB, 4, 1, OPK_BF16>(go, WB + bl.outp[i], reinterpret_cast<const float*>(Zb),
+                                                                                 bsB / 2, ld, 1.f, r, s)));
+      continue;
+    }
     if (conv16()) {
       const ConvGeom gc{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles};
       EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};

@@ -114,6 +114,10 @@ class HipDenoiser(nn.Module):
         self._arena = arena
         self._prep_sig = None
         self._packed_sig = self._signature()
+        self._after_attach()
+
+    def _after_attach(self):
+        """Hook: extra arenas that ride on the main one (WaveNet's bf16 storage mode)."""
 
     def packed_arena(self, device) -> torch.Tensor:
         self.engine(torch.device(device))
@@ -202,7 +206,41 @@ class WaveNet(HipDenoiser):
         self._desc = _lib.WavenetDesc(mel_channels, d_encoder, residual_channels, residual_layers,
                                       int(dilation_cycle or 0), int(self.use_linear_bias))
         self._cond_channels = d_encoder
+        self._storage = "fp32"
+        self._arena_bf16 = None
         self._init_engine()
+
+    # ------------------------------------------------------------------ opt-in bf16 storage mode
+    @property
+    def storage(self) -> str:
+        """"fp32" (default, parity-grade) or "bf16": the two residual-block GEMMs read bf16 weights / activation operands and
+        accumulate in fp32 (BASELINE configs[4]).  Not parity-grade; see DESIGN.md for its measured error."""
+        return self._storage
+
+    @storage.setter
+    def storage(self, mode: str):
+        if mode not in ("fp32", "bf16"):
+            raise ValueError(f"storage must be 'fp32' or 'bf16', got {mode!r}")
+        if mode != self._storage:
+            self._storage = mode
+            self._prep_sig = None
+            if self._handle is not None and self._arena is not None:
+                self._after_attach()
+
+    def _after_attach(self):
+        l = _lib.lib()
+        if self._storage == "bf16":
+            nb = C.c_size_t()
+            _lib.check(l.fdx_wavenet_bf16_packed_bytes(C.byref(self._desc), C.byref(nb)))
+            keep, arr = _lib.host_ptr_array(self._params())
+            host = torch.empty(nb.value, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            _lib.check(l.fdx_wavenet_bf16_pack(C.byref(self._desc), arr, len(keep), C.c_void_p(host.data_ptr()), nb))
+            del keep
+            self._arena_bf16 = host.to(self._handle.device)
+            _lib.check(l.fdx_wavenet_bf16_attach(self._handle.h, _lib.ptr(self._arena_bf16), self._arena_bf16.numel()), self._handle.h)
+        elif self._arena_bf16 is not None:
+            _lib.check(l.fdx_wavenet_bf16_attach(self._handle.h, None, 0), self._handle.h)
+            self._arena_bf16 = None
 
 
 DENOISERS.register_module(name="WaveNetDenoiser", module=WaveNet, force=True)

@@ -81,6 +81,14 @@ int fdx_wavenet_pack(const fdx_wavenet_desc* d, const float* const* host_weights
  * by one RCCL broadcast and attach them -- see fish_diffusion_amd/dist.py. */
 int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const void* dev_packed, size_t bytes);
 
+/* Opt-in bf16 storage mode (BASELINE configs[4] as SURVEY F4 reads it: "bf16 storage / fp32 accumulate"): the two residual-block
+ * GEMMs read bf16 weights and bf16 activation operands through v_mfma_f32_32x32x16_bf16; everything else stays fp32.  Not
+ * parity-grade (8 mantissa bits): its error is measured and reported separately, it is never the headline path.
+ * pack: same tensor list as fdx_wavenet_pack.  attach: after fdx_wavenet_attach; dev_packed = NULL switches back to fp32. */
+int fdx_wavenet_bf16_packed_bytes(const fdx_wavenet_desc* d, size_t* bytes);
+int fdx_wavenet_bf16_pack(const fdx_wavenet_desc* d, const float* const* host_weights, int n_weights, void* host_packed, size_t bytes);
+int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev_packed, size_t bytes);
+
 /* Step-invariant work for one batch of utterances (conditioner slabs for all layers, wavenet.py:108).
  * cond: dev [B][d_encoder][T]; cond_mask: dev [B][T] bytes (1 = masked, wavenet.py:220-221) or NULL. */
 int fdx_wavenet_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask,

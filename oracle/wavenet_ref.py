@@ -75,24 +75,40 @@ def step_mlp(sd: SD, t: torch.Tensor, C: int) -> torch.Tensor:
     return F.linear(e, sd["mlp.2.linear.weight"], sd.get("mlp.2.linear.bias"))
 
 
-def residual_block(sd: SD, i: int, x, cond, step, dilation: int):
-    """wavenet.py:106-120."""
+def residual_block(sd: SD, i: int, x, cond, step, dilation: int, operand_round=None):
+    """wavenet.py:106-120.  (`operand_round`: see bf16_storage_model -- None for the reference arithmetic.)"""
     p = f"residual_layers.{i}."
     s = F.linear(step, sd[p + "diffusion_projection.linear.weight"],
                  sd.get(p + "diffusion_projection.linear.bias")).unsqueeze(-1)
     c = F.conv1d(cond, sd[p + "conditioner_projection.conv.weight"], sd[p + "conditioner_projection.conv.bias"])
     y = x + s
+    if operand_round is not None:
+        y = operand_round(y)
     y = F.conv1d(y, sd[p + "conv_layer.conv.weight"], sd[p + "conv_layer.conv.bias"],
                  padding=dilation, dilation=dilation) + c
     gate, filt = torch.chunk(y, 2, dim=1)
     y = torch.sigmoid(gate) * torch.tanh(filt)
+    if operand_round is not None:
+        y = operand_round(y)
     y = F.conv1d(y, sd[p + "output_projection.conv.weight"], sd[p + "output_projection.conv.bias"])
     residual, skip = torch.chunk(y, 2, dim=1)
     return (x + residual) / math.sqrt(2.0), skip
 
 
+def bf16_storage_model(sd: SD) -> "tuple[SD, callable]":
+    """NOT a reference function: a CPU model of the library's opt-in bf16 storage mode (BASELINE configs[4] "bf16 storage,
+    fp32 accumulate"), used only to tell rounding policy from layout bugs.  Returns (state with the two residual-block GEMM
+    weights rounded to bf16, rounding function for their activation operands)."""
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    sd2 = dict(sd)
+    for k in sd:
+        if k.startswith("residual_layers.") and (k.endswith("conv_layer.conv.weight") or k.endswith("output_projection.conv.weight")):
+            sd2[k] = rb(sd[k])
+    return sd2, rb
+
+
 def wavenet_forward(sd: SD, x, diffusion_step, conditioner, x_masks=None, cond_masks=None, *,
-                    residual_layers=20, dilation_cycle=None, taps=None):
+                    residual_layers=20, dilation_cycle=None, taps=None, operand_round=None):
     """wavenet.py:194-236.  x [B,M,T] (or [B,1,M,T]); diffusion_step [B]; conditioner [B,E,T].
 
     ``taps``: optional dict that receives intermediate activations (for per-layer parity tests).
@@ -113,7 +129,7 @@ def wavenet_forward(sd: SD, x, diffusion_step, conditioner, x_masks=None, cond_m
         taps["x_in"] = x
     skips = []
     for i, d in enumerate(layer_dilations(residual_layers, dilation_cycle)):
-        x, s = residual_block(sd, i, x, conditioner, step, d)
+        x, s = residual_block(sd, i, x, conditioner, step, d, operand_round)
         skips.append(s)
         if taps is not None:
             taps[f"x_{i}"] = x
