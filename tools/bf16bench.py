@@ -16,7 +16,7 @@ diff.step_rng = "philox"
 T = 861
 feats = bench.synth_inputs(B, T, dev, 0)[0]
 x0 = torch.randn(B, 128, T, device=dev)
-sn = torch.randn(1000 // interval, B, 128, T, device=dev) if pred == "naive" and B * (1000 // interval) <= 400 else None
+sn = torch.randn(1000 // interval, B, 128, T, device=dev) if pred == "naive" and B * (1000 // interval) <= 1000 else None
 out = {}
 for mode in ("fp32", "bf16"):
     diff.denoise_fn.storage = mode

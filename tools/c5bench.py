@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] as SURVEY F4 reads it, in the precision this library has (fp32): DDPM ("naive") sampler with
 sampler_interval=1 => 1000 denoiser calls, multi-speaker front end (speaker-embedding table), one rank's share of the
-batch-128 job over 8 GPUs = 16 utterances of 10 s, then the vocoder.  The bf16 storage mode the config names is not built
-(DESIGN.md "What comes next"); this records what the fp32 path does on that shape."""
+batch-128 job over 8 GPUs = 16 utterances of 10 s, then the vocoder.  Third argument "bf16" selects the opt-in bf16 storage mode the config names (fp32 is the default)."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +11,7 @@ from fish_diffusion_amd import DiffSinger, pitch_to_scale  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+storage = sys.argv[3] if len(sys.argv) > 3 else "fp32"      # "bf16": the opt-in storage mode the config names
 dev = torch.device("cuda", 0)
 diff, voc = bench.seeded_modules(dev)
 voc.model.rng = "philox"
@@ -22,6 +22,7 @@ cfg = dict(text_encoder=dict(type="NaiveProjectionEncoder", input_size=256, outp
 m = DiffSinger(cfg).to(dev).eval()
 m.diffusion = diff                                   # the seeded full-size denoiser of bench.py
 diff.step_rng = "philox"                             # per-step noise from the device generator (no [1000, B, M, T] tensor)
+diff.denoise_fn.storage = storage
 T = 861
 g = torch.Generator().manual_seed(5)
 contents = torch.randn(B, T, 256, generator=g).to(dev)
@@ -38,5 +39,5 @@ for rep in range(2):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     fl = steps * B * T * 95.18e6
-    print(f"pass {rep}: B={B}, {steps} naive steps: denoise {1e3*(t1-t0):.0f} ms ({fl/(t1-t0)/1e12:.1f} TFLOP/s = {fl/(t1-t0)/157.3e12*100:.1f} % of the fp32 roof), "
+    print(f"pass {rep} [{storage}]: B={B}, {steps} naive steps: denoise {1e3*(t1-t0):.0f} ms ({fl/(t1-t0)/1e12:.1f} TFLOP/s = {fl/(t1-t0)/157.3e12*100:.1f} % of the fp32 roof), "
           f"vocoder {1e3*(t2-t1):.0f} ms -> {B*10/(t2-t0):.2f}x real-time per GPU; finite: {bool(torch.isfinite(wav).all())}")
