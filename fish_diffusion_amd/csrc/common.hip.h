@@ -100,6 +100,7 @@ struct fdx_ctx {
   fdx::DevBuf xin, X, Y, Z, SK, H, EPS, P, condp, condraw, P2;
   const void* wn_arena_bf16 = nullptr;   // opt-in bf16 storage mode: residual-block weights as bf16 fragments (wavenet.hip)
   fdx::DevBuf Yb, Zb;                    // ... and the two GEMM operands in C8-blocked bf16
+  int bf16_B = 0, bf16_T = 0;            // geometry Yb / Zb were last zeroed for
   bool cond_masked = false; int condraw_ld = 0;
   fdx::DevBuf tdev, E, Hm, S0, S;      // step-embedding pipeline; ldn below
   int n_emb = 0, ldn = 0;

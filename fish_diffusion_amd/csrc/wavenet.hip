@@ -353,9 +353,11 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   FDX_HIP(h, h->condp.ensure(sz(E), geom, s));
   FDX_HIP(h, h->P.ensure(sz(L * 2 * C), geom, s));
   if (h->wn_arena_bf16) {   // blocked bf16 operands: same columns (and zero halos) as the fp32 rows, 2 bytes per element
-    const bool gb = geom || h->Yb.cap < sz(C) / 2;
+    // (their own geometry stamp: the geometry may have changed while the handle ran in fp32 mode, which does not touch them)
+    const bool gb = B != h->bf16_B || T != h->bf16_T;
     FDX_HIP(h, h->Yb.ensure(sz(C) / 2, gb, s));
     FDX_HIP(h, h->Zb.ensure(sz(C) / 2, gb, s));
+    h->bf16_B = B; h->bf16_T = T;
   }
   return FDX_OK;
 }

@@ -183,6 +183,26 @@ def test_wavenet_bf16_storage_mode(dev):
             assert torch.equal(again, fp32) and rel_err(fp32, ref32) < 2e-5
 
 
+def test_bf16_storage_mode_under_the_sampler(dev):
+    """The opt-in mode through GaussianDiffusion (recorded graphs are keyed on it): UniPC / PLMS with masks and a geometry change;
+    the mel stays bf16-close to the fp32 path's and switching back reproduces fp32 bit for bit."""
+    sd = wavenet_sd(WN_SMALL, 101)
+    diff = _diffusion(WN_SMALL, sd, dev)
+    g = torch.Generator().manual_seed(17)
+    for B, T, pred in ((2, 45, "unipc"), (1, 130, "plms"), (2, 45, "unipc")):
+        feats, x0 = torch.randn(B, T, 256, generator=g).to(dev), torch.randn(B, 128, T, generator=g).to(dev)
+        m = torch.zeros(B, T, dtype=torch.bool, device=dev)
+        m[-1, T - 9:] = True
+        kw = dict(sampler_interval=50, noise_predictor=pred, x_masks=m, cond_masks=m, x_init=x0)
+        a = diff(feats, **kw)
+        diff.denoise_fn.storage = "bf16"
+        b1, b2 = diff(feats, **kw), diff(feats, **kw)            # second run replays the recorded graph
+        diff.denoise_fn.storage = "fp32"
+        a2 = diff(feats, **kw)
+        assert torch.equal(a, a2) and torch.equal(b1, b2)
+        assert torch.isfinite(b1).all() and 0 < rel_err(b1.cpu(), a.cpu()) < 3e-2, (B, T, pred)
+
+
 def test_wavenet_ragged_lengths_vs_oracle(dev):
     """T not a multiple of any tile size, T smaller than the receptive field, B > 1 with per-item timesteps."""
     cfg = WN_SMALL
