@@ -195,9 +195,14 @@ def main():
                     "overlaps the sampler of k+1).  Measured on MI355X: 96.3 vs 95.0 ms per step -- no gain, the co-running "
                     "vocoder kernels slow the denoiser's by as much as they hide; off by default.")
     ap.add_argument("--no-prof", action="store_true", help="do not time the dominant kernel with HIP events")
+    ap.add_argument("--storage", choices=("fp32", "bf16"), default="fp32",
+                    help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype, "
+                         "no roofline / cpu_baseline -- the contract's line is the fp32 default")
     ap.add_argument("--prof-stride", type=int, default=7, help="time every N-th launch of the dominant kernel (7 is co-prime "
                     "with the 20 layers, so every layer / dilation is sampled)")
     args = ap.parse_args()
+    if args.storage == "bf16":
+        args.no_prof = args.no_cpu_baseline = True
 
     from fish_diffusion_amd import _lib, dist as fdist
     import ctypes as C
@@ -217,6 +222,8 @@ def main():
     t0 = time.perf_counter()
     fdist.broadcast_model_weights(diff.denoise_fn, voc.model, dev, src=0)
     torch.cuda.synchronize()
+    if args.storage == "bf16":   # after the (fp32) arenas are in place: every rank packs its own bf16 copy of the two GEMMs' weights
+        diff.denoise_fn.storage = "bf16"
     t_bcast = time.perf_counter() - t0
     voc.model.rng = "philox"          # perf mode: source noise drawn on the device inside the library
     feats, f0 = synth_inputs(args.batch, T, dev, 1234 + rank)
@@ -289,7 +296,7 @@ def main():
                   f"audio-seconds/sec ({n_steps}-step denoise + NSF-HiFiGAN, 44.1 kHz)",
         "value": round(value, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded N(0,1) features, vibrato f0 with an unvoiced gap; random-init weights of the named architecture)",
+        "dtype": "f32" if args.storage == "fp32" else "bf16 storage / f32 accumulate (opt-in mode, not parity-grade)", "data": "synthetic (seeded N(0,1) features, vibrato f0 with an unvoiced gap; random-init weights of the named architecture)",
         "config": {"workload": f"svc_hubert_soft (diff_svc_v2 WaveNet C=512 x 20 layers) {n_steps}-step UniPC + NSF-HiFiGAN config_v1 (hop 512), "
                                f"batch={args.batch} x {args.seconds:g} s @44.1 kHz (T={T}) per GPU",
                    "batch_per_gpu": args.batch, "frames": T, "sampler": "unipc", "sampler_steps": n_steps,
