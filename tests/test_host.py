@@ -487,3 +487,69 @@ def test_tfdec_contract_and_packing(lib):
     np.testing.assert_allclose(run(ca_kv), (W[D:] @ xv + b[D:, None]).numpy(), rtol=1e-4, atol=1e-5)
     Ws, bs = sd["layers.0.self_attn.in_proj_weight"], sd["layers.0.self_attn.in_proj_bias"]
     np.testing.assert_allclose(run(sa_in), (Ws @ xv + bs[:, None]).numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ opt-in bf16 storage mode: packing + blocked operand layout
+def test_wavenet_bf16_packing_and_blocked_layout_match_kernel_index_math(lib):
+    """numpy emulation of the bf16 K loop of convgemm_kernel<..., OPK_BF16> (v_mfma_f32_32x32x16_bf16 operand maps: lane (half, i)
+    holds row / column i and the 8 consecutive k = 8*half .. 8*half+7) over the arena written by fdx_wavenet_bf16_pack and a
+    C8-blocked bf16 activation buffer, against F.conv1d on the same bf16-rounded operands."""
+    from fish_diffusion_amd import WaveNet
+    net = WaveNet(**WN_SMALL)
+    sd = wavenet_sd(WN_SMALL, 3)
+    net.load_state_dict(sd)
+    nb = C.c_size_t()
+    lib.check(lib.lib().fdx_wavenet_bf16_packed_bytes(C.byref(net._desc), C.byref(nb)))
+    keep, arr = lib.host_ptr_array(net._params())
+    raw = np.zeros(nb.value // 2, np.uint16)
+    lib.check(lib.lib().fdx_wavenet_bf16_pack(C.byref(net._desc), arr, len(keep), C.c_void_p(raw.ctypes.data), nb))
+    arena = (raw.astype(np.uint32) << 16).view(np.float32)                     # bf16 -> fp32, exact
+    Cc, L = 64, 4
+    conv_mt, outp_mt, conv_it, outp_it = Cc // 32, 2 * Cc // 64, (Cc // 16) * 3, Cc // 16
+    per_layer = (conv_mt * conv_it + outp_mt * outp_it) * 2 * 64 * 8
+    assert arena.size == L * per_layer
+    rb16 = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    T, halo, ld = 40, 32, 32 + 64 + 32
+    g = torch.Generator().manual_seed(0)
+    y = rb16(torch.randn(Cc, T, generator=g))
+    Yb = np.zeros((Cc // 8, ld, 8), np.float32)                                # element (c, t) at [c >> 3][halo + t][c & 7]
+    for c in range(Cc):
+        Yb[c >> 3, halo:halo + T, c & 7] = y[c].numpy()
+
+    def contract(frags, n_it, taps, shift0, dshift):                           # frags [n_it][2 rb][64 lanes][8]; one 64-column tile at t0 = 0
+        acc = np.zeros((2, 2, 32, 32))                                         # [rb][nb][row i][column n]
+        n = np.arange(32)
+        for it in range(n_it):
+            cb16, tap = divmod(it, taps)
+            for half in range(2):
+                for nbk in range(2):
+                    col = halo + 2 * n + nbk + shift0 + tap * dshift            # lane n owns the column pair (2n, 2n+1)
+                    Bk = Yb[2 * cb16 + half][col]                               # [32 columns][8 k]
+                    for rb in range(2):
+                        A = frags[it, rb, half * 32:half * 32 + 32]             # [32 rows][8 k]
+                        acc[rb, nbk] += A.astype(np.float64) @ Bk.T.astype(np.float64)
+        out = np.zeros((2, 32, 64))
+        out[:, :, 0::2], out[:, :, 1::2] = acc[:, 0], acc[:, 1]
+        return out[:, :, :T]
+
+    layer, dil = 1, 2                                                           # layer 1: dilation 2
+    base = layer * per_layer
+    conv = arena[base:base + conv_mt * conv_it * 2 * 64 * 8].reshape(conv_mt, conv_it, 2, 64, 8)
+    W = rb16(sd[f"residual_layers.{layer}.conv_layer.conv.weight"])
+    ref = F.conv1d(y[None].double(), W.double(), None, padding=dil, dilation=dil)[0].numpy()
+    for mt in range(conv_mt):
+        got = contract(conv[mt], conv_it, 3, -dil, dil)
+        np.testing.assert_allclose(got[0], ref[mt * 32:mt * 32 + 32], rtol=1e-6, atol=1e-6)                    # gate rows
+        np.testing.assert_allclose(got[1], ref[Cc + mt * 32:Cc + mt * 32 + 32], rtol=1e-6, atol=1e-6)          # filter rows
+    o0 = base + conv_mt * conv_it * 2 * 64 * 8
+    outp = arena[o0:o0 + outp_mt * outp_it * 2 * 64 * 8].reshape(outp_mt, outp_it, 2, 64, 8)
+    Wo = rb16(sd[f"residual_layers.{layer}.output_projection.conv.weight"][:, :, 0])
+    refo = (Wo.double() @ y.double()).numpy()
+    for mt in range(outp_mt):
+        got = contract(outp[mt], outp_it, 1, 0, 0)
+        np.testing.assert_allclose(np.concatenate([got[0], got[1]]), refo[mt * 64:mt * 64 + 64], rtol=1e-6, atol=1e-6)
+    # the storage switch itself is host state until a device exists
+    net.storage = "bf16"
+    assert net.storage == "bf16"
+    with pytest.raises(ValueError):
+        net.storage = "fp16"
