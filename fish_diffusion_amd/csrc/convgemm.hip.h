@@ -287,12 +287,28 @@ __device__ __forceinline__ void stb2(__bf16* base, int ld, int c, int t, f2 v, b
   p[8] = (__bf16)(two ? v.y : 0.f);      // next column, same channel (column T of an odd-length row gets its zero)
 }
 
+// four consecutive channels c0 .. c0+3 (c0 % 4 == 0) of the column pair (t, t+1): one 8-byte store per column -- the four
+// accumulator rows r = 4q .. 4q+3 a lane owns are exactly such a quad (acc_row), so a wave's split-K sites group naturally
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stb2x4(__bf16* base, int ld, int c0, int t, const f2 (&v)[4], bool two) {
+  __bf16* p = base + ((long)(c0 >> 3) * ld + t) * 8 + (c0 & 7);
+  *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0].x, (__bf16)v[1].x, (__bf16)v[2].x, (__bf16)v[3].x};
+  *reinterpret_cast<bf16x4*>(p + 8) = two ? bf16x4{(__bf16)v[0].y, (__bf16)v[1].y, (__bf16)v[2].y, (__bf16)v[3].y}
+                                           : bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+}
+
 struct EpiGateB : EpiGate {  // as EpiGate, the gated output goes to the blocked bf16 operand of the out-projection
+  static constexpr bool kQuad = true;   // the kernel hands over a wave's four sites at once (store4)
   __bf16* outb; long ob_bs;   // [B][C/8][ld][8], item stride in bf16 elements
-  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 g, f2 f, const Pre& p) const {
-    if (row >= C) return;
+  __device__ __forceinline__ f2 value(f2 g, f2 f, const Pre& p) const {
     g += p.pg; f += p.pf;
-    stb2(outb + b * ob_bs, ldo, row, t, f2{gate1(g.x, f.x), gate1(g.y, f.y)}, two);
+    return f2{gate1(g.x, f.x), gate1(g.y, f.y)};
+  }
+  __device__ __forceinline__ void store4(int b, int row0, int t, bool two, const f2 (&v)[4]) const {
+    stb2x4(outb + b * ob_bs, ldo, row0, t, v, two);
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 g, f2 f, const Pre& p) const {   // per-site form
+    if (row < C) stb2(outb + b * ob_bs, ldo, row, t, value(g, f, p), two);
   }
 };
 
@@ -309,13 +325,14 @@ struct EpiResSkipB : EpiResSkip {  // as EpiResSkip; the next conv's input Y = X
     }
     return p;
   }
-  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
+  static constexpr bool kQuadY = true;   // fp32 stores per site; the bf16 operand of the next conv in quads (store_y4)
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p, f2& yv) const {
     v += p.bias;
     if (is_res(row)) {
       const long o = b * bs + (long)row * ld + t;
       const f2 xn = div_const(p.old + v, 1.41421356237309504880f, 0.70710678118654752440f);
       st2p_keep(X + o, xn, two);
-      if (Yb) stb2(Yb + b * yb_bs, ld, row, t, xn + p.sb, two);
+      yv = xn + p.sb;
     } else {
       const long o = b * bs + (long)(row - C) * ld + t;
       f2 s = v;
@@ -323,6 +340,14 @@ struct EpiResSkipB : EpiResSkip {  // as EpiResSkip; the next conv's input Y = X
       if (skip_mode >= 2) s = div_const(s, inv_div, r_inv_div);
       st2p_keep(SK + o, s, two);
     }
+  }
+  __device__ __forceinline__ void store_y4(int b, int row0, int t, bool two, const f2 (&v)[4]) const {
+    if (Yb && is_res(row0)) stb2x4(Yb + b * yb_bs, ld, row0, t, v, two);
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {   // per-site form (non-split tiles)
+    f2 yv{0.f, 0.f};
+    store(b, row, t, two, v, p, yv);
+    if (Yb && is_res(row)) stb2(Yb + b * yb_bs, ld, row, t, yv, two);
   }
 };
 
@@ -753,9 +778,17 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
 #pragma unroll
         for (int w = 1; w < NW; ++w) sum[i] += *reinterpret_cast<const f4*>(red + ridx(w, r) + 4 * mtl);
       }
+      if constexpr (OPK == OPK_BF16) {
+        static_assert(NS == 4, "a wave's four sites = one channel quad");
+        f2 v[4];
 #pragma unroll
-      for (int i = 0; i < NS; ++i)
-        epi.store(item, site_row(wave * NS + i), tc, col_two, f2{sum[i][0], sum[i][1]}, f2{sum[i][2], sum[i][3]}, pre[i]);
+        for (int i = 0; i < 4; ++i) v[i] = epi.value(f2{sum[i][0], sum[i][1]}, f2{sum[i][2], sum[i][3]}, pre[i]);
+        epi.store4(item, site_row(wave * NS), tc, col_two, v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+          epi.store(item, site_row(wave * NS + i), tc, col_two, f2{sum[i][0], sum[i][1]}, f2{sum[i][2], sum[i][3]}, pre[i]);
+      }
     } else {
       f2 sum[NS];
 #pragma unroll
@@ -792,8 +825,19 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if constexpr (OPK == OPK_BF16) {
+        static_assert(NS == 8, "a wave's eight sites = two channel quads");
+        f2 y[8];
 #pragma unroll
-      for (int i = 0; i < NS; ++i) epi.store(item, site_row(wave * NS + i), tc, col_two, sum[i], pre[i]);
+        for (int i = 0; i < 8; ++i) { y[i] = f2{0.f, 0.f}; epi.store(item, site_row(wave * NS + i), tc, col_two, sum[i], pre[i], y[i]); }
+        const f2 (&ya)[4] = *reinterpret_cast<const f2 (*)[4]>(&y[0]);
+        const f2 (&yb)[4] = *reinterpret_cast<const f2 (*)[4]>(&y[4]);
+        epi.store_y4(item, site_row(wave * NS), tc, col_two, ya);
+        epi.store_y4(item, site_row(wave * NS + 4), tc, col_two, yb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) epi.store(item, site_row(wave * NS + i), tc, col_two, sum[i], pre[i]);
+      }
     }
     FDX_STAMP(5);
   } else {
