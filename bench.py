@@ -1,28 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path's headline metric on MI355X.
+"""bench.py -- the hot path's metrics on MI355X, one JSON line per run.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|vocoder|sharded|ddpm1000]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): audio-seconds/sec (100-step denoise + NSF-HiFiGAN, 44.1 kHz).
-One "step" = one batch of synthetic utterances through the whole path with the inputs already in HBM:
-    features [B,T,256] + f0 [B,T]  ->  x_T ~ N(0,1)  ->  100-step UniPC sampler driving the WaveNet denoiser
-    ->  denorm  ->  NSF-HiFiGAN (config_v1, hop 512)  ->  waveform [B, T*512]
-Workload at N=1 = BASELINE configs[1]: svc_hubert_soft arch (diff_svc_v2: C=512, 20 layers), batch=1, 10 s @ 44.1 kHz
-(T=861), sampler_interval=10.  With N>1 every rank runs the same per-GPU workload on its own utterances
-(weak scaling; utterances are independent -- SURVEY 8e); the only collective is the start-up RCCL broadcast of
-the packed weights (outside the timed region) and the max-over-ranks of the wall time.
+`--config` selects a BASELINE.json `configs[]` entry (default: the one the headline metric is quoted on):
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the dilated-conv + gate MFMA kernel of the
-residual block, 60 % of all FLOPs): algorithmic FLOPs per launch / its average launch duration measured with HIP
-events on the launch stream inside the timed region; the bound is the fp32 MFMA roof (157.3 TFLOP/s: the path is
-fp32 for parity and compute-bound by 8-19x).  `cpu_baseline` is the CPU oracle (the pinned restatement of
-the reference's PyTorch path, torch CPU ops) timed on this box's host cores on a bounded sample.
+  headline  (configs[1]; aliases 1, c1)   svc_hubert_soft arch (diff_svc_v2 WaveNet C=512 x 20 layers), batch 1 x 10 s @ 44.1 kHz
+            (T=861), 100-step UniPC, then NSF-HiFiGAN config_v1 (hop 512).  One step = one utterance: features [1,T,256] + f0 ->
+            x_T ~ N(0,1) -> sampler -> denorm -> vocoder -> waveform [1, T*512].  Every timed step gets a FRESH feature tensor,
+            so the hoisted conditioner GEMM (`fdx_wavenet_prepare`) runs inside the timed region, as it does per utterance when
+            serving.
+  vocoder   (configs[2]; aliases 2, c2)   NSF-HiFiGAN only, tools/nsf_hifigan/config_v1_256.json (hop 256: what
+            configs/vocoder_nsf_hifigan.py:31 points at), batch 32 x 10 s mel (T=1722).  One step = one batch.
+  sharded   (configs[3]; aliases 3, c3, c4)   svc_content_vec (same model): 64 ragged utterances of 6-10 s, sharded longest-first
+            over the ranks, masked micro-batches of <= 8 through `pipeline.synthesize`, 100-step UniPC + vocoder.  One step =
+            this rank's whole shard.  With one process the shard is rank 0's share of an 8-way job (`--virtual-world`).
+  ddpm1000  (configs[4]; aliases 4, c5)   1000-step DDPM ("naive", sampler_interval=1), speaker-embedding front end, 16 x 10 s
+            utterances per GPU (= batch 128 over 8 GPUs), then the vocoder; fp32, or `--storage bf16` for the opt-in bf16 storage
+            mode the config names (labelled as such, never parity-grade).
+
+Inputs are resident in HBM when the timed region starts; `value` is the whole-job aggregate over all ranks (weak scaling: every
+rank runs the same per-GPU workload on its own utterances; the only collective is the start-up RCCL broadcast of the packed
+weights, outside the timed region, and the MAX over ranks of the wall time).  `pcie_inclusive` (headline only) repeats the step
+with features / f0 starting in pinned host memory and the waveform copied back: reported beside `value`, never as `value`.
+
+`roofline` is for the config's dominant kernel: algorithmic FLOPs per launch / average launch duration from HIP events recorded
+on the launch stream inside the timed region (`fdx_prof_*`), against the fp32 MFMA roof (157.3 TFLOP/s: the path is fp32 for
+parity and compute-bound); `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of the same
+command (profiles/).  `cpu_baseline` = the CPU oracle (pinned restatement of the reference's PyTorch path, torch CPU ops) timed
+on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
+import glob
 import json
 import math
 import os
@@ -40,13 +54,28 @@ NSF_V1 = dict(resblock="1", upsample_rates=[8, 8, 2, 2, 2], upsample_kernel_size
               upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
               resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_mels=128, n_fft=2048, hop_size=512,
               win_size=2048, sampling_rate=44100, fmin=40, fmax=16000)  # tools/nsf_hifigan/config_v1.json
+NSF_V1_256 = dict(NSF_V1, upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], hop_size=256)  # config_v1_256.json
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix == vector peak
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
+BASELINE_METRIC = "audio-seconds/sec/GPU (100-step denoise + NSF-HiFiGAN, 44.1 kHz)"   # BASELINE.json "metric", verbatim
+
+ALIASES = {"headline": "headline", "1": "headline", "c1": "headline", "configs1": "headline",
+           "vocoder": "vocoder", "2": "vocoder", "c2": "vocoder", "configs2": "vocoder",
+           "sharded": "sharded", "3": "sharded", "c3": "sharded", "c4": "sharded", "configs3": "sharded",
+           "ddpm1000": "ddpm1000", "4": "ddpm1000", "c5": "ddpm1000", "configs4": "ddpm1000"}
+DEFAULT_STEPS = {"headline": (5, 2), "vocoder": (5, 2), "sharded": (3, 1), "ddpm1000": (2, 1)}
 
 
+# ====================================================================================================== algorithmic work
 def wavenet_flops_per_frame(c=WN_CFG):
-    C, L, M, E = c["residual_channels"], c["residual_layers"], c["mel_channels"], c["d_encoder"]
-    return 2.0 * (M * C + L * (3 * C * 2 * C + E * 2 * C + C * 2 * C) + C * C + C * M)
+    C_, L, M, E = c["residual_channels"], c["residual_layers"], c["mel_channels"], c["d_encoder"]
+    return 2.0 * (M * C_ + L * (3 * C_ * 2 * C_ + E * 2 * C_ + C_ * 2 * C_) + C_ * C_ + C_ * M)
+
+
+def wavenet_hoisted_flops_per_frame(c=WN_CFG):
+    """The step-invariant part of the above: the L conditioner projections (wavenet.py:108), executed once per utterance."""
+    return 2.0 * c["residual_layers"] * c["d_encoder"] * 2 * c["residual_channels"]
 
 
 def nsf_flops_per_sample(h=NSF_V1):
@@ -68,74 +97,64 @@ def nsf_flops_per_sample(h=NSF_V1):
     return total
 
 
-def seeded_modules(device, seed=1234):
+def e2e_flops(frames_total, n_steps, samples_total, n_utt_frames_hoist, h=NSF_V1, denoise=True):
+    """(algorithmic, executed) FLOPs of one bench step.  Algorithmic = the reference's op count (every step pays the
+    conditioner projections).  Executed = what the device ran: the conditioner projections once per utterance."""
+    voc = nsf_flops_per_sample(h) * samples_total
+    if not denoise:
+        return voc, voc
+    alg = wavenet_flops_per_frame() * frames_total * n_steps + voc
+    return alg, alg - wavenet_hoisted_flops_per_frame() * n_utt_frames_hoist * (n_steps - 1)
+
+
+# ====================================================================================================== modules and inputs
+def seeded_modules(device, seed=1234, nsf=None, denoiser=True):
     """Random-init weights of the named architecture (no checkpoints exist offline).  The reference zero-inits the
     final projection (wavenet.py:192) and N(0,0.01)-inits the vocoder, which would make every activation ~0: use
     fan-in scaled draws so the data flowing through the kernels has O(1) magnitude (DVFS sees realistic toggling)."""
     from fish_diffusion_amd import DIFFUSIONS, NsfHifiGAN
     from fish_diffusion_amd.nsf_hifigan import generator_param_table
+    nsf = nsf or NSF_V1
     torch.manual_seed(seed)
-    diff = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_CFG),
-                                 spec_min=[-5], spec_max=[0], sampler_interval=10))
-    torch.nn.init.normal_(diff.denoise_fn.output_projection.conv.weight, std=0.02)
+    diff = None
+    if denoiser:
+        diff = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_CFG),
+                                     spec_min=[-5], spec_max=[0], sampler_interval=10))
+        torch.nn.init.normal_(diff.denoise_fn.output_projection.conv.weight, std=0.02)
+        diff = diff.to(device).eval()
     g = torch.Generator().manual_seed(seed + 1)
     state = {}
-    for key, shape, _ in generator_param_table(NSF_V1):
+    for key, shape, _ in generator_param_table(nsf):
         if key.endswith("bias") or len(shape) < 3:
             state[key] = torch.randn(shape, generator=g) * 0.01
         else:
-            fan_in = shape[1] * shape[2] if "ups." not in key else shape[0] * shape[2] / max(1, NSF_V1["upsample_rates"][int(key.split(".")[1])])
+            fan_in = shape[1] * shape[2] if "ups." not in key else shape[0] * shape[2] / max(1, nsf["upsample_rates"][int(key.split(".")[1])])
             state[key] = torch.randn(shape, generator=g) * math.sqrt(1.0 / max(1.0, fan_in))
-    voc = NsfHifiGAN.from_state(NSF_V1, state, use_natural_log=False)
-    return diff.to(device).eval(), voc.to(device).eval()
+    voc = NsfHifiGAN.from_state(nsf, state, use_natural_log=False)
+    return diff, voc.to(device).eval()
+
+
+def synth_f0(T, frame_rate=44100 / 512):
+    """220 * 2^(0.3 sin(2 pi 0.7 t)) Hz with frames 100-130 unvoiced."""
+    t = torch.arange(T, dtype=torch.float32) / frame_rate
+    f0 = 220.0 * torch.pow(2.0, 0.3 * torch.sin(2 * math.pi * 0.7 * t))
+    f0[100:130] = 0.0
+    return f0
 
 
 def synth_inputs(B, T, device, seed):
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(B, T, 256, generator=g)
-    t = torch.arange(T, dtype=torch.float32) / (44100 / 512)
-    f0 = 220.0 * torch.pow(2.0, 0.3 * torch.sin(2 * math.pi * 0.7 * t))
-    f0[100:130] = 0.0
-    return feats.to(device), f0[None].repeat(B, 1).contiguous().to(device)
+    return feats.to(device), synth_f0(T)[None].repeat(B, 1).contiguous().to(device)
 
 
 def one_step(diff, voc, feats, f0, interval, streams=None):
-    """One utterance batch: sampler, then vocoder.  With `streams` = (s_den, s_voc) the two stages are enqueued on
-    separate HIP streams (vocoder waits on an event): consecutive steps are independent utterances, so the vocoder of
-    step k overlaps the sampler of step k+1 and fills the CUs the batch-1 denoiser leaves idle (224 tiles / 256 CUs)."""
-    if streams is None:
-        mel = diff(feats, sampler_interval=interval)                       # [B, T, M] (log10-scale mel, diff_svc_v2)
-        return voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)     # spec2wav for a batch (nsf_hifigan.py:72-85)
-    s_den, s_voc = streams
-    with torch.cuda.stream(s_den):
-        mel = diff(feats, sampler_interval=interval)
-        done = torch.cuda.Event()
-        done.record(s_den)
-    with torch.cuda.stream(s_voc):
-        s_voc.wait_event(done)
-        mel.record_stream(s_voc)
-        wav = voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)
-    return wav
+    """One utterance batch: sampler, then vocoder (kept for tools/*: the headline config's step)."""
+    mel = diff(feats, sampler_interval=interval)                       # [B, T, M] (log10-scale mel, diff_svc_v2)
+    return voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)     # spec2wav for a batch (nsf_hifigan.py:72-85)
 
 
-def pmc_traffic(batch: int, T: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.py ->
-    profiles/*_pmc_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so bench.py cannot collect them
-    itself).  Only valid for the configuration the counters were collected on (batch 1, T = 861)."""
-    if batch != 1 or T != 861:
-        return None, None
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    for k, v in d["kernels"].items():
-        if "EpiGate" in k:
-            return v["hbm_bytes"], os.path.relpath(files[-1], ROOT)
-    return None, None
-
-
+# ====================================================================================================== helpers
 def usable_cores() -> int:
     """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box is a
     256-thread EPYC with a 16-CPU quota: 256 torch threads there oversubscribe 16x and run ~5x slower than 16)."""
@@ -149,63 +168,137 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(diff, voc, T, seconds, n_steps, sample_steps):
-    """The oracle (restatement of the reference PyTorch path, same torch CPU ops) on this box's host cores.
-    Bounded sample: `sample_steps` of the `n_steps` UniPC steps at full length + the full vocoder pass; the rest of
-    the sampler is extrapolated linearly (every step is the same denoiser call)."""
-    from oracle import nsf_hifigan_ref, sampler_ref, wavenet_ref
+TRAFFIC_KEYS = {"convgate": ("EpiGate",), "outproj": ("EpiResSkip",), "nsf_resblock": ("2, false, 1, EpiResblock",)}
+
+
+def pmc_traffic(config: str, kernel: str, expect: dict):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json;
+    FETCH_SIZE and WRITE_SIZE need separate passes, so bench.py cannot collect them itself).  A file is only used for the
+    workload it was collected on: its "workload" record must equal `expect` (files without one are the round-1 headline files:
+    batch 1, T = 861)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        wl = d.get("workload", {"config": "headline", "batch": 1, "frames": 861})
+        if wl != expect:
+            continue
+        for k, v in d["kernels"].items():
+            if any(s in k for s in TRAFFIC_KEYS[kernel]):
+                return v["hbm_bytes"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def prof_begin(handle, kind, stride):
+    from fish_diffusion_amd import _lib
+    _lib.check(_lib.lib().fdx_prof_select(handle.h, kind), handle.h)
+    _lib.check(_lib.lib().fdx_prof_enable(handle.h, stride), handle.h)
+
+
+def prof_pause(handle):
+    from fish_diffusion_amd import _lib
+    _lib.check(_lib.lib().fdx_prof_enable(handle.h, -1), handle.h)
+
+
+def prof_end(handle):
+    """(launches, avg_ms, flops_per_launch) of the launches recorded since prof_begin."""
+    from fish_diffusion_amd import _lib
+    n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+    _lib.check(_lib.lib().fdx_prof_read(handle.h, C.byref(n), C.byref(ms), C.byref(fl)), handle.h)
+    _lib.check(_lib.lib().fdx_prof_enable(handle.h, 0), handle.h)
+    if not n.value:
+        return 0, 0.0, 0.0
+    return n.value, ms.value / n.value, fl.value
+
+
+def roofline_entry(kernel_desc, n, avg_ms, flops, peak, sampling, traffic=None, traffic_src=None, alg_bytes=None):
+    ach = flops / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": kernel_desc, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+            "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
+            "hbm_fraction": (round(traffic / (avg_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if traffic else None),
+            "launches_timed": n, "sampling": sampling, "avg_launch_us": round(avg_ms * 1e3, 2),
+            "timing": "hipExtLaunchKernel start/stop events on the launch stream, timed region", "flops_per_launch": flops}
+
+
+def cpu_denoiser(diff):
+    from oracle import wavenet_ref
+    sd = {k: v.detach().cpu() for k, v in diff.denoise_fn.state_dict().items()}
+    return lambda x, t, c, xm, cm: wavenet_ref.wavenet_forward(sd, x, t, c, xm, cm, residual_layers=WN_CFG["residual_layers"],
+                                                               dilation_cycle=WN_CFG["dilation_cycle"])
+
+
+def cpu_chain(diff, voc, nsf, T, n_steps, sample_steps, predictor=None):
+    """The oracle chain on this box's host cores for ONE utterance of T frames: `sample_steps` of the `n_steps` denoiser calls at
+    full length (the rest extrapolated linearly: every step is the same call) + the full vocoder pass."""
+    from oracle import nsf_hifigan_ref, sampler_ref
     cores = usable_cores()
     torch.set_num_threads(cores)
-    sd = {k: v.detach().cpu() for k, v in diff.denoise_fn.state_dict().items()}
-    gsd = {k: v.detach().cpu() for k, v in voc.model.state_dict().items()}
     g = torch.Generator().manual_seed(0)
-    feats, x0 = torch.randn(1, T, 256, generator=g), torch.randn(1, 128, T, generator=g)
-    den = lambda x, t, c, xm, cm: wavenet_ref.wavenet_forward(sd, x, t, c, xm, cm, residual_layers=WN_CFG["residual_layers"],  # noqa: E731
-                                                              dilation_cycle=WN_CFG["dilation_cycle"])
+    t_den = 0.0
+    hop = nsf["hop_size"]
     with torch.no_grad():
-        den(x0, torch.tensor([500.0]), feats.transpose(1, 2), None, None)   # warm-up (thread pool, MKL-DNN primitives)
-        t0 = time.perf_counter()
-        mel = sampler_ref.diffusion_sample(den, feats, x_init=x0, sampler_interval=1000 // sample_steps)
-        t_den = (time.perf_counter() - t0) / sample_steps * n_steps
-        f0 = torch.full((1, T), 220.0)
+        if diff is not None:
+            den = cpu_denoiser(diff)
+            feats, x0 = torch.randn(1, T, 256, generator=g), torch.randn(1, 128, T, generator=g)
+            den(x0, torch.tensor([500.0]), feats.transpose(1, 2), None, None)   # warm-up (thread pool, MKL-DNN primitives)
+            kw = {}
+            if predictor == "naive":
+                kw = dict(predictor="naive", step_noise=torch.randn(sample_steps, 1, 128, T, generator=g))
+            t0 = time.perf_counter()
+            mel = sampler_ref.diffusion_sample(den, feats, x_init=x0, sampler_interval=1000 // sample_steps, **kw)
+            t_den = (time.perf_counter() - t0) / sample_steps * n_steps
+            melv = 2.30259 * mel.transpose(1, 2)
+        else:
+            melv = torch.randn(1, 128, T, generator=g) * 0.5 - 2.0
+        gsd = {k: v.detach().cpu() for k, v in voc.model.state_dict().items()}
+        f0 = synth_f0(T, nsf["sampling_rate"] / hop)[None]
         ri = torch.rand(1, 9, generator=g)
-        sn = torch.randn(1, T * 512, 9, generator=g)
+        sn = torch.randn(1, T * hop, 9, generator=g)
         t0 = time.perf_counter()
-        nsf_hifigan_ref.generator_forward(gsd, NSF_V1, 2.30259 * mel.transpose(1, 2), f0, ri, sn)
+        nsf_hifigan_ref.generator_forward(gsd, nsf, melv, f0, ri, sn)
         t_voc = time.perf_counter() - t0
-    return {"value": seconds / (t_den + t_voc), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"1 x {seconds:g} s utterance (T={T}): {sample_steps} of {n_steps} UniPC steps timed ({t_den / n_steps * 1e3:.0f} ms/step"
-                      + ("" if sample_steps == n_steps else f", extrapolated x{n_steps / sample_steps:g}")
-                      + f") + full NSF-HiFiGAN pass ({t_voc:.2f} s); torch {torch.__version__} CPU, {cores} threads",
-            "denoise_s": t_den, "vocoder_s": t_voc}
+    return t_den, t_voc, cores
 
 
+def flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)   # RCCL prints its version banner through C stdio: keep the JSON line the LAST line of stdout
+    except Exception:
+        pass
+
+
+# ====================================================================================================== main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (configs[1]: 1)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="headline", help="headline | vocoder | sharded | ddpm1000 (aliases: 1..4, c1 c2 c3 c5)")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (headline: 1, vocoder: 32, ddpm1000: 16)")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--interval", type=int, default=10, help="sampler_interval: 10 => 100 UniPC steps")
+    ap.add_argument("--interval", type=int, default=None, help="sampler_interval (headline / sharded: 10 => 100 UniPC steps; ddpm1000: 1)")
+    ap.add_argument("--virtual-world", type=int, default=8, help="sharded config, single process: play rank 0 of this many ranks (1 = all 64 utterances)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=100, help="UniPC steps the CPU baseline actually runs (100 = the whole "
-                    "workload, ~10 s on 16 cores; fewer steps are extrapolated linearly)")
-    ap.add_argument("--overlap", action="store_true", help="sampler and vocoder on separate HIP streams (vocoder of utterance k "
-                    "overlaps the sampler of k+1).  Measured on MI355X: 96.3 vs 95.0 ms per step -- no gain, the co-running "
-                    "vocoder kernels slow the denoiser's by as much as they hide; off by default.")
+    ap.add_argument("--cpu-sample-steps", type=int, default=None, help="denoiser calls the CPU baseline actually runs (the rest extrapolated linearly)")
     ap.add_argument("--no-prof", action="store_true", help="do not time the dominant kernel with HIP events")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive repeat of the headline step")
     ap.add_argument("--storage", choices=("fp32", "bf16"), default="fp32",
-                    help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype, "
-                         "no roofline / cpu_baseline -- the contract's line is the fp32 default")
-    ap.add_argument("--prof-stride", type=int, default=7, help="time every N-th launch of the dominant kernel (7 is co-prime "
-                    "with the 20 layers, so every layer / dilation is sampled)")
+                    help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype")
+    ap.add_argument("--prof-stride", type=int, default=None, help="time every N-th launch of the dominant kernel")
     args = ap.parse_args()
-    if args.storage == "bf16":
-        args.no_prof = args.no_cpu_baseline = True
+    cfg = ALIASES.get(str(args.config).lower())
+    if cfg is None:
+        raise SystemExit(f"unknown --config {args.config!r}")
+    steps, warmup = DEFAULT_STEPS[cfg]
+    steps = args.steps if args.steps is not None else steps
+    warmup = args.warmup if args.warmup is not None else warmup
 
-    from fish_diffusion_amd import _lib, dist as fdist
-    import ctypes as C
+    from fish_diffusion_amd import _lib, dist as fdist, pipeline
 
     rank, local_rank, world = fdist.init_process_group()
     if world != args.gpus and world > 1:
@@ -215,111 +308,268 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    T = int(args.seconds * 44100) // 512
-    n_steps = 1000 // args.interval
-    diff, voc = seeded_modules(dev)
-    # rank 0's packed weights reach the other ranks by one RCCL broadcast (outside the timed region)
-    t0 = time.perf_counter()
-    fdist.broadcast_model_weights(diff.denoise_fn, voc.model, dev, src=0)
-    torch.cuda.synchronize()
-    if args.storage == "bf16":   # after the (fp32) arenas are in place: every rank packs its own bf16 copy of the two GEMMs' weights
-        diff.denoise_fn.storage = "bf16"
-    t_bcast = time.perf_counter() - t0
-    voc.model.rng = "philox"          # perf mode: source noise drawn on the device inside the library
-    feats, f0 = synth_inputs(args.batch, T, dev, 1234 + rank)
-
-    eng = diff.denoise_fn.engine(dev)
-
     def sync_barrier():
         torch.cuda.synchronize()
         if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev)) if args.overlap else None
-    if streams:   # inputs were produced on the default stream
-        for st_ in streams:
-            st_.wait_stream(torch.cuda.current_stream(dev))
-    for _ in range(args.warmup):
-        one_step(diff, voc, feats, f0, args.interval, streams)
+    nsf = NSF_V1_256 if cfg == "vocoder" else NSF_V1
+    hop = nsf["hop_size"]
+    T = int(args.seconds * 44100) // hop
+    diff, voc = seeded_modules(dev, nsf=nsf, denoiser=cfg != "vocoder")
+    # rank 0's packed weights reach the other ranks by one RCCL broadcast (outside the timed region)
+    t0 = time.perf_counter()
+    fdist.broadcast_model_weights(diff.denoise_fn if diff is not None else None, voc.model, dev, src=0)
+    torch.cuda.synchronize()
+    t_weights = time.perf_counter() - t0
+    if args.storage == "bf16":
+        if diff is None:
+            raise SystemExit("--storage bf16 applies to the denoiser")
+        diff.denoise_fn.storage = "bf16"
+    voc.model.rng = "philox"          # perf mode: source noise drawn on the device inside the library
+    bf16 = args.storage == "bf16"
+    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+
+    n_total = steps + warmup
+    extra = {}
+    # ------------------------------------------------------------------------------------------------ per-config step
+    if cfg == "headline":
+        B = args.batch or 1
+        interval = args.interval or 10
+        n_steps = 1000 // interval
+        pool = [synth_inputs(B, T, dev, 1234 + rank + 1000 * k)[0] for k in range(n_total)]   # a fresh conditioner per step
+        f0 = synth_inputs(B, T, dev, 0)[1]
+
+        def step(k):
+            return one_step(diff, voc, pool[k], f0, interval)
+        audio_s = B * T * hop / 44100.0
+        alg, exe = e2e_flops(B * T, n_steps, B * T * hop, B * T, nsf)
+        metric = BASELINE_METRIC if n_steps == 100 else f"audio-seconds/sec/GPU ({n_steps}-step denoise + NSF-HiFiGAN, 44.1 kHz)"
+        workload = (f"BASELINE configs[1]: svc_hubert_soft (diff_svc_v2 WaveNet C=512 x 20 layers) {n_steps}-step UniPC + NSF-HiFiGAN "
+                    f"config_v1 (hop 512), batch={B} x {args.seconds:g} s @44.1 kHz (T={T}) per GPU, fresh features every step")
+        cfg_extra = {"batch_per_gpu": B, "frames": T, "sampler": "unipc", "sampler_steps": n_steps}
+        prof_handle = lambda: diff.denoise_fn.engine(dev)   # noqa: E731
+        prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 7   # 7 is co-prime with the 20 layers: every dilation sampled
+        C_, M_ = WN_CFG["residual_channels"], B * T
+        alg_bytes = 4 * (2 * C_ * 3 * C_ + C_ * M_ + 2 * C_ * M_ + C_ * M_)   # weights + Y in + conditioner slab in + Z out
+        kdesc = (("convgemm_kernel<2,splitK,OPK_BF16,EpiGateB> (v_mfma_f32_32x32x16_bf16)" if bf16 else
+                  "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + ": dilated conv k=3 + gate of the residual block")
+        traffic_key, traffic_expect = "convgate", {"config": "headline", "batch": B, "frames": T}
+    elif cfg == "vocoder":
+        B = args.batch or 32
+        n_steps = 0
+        g = torch.Generator().manual_seed(2000 + rank)
+        mels = [(torch.randn(B, 128, T, generator=g) * 0.5 - 2.0).to(dev) for _ in range(2)]
+        f0 = synth_f0(T, 44100 / hop)[None].repeat(B, 1).contiguous().to(dev)
+
+        def step(k):
+            return voc.model(mels[k & 1], f0)
+        audio_s = B * T * hop / 44100.0
+        alg, exe = e2e_flops(0, 0, B * T * hop, 0, nsf, denoise=False)
+        metric = "audio-seconds/sec/GPU (NSF-HiFiGAN vocoder only, 44.1 kHz)"
+        workload = (f"BASELINE configs[2]: NSF-HiFiGAN only, tools/nsf_hifigan/config_v1_256.json (hop 256), batch={B} x {args.seconds:g} s mel "
+                    f"(T={T}) per GPU")
+        cfg_extra = {"batch_per_gpu": B, "frames": T, "hop": hop}
+        prof_handle = lambda: voc.model.engine(dev)   # noqa: E731
+        prof_kind, stride = _lib.PROF_NSF_RESBLOCK, args.prof_stride or 5
+        alg_bytes = None
+        kdesc = ("convgemm_kernel<2,noSplit,PRE_LRELU,EpiResblock> (v_mfma_f32_32x32x2_f32): the ResBlock1 convs (k = 3/7/11, leaky-relu on the "
+                 "operand, residual / MRF mean in the epilogue) of the stages with >= 64 channels; FLOP-weighted over the launches timed")
+        traffic_key, traffic_expect = "nsf_resblock", {"config": "vocoder", "batch": B, "frames": T}
+    elif cfg == "sharded":
+        interval = args.interval or 10
+        n_steps = 1000 // interval
+        vworld = world if world > 1 else max(1, args.virtual_world)
+        vrank = rank if world > 1 else 0
+        g = torch.Generator().manual_seed(4)
+        lens = torch.randint(516, 862, (64,), generator=g).tolist()       # 6-10 s at hop 512
+        feats = [torch.randn(n, 256, generator=g).to(dev) for n in lens]
+        f0s = [synth_f0(n).to(dev) for n in lens]
+        mine = fdist.shard_utterances(lens, vrank, vworld)
+        batches = pipeline.make_batches([lens[i] for i in mine], 8)
+
+        def step(k):
+            return pipeline.synthesize(diff, voc, feats, f0s, max_batch=8, sampler_interval=interval, rank=vrank, world=vworld)
+        frames = sum(lens[i] for i in mine)
+        audio_s = frames * hop / 44100.0
+        alg, exe = e2e_flops(frames, n_steps, frames * hop, frames, nsf)
+        B = max(len(b) for b in batches)
+        metric = "audio-seconds/sec/GPU (100-step denoise + NSF-HiFiGAN, 44.1 kHz; 64 ragged utterances sharded by utterance)"
+        workload = (f"BASELINE configs[3]: svc_content_vec, 64 utterances of 6-10 s (T in [516, 861]) sharded longest-first over {vworld} ranks"
+                    + ("" if world > 1 else f" (this process = rank 0 of a virtual {vworld}-way job)")
+                    + f"; this rank: {len(mine)} utterances, {frames} frames, masked micro-batches {[len(b) for b in batches]}; {n_steps}-step UniPC + "
+                    "NSF-HiFiGAN config_v1 per utterance")
+        cfg_extra = {"utterances_total": 64, "utterances_this_rank": len(mine), "frames_this_rank": frames, "shards": vworld,
+                     "micro_batches": [len(b) for b in batches], "sampler": "unipc", "sampler_steps": n_steps}
+        prof_handle = lambda: diff.denoise_fn.engine(dev)   # noqa: E731
+        prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 7
+        alg_bytes = None
+        kdesc = "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32): dilated conv k=3 + gate of the residual block (masked micro-batches)"
+        traffic_key, traffic_expect = "convgate", {"config": "sharded", "batch": B, "frames": max(lens[i] for i in mine)}
+    else:  # ddpm1000
+        from fish_diffusion_amd import DiffSinger, pitch_to_scale
+        B = args.batch or 16
+        interval = args.interval or 1
+        n_steps = 1000 // interval
+        mcfg = dict(text_encoder=dict(type="NaiveProjectionEncoder", input_size=256, output_size=256),
+                    speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=128, output_size=256, use_embedding=True),
+                    pitch_encoder=dict(type="NaiveProjectionEncoder", input_size=1, output_size=256, preprocessing=pitch_to_scale),
+                    diffusion=dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_CFG), spec_min=[-5], spec_max=[0]))
+        torch.manual_seed(77)
+        model = DiffSinger(mcfg).to(dev).eval()
+        model.diffusion = diff                           # the seeded full-size denoiser
+        diff.step_rng = "philox"                         # per-step noise from the device generator (no [1000, B, M, T] tensor)
+        g = torch.Generator().manual_seed(5 + rank)
+        contents = [torch.randn(B, T, 256, generator=g).to(dev) for _ in range(2)]
+        f0 = synth_inputs(B, T, dev, 0)[1]
+        spk = torch.randint(0, 128, (B,), generator=g).to(dev)
+
+        def step(k):
+            mel = model.infer(spk, contents[k & 1], f0, sampler_interval=interval, noise_predictor="naive")
+            return voc.model(mel.transpose(1, 2).contiguous(), f0, mel_scale=2.30259)
+        audio_s = B * T * hop / 44100.0
+        alg, exe = e2e_flops(B * T, n_steps, B * T * hop, B * T, nsf)
+        metric = f"audio-seconds/sec/GPU ({n_steps}-step DDPM denoise + NSF-HiFiGAN, 44.1 kHz)"
+        workload = (f"BASELINE configs[4] as SURVEY F4 reads it: diff_svc_v2 WaveNet, DDPM (naive) sampler, {n_steps} denoiser calls, multi-speaker "
+                    f"front end (128-entry speaker embedding), batch={B} x {args.seconds:g} s per GPU (= batch 128 over 8 GPUs), then NSF-HiFiGAN config_v1; "
+                    + ("bf16 storage / fp32 accumulate (opt-in mode)" if bf16 else "fp32"))
+        cfg_extra = {"batch_per_gpu": B, "frames": T, "sampler": "naive (DDPM ancestral)", "sampler_steps": n_steps, "step_noise": "device Philox"}
+        prof_handle = lambda: diff.denoise_fn.engine(dev)   # noqa: E731
+        prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 97   # co-prime with 20: every layer sampled, ~200 launches
+        C_, M_ = WN_CFG["residual_channels"], B * T
+        esz = 2 if bf16 else 4
+        alg_bytes = esz * (2 * C_ * 3 * C_ + C_ * M_ + C_ * M_) + 4 * 2 * C_ * M_    # weights + Y in + Z out (+ fp32 conditioner slab)
+        kdesc = (("convgemm_kernel<2,splitK,OPK_BF16,EpiGateB> (v_mfma_f32_32x32x16_bf16)" if bf16 else
+                  "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + f": dilated conv k=3 + gate of the residual block at batch {B}")
+        traffic_key, traffic_expect = "convgate", {"config": "ddpm1000" + ("_bf16" if bf16 else ""), "batch": B, "frames": T}
+
+    # ------------------------------------------------------------------------------------------------ warm-up, timed region
+    for k in range(warmup):
+        step(k)
     sync_barrier()
-    if not args.no_prof:
-        _lib.check(_lib.lib().fdx_prof_enable(eng.h, args.prof_stride), eng.h)
+    do_prof = not args.no_prof
+    if do_prof:
+        prof_begin(prof_handle(), prof_kind, stride)
         sync_barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        wav = one_step(diff, voc, feats, f0, args.interval, streams)
-        if k == 0 and not args.no_prof:   # the dominant kernel is timed on the first timed step only (it needs the eager
-            _lib.check(_lib.lib().fdx_prof_enable(eng.h, -1), eng.h)   # launch path); the other steps replay the hipGraph
+    for k in range(steps):
+        out = step(warmup + k)
+        if k == 0 and do_prof:       # the dominant kernel is timed on the first timed step only (it needs the eager launch path);
+            prof_pause(prof_handle())   # the other steps replay the hipGraph
     sync_barrier()
     dt = time.perf_counter() - t0
     dt = fdist.barrier_max(dt, dev)
+    del out
 
     roofline = None
-    if not args.no_prof:
-        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
-        _lib.check(_lib.lib().fdx_prof_read(eng.h, C.byref(n), C.byref(ms), C.byref(fl)), eng.h)
-        _lib.check(_lib.lib().fdx_prof_enable(eng.h, 0), eng.h)
-        if n.value:
-            avg_ms = raw_ms = ms.value / n.value   # per-dispatch begin/end stamps (hipExtLaunchKernel events)
-            ach = fl.value / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(args.batch, T)
-            C_, M_ = WN_CFG["residual_channels"], args.batch * T
-            alg_bytes = 4 * (2 * C_ * 3 * C_ + C_ * M_ + 2 * C_ * M_ + C_ * M_)   # weights + Y in + conditioner slab in + Z out
-            kname = ("convgemm_kernel<2,splitK,EpiGate> (v_mfma_f32_32x32x2_f32)" if os.environ.get("FDX_RESBLOCK_MFMA") == "32"
-                     else "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)")
-            roofline = {"bound": "mfma", "kernel": kname + ": dilated conv k=3 + gate of the residual block",
-                        "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-                        "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                        "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
-                        "hbm_fraction": (round(traffic / (avg_ms * 1e-3) / 8.0e12, 4) if traffic else None), "launches_timed": n.value, "sampling": f"every {args.prof_stride}th launch of the first timed step", "avg_launch_us": round(avg_ms * 1e3, 2),
-                        "timing": "hipExtLaunchKernel start/stop events on the launch stream, timed region",
-                        "flops_per_launch": fl.value}
+    if do_prof:
+        n, avg_ms, fl = prof_end(prof_handle())
+        if n:
+            traffic, traffic_src = pmc_traffic(cfg, traffic_key, traffic_expect)
+            roofline = roofline_entry(kdesc, n, avg_ms, fl, peak, f"every {stride}th launch of the first timed step", traffic, traffic_src, alg_bytes)
 
-    # per-stage split (outside the timed region)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record()
-    mel = diff(feats, sampler_interval=args.interval)
-    ev[1].record()
-    voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)
-    ev[2].record()
-    torch.cuda.synchronize()
-    den_ms, voc_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    # ------------------------------------------------------------------------------------------------ outside the timed region
+    other = []
+    stages = None
+    if cfg in ("headline", "ddpm1000") and do_prof and not bf16 and rank == 0:   # the second residual-block kernel, one extra step
+        prof_begin(prof_handle(), _lib.PROF_WN_OUTPROJ, stride)
+        step(warmup)
+        torch.cuda.synchronize()
+        n, avg_ms, fl = prof_end(prof_handle())
+        if n:
+            tr, src = pmc_traffic(cfg, "outproj", traffic_expect)
+            e = roofline_entry("convgemm_kernel<2,splitK,EpiResSkip> (v_mfma_f32_32x32x2_f32): 1x1 out-projection + residual / skip epilogue", n,
+                               avg_ms, fl, peak, f"every {stride}th launch of one extra step outside the timed region", tr, src)
+            other.append(e)
+    if cfg == "headline":
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        mel = diff(pool[0], sampler_interval=interval)
+        ev[1].record()
+        voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)
+        ev[2].record()
+        torch.cuda.synchronize()
+        stages = {"denoise": round(ev[0].elapsed_time(ev[1]), 2), "vocoder": round(ev[1].elapsed_time(ev[2]), 2)}
+        if not args.no_pcie:      # the same step with host-resident inputs / outputs: reported beside `value`
+            hf = [p.cpu().pin_memory() for p in pool[:max(2, min(len(pool), steps))]]
+            hf0 = f0.cpu().pin_memory()
+            hw = torch.empty((B, 1, T * hop), dtype=torch.float32).pin_memory()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(steps):
+                w = one_step(diff, voc, hf[k % len(hf)].to(dev, non_blocking=True), hf0.to(dev, non_blocking=True), interval)
+                hw.copy_(w, non_blocking=True)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t1
+            extra["pcie_inclusive"] = {"value": round(steps * audio_s / dtp, 3), "ms_per_step": round(dtp / steps * 1e3, 3),
+                                       "bytes_h2d_per_step": int(hf[0].numel() * 4 + hf0.numel() * 4), "bytes_d2h_per_step": int(hw.numel() * 4),
+                                       "note": "features + f0 start in pinned host memory, waveform ends there; measured on this rank after the timed "
+                                               "region -- reported beside `value`, never as `value`"}
 
-    audio_s = args.batch * T * 512 / 44100.0
-    value = world * args.steps * audio_s / dt
-    flops_step = args.batch * (wavenet_flops_per_frame() * T * n_steps + nsf_flops_per_sample() * T * 512)
-    e2e_tflops = flops_step * args.steps / dt / 1e12
-
+    audio_all = fdist.sum_over_ranks(audio_s, dev)      # weak configs: world x audio_s; sharded: the ranks' shards differ
+    value = steps * audio_all / dt
+    alg, exe = fdist.sum_over_ranks(alg, dev) / world, fdist.sum_over_ranks(exe, dev) / world   # per-GPU means
+    e2e_alg = alg * steps / dt / 1e12
+    e2e_exe = exe * steps / dt / 1e12
     out = {
-        "metric": "audio-seconds/sec (100-step denoise + NSF-HiFiGAN, 44.1 kHz)" if n_steps == 100 else
-                  f"audio-seconds/sec ({n_steps}-step denoise + NSF-HiFiGAN, 44.1 kHz)",
-        "value": round(value, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.storage == "fp32" else "bf16 storage / f32 accumulate (opt-in mode, not parity-grade)", "data": "synthetic (seeded N(0,1) features, vibrato f0 with an unvoiced gap; random-init weights of the named architecture)",
-        "config": {"workload": f"svc_hubert_soft (diff_svc_v2 WaveNet C=512 x 20 layers) {n_steps}-step UniPC + NSF-HiFiGAN config_v1 (hop 512), "
-                               f"batch={args.batch} x {args.seconds:g} s @44.1 kHz (T={T}) per GPU",
-                   "batch_per_gpu": args.batch, "frames": T, "sampler": "unipc", "sampler_steps": n_steps,
-                   "parallelism": f"utterance-sharded x{world} (no per-step collective)",
-                   "streams": "sampler and vocoder on separate HIP streams (vocoder of utterance k overlaps sampler of k+1)"
-                              if streams else "single stream"},
+        "metric": metric, "value": round(value, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong" if (cfg == "sharded" and world > 1) else "weak", "vs_baseline": None,
+        "dtype": "f32" if not bf16 else "bf16 storage / f32 accumulate (opt-in mode, not parity-grade)",
+        "data": "synthetic (seeded N(0,1) features, vibrato f0 with an unvoiced gap; random-init weights of the named architecture)",
+        "config": dict({"workload": workload, "name": cfg,
+                        "parallelism": f"utterance-sharded x{world} (no per-step collective)"}, **cfg_extra),
+        "value_is": "whole-job aggregate over n_gpus (per_gpu = value / n_gpus); inputs resident in HBM",
         "per_gpu": round(value / world, 3), "x_realtime_per_gpu": round(value / world, 3),
-        "stages_ms": {"denoise": round(den_ms, 2), "vocoder": round(voc_ms, 2)},
-        "end_to_end": {"tflops": round(e2e_tflops, 3), "frac_of_f32_peak": round(e2e_tflops / PEAK_F32_TFLOPS, 4),
-                       "algorithmic_flops_per_step": flops_step},
-        "weights_bcast_s": round(t_bcast, 4),
+        "stages_ms": stages,
+        "end_to_end": {"tflops": round(e2e_alg, 3), "frac_of_peak": round(e2e_alg / peak, 4),
+                       "tflops_executed": round(e2e_exe, 3), "frac_of_peak_executed": round(e2e_exe / peak, 4), "peak_tflops": peak,
+                       "algorithmic_flops_per_step": alg, "executed_flops_per_step": exe,
+                       "note": "algorithmic = the reference's op count (SURVEY 8d); executed = what the device ran (the step-invariant "
+                               "conditioner projections once per utterance instead of once per sampler step)"},
+        "weights_pack_upload_s" if world == 1 and not torch.distributed.is_initialized() else "weights_pack_bcast_s": round(t_weights, 4),
         "roofline": roofline,
+        "other_kernels": other or None,
     }
+    out.update(extra)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(diff, voc, T, args.seconds, n_steps, args.cpu_sample_steps)
-        out["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cb.items()}
+        if cfg == "headline":
+            ss = args.cpu_sample_steps or 100
+            td, tv, cores = cpu_chain(diff, voc, nsf, T, n_steps, ss)
+            sample = (f"1 x {args.seconds:g} s utterance (T={T}): {ss} of {n_steps} UniPC steps timed ({td / n_steps * 1e3:.0f} ms/step"
+                      + ("" if ss == n_steps else f", extrapolated x{n_steps / ss:g}") + f") + full NSF-HiFiGAN pass ({tv:.2f} s)")
+            cpu_audio = args.seconds
+        elif cfg == "vocoder":
+            td, tv, cores = cpu_chain(None, voc, nsf, T, 0, 0)
+            sample = f"1 of the {B} x {args.seconds:g} s mels (T={T}): one full NSF-HiFiGAN config_v1_256 pass ({tv:.2f} s)"
+            cpu_audio = args.seconds
+        elif cfg == "sharded":
+            ss = args.cpu_sample_steps or 20
+            Tm = sorted(lens[i] for i in mine)[len(mine) // 2]
+            td, tv, cores = cpu_chain(diff, voc, nsf, Tm, n_steps, ss)
+            sample = (f"1 utterance of median length (T={Tm}) run alone: {ss} of {n_steps} UniPC steps timed, extrapolated x{n_steps / ss:g}, + full "
+                      f"NSF-HiFiGAN pass ({tv:.2f} s)")
+            cpu_audio = Tm * hop / 44100.0
+        else:
+            ss = args.cpu_sample_steps or 100
+            td, tv, cores = cpu_chain(diff, voc, nsf, T, n_steps, ss, predictor="naive")
+            sample = (f"1 of the {B} x {args.seconds:g} s utterances (T={T}): {ss} of {n_steps} DDPM steps timed ({td / n_steps * 1e3:.0f} ms/step, "
+                      f"extrapolated x{n_steps / ss:g}) + full NSF-HiFiGAN pass ({tv:.2f} s); fp32")
+            cpu_audio = args.seconds
+        cb = {"value": round(cpu_audio / (td + tv), 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+              "sample": sample + f"; torch {torch.__version__} CPU, {cores} threads", "denoise_s": round(td, 4), "vocoder_s": round(tv, 4)}
+        out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = round(value / cb["value"], 1)
     else:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
     if torch.distributed.is_initialized():
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        flush_c_stdio()
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

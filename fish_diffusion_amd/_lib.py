@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("FDX_LIB_PATH") or os.path.join(_HERE, "csrc", "libfis
 FDX_ROW = 16
 SAMPLER_NAIVE, SAMPLER_UNIPC, SAMPLER_PLMS = 0, 1, 2
 MEL_LINEAR, MEL_LN, MEL_LOG10 = 0, 1, 2
+PROF_WN_CONVGATE, PROF_WN_OUTPROJ, PROF_NSF_RESBLOCK = 0, 1, 2
 MAX_STAGES, MAX_RESK, MAX_DIL = 8, 4, 4
 
 
@@ -78,6 +79,7 @@ _SIGS = {
     "fdx_wavenet_bf16_packed_bytes": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(C.c_size_t)]),
     "fdx_wavenet_bf16_pack": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(_P), C.c_int, _P, C.c_size_t]),
     "fdx_wavenet_bf16_attach": (C.c_int, [_P, _P, C.c_size_t]),
+    "fdx_wavenet_bf16_from_arena": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "fdx_wavenet_prepare": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "fdx_wavenet_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
     "fdx_convnext_num_weights": (C.c_int, [C.POINTER(ConvNextDesc)]),
@@ -93,6 +95,7 @@ _SIGS = {
     "fdx_tfdec_prepare": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "fdx_tfdec_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
     "fdx_sampler_run": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_uint64, _P, _P]),
+    "fdx_q_sample": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P]),
     "fdx_denorm_spec": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "fdx_randn": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P]),
     "fdx_nsf_num_weights": (C.c_int, [C.POINTER(NsfDesc)]),
@@ -120,6 +123,7 @@ _SIGS = {
     "fdx_debug_conv1d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, _P, _P]),
     "fdx_prof_enable": (C.c_int, [_P, C.c_int]),
+    "fdx_prof_select": (C.c_int, [_P, C.c_int]),
     "fdx_prof_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fdx_prof_calibrate": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
 }

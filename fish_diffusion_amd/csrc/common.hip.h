@@ -18,8 +18,11 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // multiple of `cols` (tile overhang) plus kHalo more.  Always a multiple of 32 floats (128 B).
 inline int padded_ld(int T, int cols = 256) { return kHalo + round_up(T, cols) + kHalo; }
 
-// bumped whenever any DevBuf (re)allocates: cached hipGraphs bake buffer addresses in, so their keys include it
-inline uint64_t g_alloc_generation = 0;
+// Allocation generation of the context whose API call is running on this thread (GenScope below): bumped whenever one of ITS
+// DevBufs (re)allocates.  Recorded hipGraphs bake buffer addresses in, so their keys include the context's counter.  Per context
+// and thread-local on purpose: a process-global counter would race between handles driven from different threads (the handles
+// are only serialised per handle) and would make one handle's reallocation throw away every other handle's graphs.
+inline thread_local uint64_t* tl_alloc_gen = nullptr;
 
 struct DevBuf {
   void* p = nullptr;
@@ -37,7 +40,7 @@ struct DevBuf {
       hipError_t e = hipMalloc(&p, bytes);
       if (e != hipSuccess) { p = nullptr; return e; }
       cap = bytes;
-      ++g_alloc_generation;
+      if (tl_alloc_gen) ++*tl_alloc_gen;
     }
     if (zero && bytes) return hipMemsetAsync(p, 0, bytes, s);
     return hipSuccess;
@@ -75,13 +78,31 @@ struct NsfLayout {
   size_t total_floats = 0;
 };
 
+// Which launches fdx_prof_* times (fdx_prof_select): one kernel family at a time
+enum { PROF_WN_CONVGATE = 0,    // WaveNet: dilated conv k=3 + gate (convgemm16_kernel<EpiGate16> / convgemm_kernel<..., EpiGate>)
+       PROF_WN_OUTPROJ = 1,     // WaveNet: out-projection + residual / skip (convgemm_kernel<2,true,0,EpiResSkip>)
+       PROF_NSF_RESBLOCK = 2 }; // NSF-HiFiGAN: the ResBlock convs on convgemm_kernel<2,false,PRE_LRELU,EpiResblock> (C >= 64 stages)
 struct ProfEvents {
   bool on = false;
-  int stride = 1;          // record every stride-th launch of the dominant kernel
+  int kind = PROF_WN_CONVGATE;
+  int stride = 1;          // record every stride-th launch of the selected kernel
   long seen = 0;
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
-  double flops_per_launch = 0;
+  double flops_total = 0;  // algorithmic FLOPs of the recorded launches
+  // events for this launch, or false (not selected / not sampled).  Event-creation errors simply skip the launch.
+  bool take(int k, double flops, hipEvent_t& ev0, hipEvent_t& ev1) {
+    if (!on || k != kind || (seen++ % stride) != 0) return false;
+    if (used == start.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess) return false;
+      if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return false; }
+      start.push_back(a); stop.push_back(b);
+    }
+    ev0 = start[used]; ev1 = stop[used]; ++used;
+    flops_total += flops;
+    return true;
+  }
 };
 
 }  // namespace fdx
@@ -141,7 +162,16 @@ struct fdx_ctx {
   fdx::DevBuf scratch_a, scratch_b;   // small per-call scratch of the product paths (spec stats, rand_ini copies)
   fdx::DevBuf dbg_w, dbg_x, dbg_b;    // fdx_debug_conv1d only
   fdx::ProfEvents prof;
+  uint64_t alloc_gen = 0;             // see fdx::tl_alloc_gen
 };
+
+namespace fdx {
+struct GenScope {   // first statement of every entry point that may (re)allocate context buffers
+  uint64_t* prev;
+  explicit GenScope(fdx_ctx* h) : prev(tl_alloc_gen) { tl_alloc_gen = h ? &h->alloc_gen : nullptr; }
+  ~GenScope() { tl_alloc_gen = prev; }
+};
+}  // namespace fdx
 
 void fdx_rg_free(void* p);   // refinegan.hip
 void fdx_cn_free(void* p);   // convnext.hip

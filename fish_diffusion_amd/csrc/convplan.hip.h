@@ -41,12 +41,16 @@ inline long no_split_min_wgs() {
 
 template <bool LRELU, class Epi>
 inline hipError_t run_conv(const float* arena, const PackedW& p, int B, int T, const float* X, long x_bs, int ldx, int shift0,
-                           int dshift, float slope, const Epi& e, hipStream_t s) {
+                           int dshift, float slope, const Epi& e, hipStream_t s, ProfEvents* prof = nullptr, int prof_kind = -1) {
   ConvGeom g{B, T, p.cin8, p.taps, shift0, dshift, p.n_mtiles};
   const float4* Wp = reinterpret_cast<const float4*>(arena + p.w_off);
   const long wg_nosplit = (long)B * ((T + 255) / 256) * p.n_mtiles;
   if (p.RB == 1) return launch_convgemm<1, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
-  if (wg_nosplit >= no_split_min_wgs() || p.cin8 * p.taps < 4) return launch_convgemm<2, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
+  if (wg_nosplit >= no_split_min_wgs() || p.cin8 * p.taps < 4) {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: this instantiation is the vocoder's dominant kernel
+    if (prof) prof->take(prof_kind, 2.0 * p.rows * (8.0 * p.cin8) * p.taps * (double)B * T, ev0, ev1);
+    return launch_convgemm<2, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s, ev0, ev1);
+  }
   return launch_convgemm<2, true, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
 }
 

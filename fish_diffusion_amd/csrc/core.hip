@@ -40,6 +40,7 @@ extern "C" int fdx_create(int device, fdx_handle* out) {
 }
 
 extern "C" int fdx_destroy(fdx_handle h) {
+  GenScope gen_scope(h);
   if (!h) return FDX_OK;
   (void)hipSetDevice(h->device);
   if (h->rg) fdx_rg_free(h->rg);
@@ -59,16 +60,27 @@ extern "C" const char* fdx_last_error(fdx_handle h) {
 }
 
 extern "C" int fdx_prof_enable(fdx_handle h, int on) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (on < 0) { h->prof.on = false; return FDX_OK; }   // pause: keep what was recorded for fdx_prof_read
   h->prof.on = on != 0;
   h->prof.stride = on > 1 ? on : 1;   // on = N > 1: sample every N-th launch (keeps the probe effect out of `value`)
   h->prof.seen = 0;
   h->prof.used = 0;
+  h->prof.flops_total = 0;
+  return FDX_OK;
+}
+
+extern "C" int fdx_prof_select(fdx_handle h, int kind) {
+  GenScope gen_scope(h);
+  if (!h) return FDX_E_ARG;
+  if (kind < PROF_WN_CONVGATE || kind > PROF_NSF_RESBLOCK) return fail(h, FDX_E_ARG, "fdx_prof_select: unknown kernel family %d", kind);
+  h->prof.kind = kind;
   return FDX_OK;
 }
 
 extern "C" int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   double tot = 0;
   for (size_t i = 0; i < h->prof.used; ++i) {
@@ -79,12 +91,14 @@ extern "C" int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, do
   }
   if (n_launches) *n_launches = (int)h->prof.used;
   if (total_ms) *total_ms = tot;
-  if (flops_per_launch) *flops_per_launch = h->prof.flops_per_launch;
+  if (flops_per_launch) *flops_per_launch = h->prof.used ? h->prof.flops_total / (double)h->prof.used : 0.0;
   h->prof.used = 0;
+  h->prof.flops_total = 0;
   return FDX_OK;
 }
 
 extern "C" int fdx_prof_calibrate(fdx_handle h, fdx_stream st, double* empty_pair_ms) {
+  GenScope gen_scope(h);
   if (!h || !empty_pair_ms) return FDX_E_ARG;
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
@@ -105,6 +119,7 @@ extern "C" int fdx_prof_calibrate(fdx_handle h, fdx_stream st, double* empty_pai
 extern "C" int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, int T, const float* host_w,
                                 const float* host_bias, int Cout, int k, int dilation, float in_slope, int mode, float* y,
                                 fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h || !x || !host_w || !y) return FDX_E_ARG;
   if (B <= 0 || Cin <= 0 || T <= 0 || Cout <= 0 || k <= 0 || !(k & 1) || dilation <= 0)
     return fail(h, FDX_E_ARG, "fdx_debug_conv1d: bad geometry");

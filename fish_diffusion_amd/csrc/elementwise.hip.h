@@ -138,14 +138,14 @@ static __global__ void k_unipc_post_pre(float* __restrict__ x, float* __restrict
 // ---------------------------------------------------------------- DDPM ancestral step (noise_predictor.py:73-104)
 static __global__ void k_naive_step(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
                              long n_bs, int n_ld, long bs, int ld, int M, int T, float sr, float srm1, float c1,
-                             float c2, float nscale) {
+                             float c2, float nscale, float clip_min, float clip_max) {
   const int t = blockIdx.x * kEwBlock + threadIdx.x;
   if (t >= T) return;
   const int b = blockIdx.y / M, m = blockIdx.y % M;
   const long o = b * bs + (long)m * ld + t;
   const float xv = x[o];
   float x0 = sr * xv - srm1 * eps[o];
-  x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  x0 = fminf(fmaxf(x0, clip_min), clip_max);   // torch.clamp(min=clip_min, max=clip_max), noise_predictor.py:90
   const float mean = c1 * x0 + c2 * xv;
   x[o] = mean + nscale * noise[b * n_bs + (long)m * n_ld + t];
 }
@@ -174,6 +174,25 @@ static __global__ void k_plms_blend(float* __restrict__ out, const float* __rest
   else if (stage == 2) r = (ev * 23.f - h1[o] * 16.f + h2[o] * 5.f) / 12.f;
   else r = (ev * 55.f - h1[o] * 59.f + h2[o] * 37.f - h3[o] * 9.f) / 24.f;
   out[o] = r;
+}
+
+// ---------------------------------------------------------------- shallow-diffusion entry (diffusion.py:223-232)
+// out = q_sample(norm_spec(src)) :  v = (src - smin) / (smax - smin) * 2 - 1   (diffusion.py:315-316; the [1,1,n] stats broadcast
+// against the LAST axis of [B,M,T], exactly as the reference's expression does), then  a * v + b * noise  (:120-127).
+// Every product / quotient / sum is its own rounding (-ffp-contract=off), in the reference's order.
+static __global__ void k_q_sample(float* __restrict__ out, const float* __restrict__ src, const float* __restrict__ noise, size_t n,
+                                  int T, int normalise, const float* __restrict__ smin, const float* __restrict__ smax, int n_spec,
+                                  int do_q, float a, float b) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = src[i];
+  if (normalise) {
+    const int k = n_spec == 1 ? 0 : (int)(i % (size_t)T);
+    const float lo = smin[k], hi = smax[k];
+    v = (v - lo) / (hi - lo) * 2.f - 1.f;
+  }
+  if (do_q) v = a * v + b * noise[i];
+  out[i] = v;
 }
 
 // ---------------------------------------------------------------- denorm_spec + transpose (diffusion.py:318-319)

@@ -117,6 +117,7 @@ __global__ void k_repeat_expand(float* __restrict__ dst, const float* __restrict
 }  // namespace
 
 extern "C" int fdx_repeat_expand(fdx_handle h, const float* src, long rows, int S, int T, float* dst, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!src || !dst || rows <= 0 || S <= 0 || T <= 0 || rows > 65535) return fail(h, FDX_E_ARG, "fdx_repeat_expand: bad arguments");
   FDX_HIP(h, hipSetDevice(h->device));
@@ -128,12 +129,14 @@ extern "C" int fdx_repeat_expand(fdx_handle h, const float* src, long rows, int 
 extern "C" int fdx_features_forward(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
                                     const float* b_text, const fdx_feature_term* terms, int n_terms, float* features,
                                     fdx_stream st) {
+  GenScope gen_scope(h);
   return fdx_features_forward_ex(h, contents, B, T, Din, E, w_text, b_text, terms, n_terms, FDX_ACT_NONE, nullptr, 0, features, st);
 }
 
 extern "C" int fdx_features_forward_ex(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
                                        const float* b_text, const fdx_feature_term* terms, int n_terms, int act,
                                        const uint8_t* mask, int channel_first, float* features, fdx_stream st) {
+  GenScope gen_scope(h);
   return fdx_features_forward_src(h, contents, B, T, 0, T, Din, E, w_text, b_text, terms, n_terms, act, mask, channel_first, features, st);
 }
 
@@ -141,6 +144,7 @@ extern "C" int fdx_features_forward_src(fdx_handle h, const float* contents, int
                                         int Din, int E, const float* w_text, const float* b_text, const fdx_feature_term* terms,
                                         int n_terms, int act, const uint8_t* mask, int channel_first, float* features,
                                         fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (S <= 0) return fail(h, FDX_E_ARG, "fdx_features_forward: contents has no frames");
   if (act != FDX_ACT_NONE && act != FDX_ACT_SILU) return fail(h, FDX_E_ARG, "fdx_features_forward_ex: unknown activation %d", act);

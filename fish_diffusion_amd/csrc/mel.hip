@@ -86,6 +86,7 @@ extern "C" int fdx_mel_num_frames(const fdx_mel_desc* d, int N, float key_shift,
 }
 
 extern "C" int fdx_mel_config(fdx_handle h, const fdx_mel_desc* d) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (mel_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
   FDX_HIP(h, hipSetDevice(h->device));
@@ -147,6 +148,7 @@ static int ensure_dft(fdx_ctx* h, const StftGeom& g, hipStream_t s) {
 
 extern "C" int fdx_mel_forward(fdx_handle h, const float* wav, int B, int N, float key_shift, float speed, int log_mode,
                                float* mel, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->mel_ok) return fail(h, FDX_E_STATE, "fdx_mel_forward: call fdx_mel_config first");
   if (!wav || !mel || B <= 0 || N <= 0) return fail(h, FDX_E_ARG, "fdx_mel_forward: bad arguments");

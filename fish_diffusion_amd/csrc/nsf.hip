@@ -161,6 +161,7 @@ extern "C" int fdx_nsf_pack(const fdx_nsf_desc* d, const float* const* w, int n,
 }
 
 extern "C" int fdx_nsf_attach(fdx_handle h, const fdx_nsf_desc* d, const void* dev, size_t bytes) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (nsf_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
   NsfLayout l;
@@ -283,6 +284,7 @@ static int nsf_source_core(fdx_ctx* h, const float* f0, int B, int T, const floa
 
 extern "C" int fdx_nsf_source(fdx_handle h, const float* f0, int B, int T, const float* rand_ini, const float* src_noise,
                               uint64_t seed, float* har, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->nsf_ok) return fail(h, FDX_E_STATE, "fdx_nsf_source: no weights attached");
   if (!f0 || !har || B <= 0 || T <= 0) return fail(h, FDX_E_ARG, "fdx_nsf_source: bad arguments");
@@ -295,6 +297,7 @@ extern "C" int fdx_nsf_source(fdx_handle h, const float* f0, int B, int T, const
 // ================================================================================================ forward
 extern "C" int fdx_nsf_forward(fdx_handle h, const float* mel, const float* f0, int B, int T, float mel_scale,
                                const float* rand_ini, const float* src_noise, uint64_t seed, float* wav, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->nsf_ok) return fail(h, FDX_E_STATE, "fdx_nsf_forward: no weights attached");
   if (!mel || !f0 || !wav || B <= 0 || T <= 0) return fail(h, FDX_E_ARG, "fdx_nsf_forward: bad arguments");
@@ -354,12 +357,12 @@ extern "C" int fdx_nsf_forward(fdx_handle h, const float* mel, const float* f0, 
         if (d.resblock_type == 1) {
           EpiResblock e1{};
           e1.out = Tm; e1.resid = nullptr; e1.bs = bs; e1.ld = g.ld; e1.bias = A + st.c1[j * nd + q].b_off; e1.M = st.cout; e1.mode = 0;
-          FDX_HIP(h, (run_conv<true>(A, st.c1[j * nd + q], B, g.L, cur, bs, g.ld, -(k - 1) / 2 * dil, dil, 0.1f, e1, s)));
+          FDX_HIP(h, (run_conv<true>(A, st.c1[j * nd + q], B, g.L, cur, bs, g.ld, -(k - 1) / 2 * dil, dil, 0.1f, e1, s, &h->prof, PROF_NSF_RESBLOCK)));
           eo.resid = cur; eo.bias = A + st.c2[j * nd + q].b_off;
-          FDX_HIP(h, (run_conv<true>(A, st.c2[j * nd + q], B, g.L, Tm, bs, g.ld, -(k - 1) / 2, 1, 0.1f, eo, s)));
+          FDX_HIP(h, (run_conv<true>(A, st.c2[j * nd + q], B, g.L, Tm, bs, g.ld, -(k - 1) / 2, 1, 0.1f, eo, s, &h->prof, PROF_NSF_RESBLOCK)));
         } else {
           eo.resid = cur; eo.bias = A + st.c1[j * nd + q].b_off;
-          FDX_HIP(h, (run_conv<true>(A, st.c1[j * nd + q], B, g.L, cur, bs, g.ld, -(k - 1) / 2 * dil, dil, 0.1f, eo, s)));
+          FDX_HIP(h, (run_conv<true>(A, st.c1[j * nd + q], B, g.L, cur, bs, g.ld, -(k - 1) / 2 * dil, dil, 0.1f, eo, s, &h->prof, PROF_NSF_RESBLOCK)));
         }
         cur = R;
       }

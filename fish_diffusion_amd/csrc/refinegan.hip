@@ -194,6 +194,7 @@ extern "C" int fdx_refinegan_pack(const fdx_refinegan_desc* d, const float* cons
 }
 
 extern "C" int fdx_refinegan_attach(fdx_handle h, const fdx_refinegan_desc* d, const void* dev, size_t bytes) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (rg_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
   fdx_rg_state* st = rg(h);
@@ -250,6 +251,7 @@ int resblock(fdx_ctx* h, const float* A, const RgRes& r, int k, int cout, bool s
 // ================================================================================================ forward
 extern "C" int fdx_refinegan_forward(fdx_handle h, const float* mel, const float* f0, int B, int T, float mel_scale,
                                      const float* const* noises, uint64_t seed, float* wav, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   fdx_rg_state* S = rg(h);
   if (!S->ok) return fail(h, FDX_E_STATE, "fdx_refinegan_forward: no weights attached");

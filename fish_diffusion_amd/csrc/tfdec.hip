@@ -417,19 +417,21 @@ extern "C" int fdx_tfdec_pack(const fdx_tfdec_desc* d, const float* const* w, in
 }
 
 extern "C" int fdx_tfdec_attach(fdx_handle h, const fdx_tfdec_desc* d, const void* dev, size_t bytes) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (td_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
   fdx_td_state* S = td(h);
   td_layout(*d, S->l);
   if (!dev || bytes != S->l.total_floats * sizeof(float)) return fail(h, FDX_E_ARG, "packed arena size mismatch");
   S->d = *d; S->arena = static_cast<const float*>(dev); S->ok = true;
-  ++g_alloc_generation;   // cached sampler graphs bake the arena address in
+  ++h->alloc_gen;   // cached sampler graphs bake the arena address in
   h->prepared = false;
   return FDX_OK;
 }
 
 // ================================================================================================ prepare (hoisted condition path)
 extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   fdx_td_state* S = td(h);
   if (!S->ok) return fail(h, FDX_E_STATE, "fdx_tfdec_prepare: no weights attached");
@@ -555,6 +557,7 @@ int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
 
 extern "C" int fdx_tfdec_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask, float* eps,
                                  fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   fdx_td_state* S = td(h);
   if (!S->ok || !h->prepared || h->den_kind != 2) return fail(h, FDX_E_STATE, "fdx_tfdec_forward: call attach + prepare first");

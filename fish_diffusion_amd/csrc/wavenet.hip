@@ -186,6 +186,7 @@ extern "C" int fdx_wavenet_pack(const fdx_wavenet_desc* d, const float* const* w
 }
 
 extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const void* dev, size_t bytes) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (wn_validate(d)) { h->err = g_last_error; return FDX_E_ARG; }
   WavenetLayout l;
@@ -278,9 +279,89 @@ extern "C" int fdx_wavenet_bf16_pack(const fdx_wavenet_desc* d, const float* con
   return FDX_OK;
 }
 
+// The bf16 arena derived ON THE DEVICE from the attached fp32 arena -- the same bytes fdx_wavenet_bf16_pack produces on the host
+// from the original tensors (round to nearest even of the same fp32 values).  This is what the Python wrapper uses: a rank that
+// received its fp32 arena by RCCL broadcast (dist.py) has no meaningful local parameters to pack from.
+// One thread per 16-byte group (8 consecutive k of one (row, tap)); `mode16` says which fragment order the fp32 arena holds.
+struct Bf16Derive { size_t conv16, outp16; size_t conv_w, outp_w; };   // per layer: bf16 offsets (16-byte units), fp32 offsets (floats)
+static __device__ __forceinline__ size_t f32_frag_index32(int mt, int n_it, int it, int rb, int r32, int c) {   // pack_convgemm, RB = 2
+  const int hi = (c & 7) >> 2, j = c & 3;
+  return ((((size_t)mt * n_it + it) * 2 + rb) * 64 + (hi * 32 + r32)) * 4 + j;
+}
+static __device__ __forceinline__ size_t f32_frag_index16(int mt, int n_it, int it, int rbk, int r16, int c) {  // pack_convgemm16
+  const int h = (c & 7) >> 2, lk = c & 3;
+  return ((((size_t)mt * n_it + it) * 2 + h) * 64 + (lk * 16 + r16)) * 4 + rbk;
+}
+static __global__ void k_bf16_from_arena(__bf16* __restrict__ dst, const float* __restrict__ A, const Bf16Derive* __restrict__ lay, int L,
+                                         int C, int conv_mt, int conv_it, int outp_mt, int outp_it, int conv_mode16, int outp_mode16) {
+  const size_t per_conv = (size_t)conv_mt * conv_it * 2 * 64, per_outp = (size_t)outp_mt * outp_it * 2 * 64;
+  const size_t gidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= (size_t)L * (per_conv + per_outp)) return;
+  const int layer = (int)(gidx / (per_conv + per_outp));
+  size_t g = gidx - (size_t)layer * (per_conv + per_outp);
+  const Bf16Derive ly = lay[layer];
+  bf16x8 v;
+  if (g < per_conv) {     // dst16[conv + ((mt*conv_it + it)*2 + rb)*64 + lane], it = cb16*3 + tap: row = rb*C + mt*32 + (lane&31), c = cb16*16 + 8*(lane>>5) + j
+    const int lane = (int)(g & 63), rb = (int)((g >> 6) & 1);
+    const size_t q = g >> 7;
+    const int it = (int)(q % conv_it), mt = (int)(q / conv_it);
+    const int cb16 = it / 3, tap = it - cb16 * 3, r32 = lane & 31;
+    const int n_it32 = (C / 8) * 3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb16 * 16 + 8 * (lane >> 5) + j;
+      const int it32 = (c >> 3) * 3 + tap;
+      const size_t src = conv_mode16 ? f32_frag_index16(mt, n_it32, it32, (rb << 1) | (r32 >> 4), r32 & 15, c)
+                                     : f32_frag_index32(mt, n_it32, it32, rb, r32, c);
+      v[j] = (__bf16)A[ly.conv_w + src];
+    }
+    *reinterpret_cast<bf16x8*>(dst + (ly.conv16 + g) * 8) = v;
+  } else {                // out-projection: row = mt*64 + rb*32 + (lane&31), c = it*16 + 8*(lane>>5) + j
+    g -= per_conv;
+    const int lane = (int)(g & 63), rb = (int)((g >> 6) & 1);
+    const size_t q = g >> 7;
+    const int it = (int)(q % outp_it), mt = (int)(q / outp_it);
+    const int r32 = lane & 31, n_it32 = C / 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = it * 16 + 8 * (lane >> 5) + j;
+      const size_t src = outp_mode16 ? f32_frag_index16(mt, n_it32, c >> 3, (rb << 1) | (r32 >> 4), r32 & 15, c)
+                                     : f32_frag_index32(mt, n_it32, c >> 3, rb, r32, c);
+      v[j] = (__bf16)A[ly.outp_w + src];
+    }
+    *reinterpret_cast<bf16x8*>(dst + (ly.outp16 + g) * 8) = v;
+  }
+}
+
+extern "C" int fdx_wavenet_bf16_from_arena(fdx_handle h, void* dev_out, size_t bytes, fdx_stream st) {
+  GenScope gen_scope(h);
+  if (!h) return FDX_E_ARG;
+  if (!h->wn_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_bf16_from_arena: attach the fp32 arena first");
+  size_t want = 0;
+  if (int rc = fdx_wavenet_bf16_packed_bytes(&h->wd, &want)) { h->err = g_last_error; return rc; }
+  if (!dev_out || bytes != want) return fail(h, FDX_E_ARG, "fdx_wavenet_bf16_from_arena: output must be %zu bytes", want);
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  WnBf16Layout bl;
+  wn_bf16_layout(h->wd, bl);
+  const int L = h->wd.residual_layers, C = h->wd.residual_channels;
+  std::vector<Bf16Derive> lay(L);
+  for (int i = 0; i < L; ++i) lay[i] = Bf16Derive{bl.conv[i], bl.outp[i], h->wl.conv[i].w_off, h->wl.outp[i].w_off};
+  FDX_HIP(h, h->scratch_b.ensure(L * sizeof(Bf16Derive), false, s));
+  FDX_HIP(h, hipMemcpyAsync(h->scratch_b.p, lay.data(), L * sizeof(Bf16Derive), hipMemcpyHostToDevice, s));
+  FDX_HIP(h, hipStreamSynchronize(s));   // `lay` dies at return (one-off set-up call)
+  const size_t groups = (size_t)L * ((size_t)bl.conv_mt * bl.conv_it + (size_t)bl.outp_mt * bl.outp_it) * 128;
+  hipLaunchKernelGGL(k_bf16_from_arena, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, static_cast<__bf16*>(dev_out), h->wn_arena,
+                     static_cast<const Bf16Derive*>(h->scratch_b.p), L, C, bl.conv_mt, bl.conv_it, bl.outp_mt, bl.outp_it, conv16() ? 1 : 0,
+                     outp16() ? 1 : 0);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
+
 // dev_packed == NULL switches the handle back to fp32.  fdx_wavenet_attach must have been called first (biases, the other
 // projections and the conditioner slab GEMM come from the fp32 arena).
 extern "C" int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev, size_t bytes) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->wn_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_bf16_attach: attach the fp32 arena first");
   if (dev) {
@@ -290,7 +371,7 @@ extern "C" int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev, size_t byt
   }
   h->wn_arena_bf16 = dev;
   h->prepared = false;    // the blocked operand buffers are sized in prepare
-  ++g_alloc_generation;   // recorded sampler graphs bake the kernel choice in
+  ++h->alloc_gen;         // recorded sampler graphs bake the kernel choice in
   return FDX_OK;
 }
 
@@ -372,6 +453,7 @@ static int wn_cond_slab(fdx_ctx* h, const float* condp, float* P, hipStream_t s)
 }
 
 extern "C" int fdx_wavenet_prepare(fdx_handle h, const float* cond, int B, int T, const uint8_t* cond_mask, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->wn_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_prepare: no weights attached");
   if (!cond || B <= 0 || T <= 0) return fail(h, FDX_E_ARG, "fdx_wavenet_prepare: bad cond/B/T");
@@ -448,17 +530,9 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   const float sqrtL = (float)std::sqrt((double)L);
   for (int i = 0; i < L; ++i) {
     const int dil = l.dil[i];
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (h->prof.on && (h->prof.seen++ % h->prof.stride) == 0) {
-      auto& pe = h->prof;
-      if (pe.used == pe.start.size()) {
-        hipEvent_t a, b;
-        FDX_HIP(h, hipEventCreate(&a)); FDX_HIP(h, hipEventCreate(&b));
-        pe.start.push_back(a); pe.stop.push_back(b);
-      }
-      ev0 = pe.start[pe.used]; ev1 = pe.stop[pe.used]; pe.used++;
-      pe.flops_per_launch = 2.0 * (2.0 * C) * (3.0 * C) * (double)B * T;
-    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, eo0 = nullptr, eo1 = nullptr;   // fdx_prof_*: one of the two kernels, sampled
+    h->prof.take(PROF_WN_CONVGATE, 2.0 * (2.0 * C) * (3.0 * C) * (double)B * T, ev0, ev1);
+    h->prof.take(PROF_WN_OUTPROJ, 2.0 * (2.0 * C) * (double)C * (double)B * T, eo0, eo1);
     const float* Pl = (Pslab ? Pslab : h->P.f()) + kHalo + (size_t)i * 2 * C * ld;
     const long p_bs = (long)L * 2 * C * ld;
     const float* sbn = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn;
@@ -475,7 +549,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       g.outb = Zb; g.ob_bs = bsB;
       const ConvGeom gc{B, T, C / 16, 3, -dil, dil, bl.conv_mt};
       FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiGateB, 4, 1, OPK_BF16>(gc, WB + bl.conv[i], reinterpret_cast<const float*>(Yb),
-                                                                              bsB / 2, ld, 1.f, g, s)));
+                                                                              bsB / 2, ld, 1.f, g, s, ev0, ev1)));
       EpiResSkipB r{};
       r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
       r.Y = nullptr; r.sb = sbn; r.sb_ld = ldn; r.sb_bs = sb_bs;
@@ -483,7 +557,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       r.Yb = (i + 1 < L) ? Yb : nullptr; r.yb_bs = bsB;
       const ConvGeom go{B, T, C / 16, 1, 0, 0, bl.outp_mt};
       FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkipB, 4, 1, OPK_BF16>(go, WB + bl.outp[i], reinterpret_cast<const float*>(Zb),
-                                                                                 bsB / 2, ld, 1.f, r, s)));
+                                                                                 bsB / 2, ld, 1.f, r, s, eo0, eo1)));
       continue;
     }
     if (conv16()) {
@@ -500,7 +574,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       const ConvGeom go{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles};
       EpiResSkip16 r{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL,
                      (float)(1.0 / (double)sqrtL)};
-      FDX_HIP(h, launch_convgemm16(go, reinterpret_cast<const float4*>(A + l.outp[i].w_off), Z, bsC, ld, r, s));
+      FDX_HIP(h, launch_convgemm16(go, reinterpret_cast<const float4*>(A + l.outp[i].w_off), Z, bsC, ld, r, s, eo0, eo1));
     } else {
       EpiResSkip r{};
       r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
@@ -508,7 +582,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       r.sb = sbn; r.sb_ld = ldn; r.sb_bs = sb_bs;
       r.skip_mode = skip_mode;
       r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
-      FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s)));
+      FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s, eo0, eo1)));
     }
   }
   {
@@ -526,6 +600,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
 
 extern "C" int fdx_wavenet_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask,
                                    float* eps, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->wn_ok || !h->prepared) return fail(h, FDX_E_STATE, "fdx_wavenet_forward: call attach + prepare first");
   if (!x || !t || !eps) return fail(h, FDX_E_ARG, "fdx_wavenet_forward: null pointer");
@@ -546,6 +621,7 @@ static void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, h
 }
 
 extern "C" int fdx_randn(fdx_handle h, float* out, size_t n, uint64_t seed, uint64_t offset, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h || !out) return FDX_E_ARG;
   FDX_HIP(h, hipSetDevice(h->device));
   if (n) launch_randn(out, n, seed, offset, as_stream(st));
@@ -608,7 +684,7 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
       const float* nz = step_noise ? step_noise + (size_t)r * n_el : h->snoise.f();
       if (!step_noise) launch_randn(h->snoise.f(), n_el, seed, (uint64_t)r * ((n_el + 3) / 4), s);
       hipLaunchKernelGGL(k_naive_step, grid, blk, 0, s, sx, eps, nz, (long)M * T, T, bs, ld, M, T, row[1], row[2], row[3],
-                         row[4], row[5]);
+                         row[4], row[5], row[6], row[7]);
     }
   } else {  // PLMS
     float* xp = h->sxt.f() + kHalo; float* prime = h->seps2.f() + kHalo;
@@ -646,6 +722,7 @@ static uint64_t fnv1a(const void* p, size_t n, uint64_t hsh = 146959810393466560
 
 extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_rows, float* x, const float* step_noise,
                                uint64_t seed, const uint8_t* x_mask, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run: call attach + prepare first");
   if (!tab || n_rows <= 0 || !x) return fail(h, FDX_E_ARG, "fdx_sampler_run: bad table / x");
@@ -710,7 +787,7 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   } else {
     uint64_t key = fnv1a(tab, (size_t)n_rows * FDX_ROW * sizeof(float));
     const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
-                              (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, g_alloc_generation,
+                              (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, h->alloc_gen,
                               (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn, (uint64_t)(uintptr_t)h->td};
     key = fnv1a(parts, sizeof parts, key);
     fdx_ctx::GraphEntry* hit = nullptr;
@@ -742,8 +819,32 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   return FDX_OK;
 }
 
+extern "C" int fdx_q_sample(fdx_handle h, const float* src, int B, int M, int T, int normalise, const float* spec_min,
+                            const float* spec_max, int n_spec, float sqrt_ac, float sqrt_1m_ac, const float* noise, float* out,
+                            fdx_stream st) {
+  GenScope gen_scope(h);
+  if (!h || !src || !out || B <= 0 || M <= 0 || T <= 0) return FDX_E_ARG;
+  if (normalise && (!spec_min || !spec_max || (n_spec != 1 && n_spec != T)))
+    return fail(h, FDX_E_ARG, "fdx_q_sample: spec_min / spec_max must have 1 or T=%d entries (they broadcast over the last axis), got %d", T, n_spec);
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  const float* dmin = nullptr; const float* dmax = nullptr;
+  if (normalise) {
+    FDX_HIP(h, h->scratch_a.ensure(2 * (size_t)n_spec * 4, false, s));
+    FDX_HIP(h, hipMemcpyAsync(h->scratch_a.p, spec_min, n_spec * 4, hipMemcpyHostToDevice, s));
+    FDX_HIP(h, hipMemcpyAsync(h->scratch_a.f() + n_spec, spec_max, n_spec * 4, hipMemcpyHostToDevice, s));
+    dmin = h->scratch_a.f(); dmax = h->scratch_a.f() + n_spec;
+  }
+  const size_t n = (size_t)B * M * T;
+  hipLaunchKernelGGL(k_q_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, src, noise, n, T, normalise, dmin, dmax, n_spec,
+                     noise != nullptr, sqrt_ac, sqrt_1m_ac);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
+
 extern "C" int fdx_denorm_spec(fdx_handle h, const float* x, int B, int M, int T, const float* spec_min,
                                const float* spec_max, int n_spec, float* mel, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h || !x || !mel || !spec_min || !spec_max) return FDX_E_ARG;
   if (n_spec != 1 && n_spec != M) return fail(h, FDX_E_ARG, "spec_min and spec_max must be either of length 1 or mel_channels");
   hipStream_t s = as_stream(st);

@@ -71,9 +71,11 @@ class GaussianDiffusion(nn.Module):
         if noise_predictor is None:
             noise_predictor = "naive" if sampler_interval == 1 else "unipc"
         self.noise_predictor = noise_predictor
-        # "torch": per-step noise of the naive sampler is drawn with torch.randn (reference RNG stream);
-        # "philox": drawn on the device inside the loop (no [n_steps,B,M,T] tensor) -- perf mode.
+        # "torch": per-step noise of the naive sampler is drawn with torch's generator, one draw per step in the reference's
+        #          order (noise_predictor.py:101), a bounded chunk of steps at a time;
+        # "philox": drawn on the device inside the loop by the library's own Philox -- perf mode.
         self.step_rng = "torch"
+        self.naive_noise_chunk_bytes = 128 << 20
 
     # ------------------------------------------------------------------ small reference helpers
     def norm_spec(self, x):
@@ -88,6 +90,23 @@ class GaussianDiffusion(nn.Module):
         shape = (t.shape[0],) + (1,) * (x_start.dim() - 1)
         return (self.sqrt_alphas_cumprod.gather(-1, t).reshape(shape) * x_start
                 + self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shape) * noise)
+
+    def _shallow_init(self, eng, x, normalise: bool, skip_steps: int, noise, st):
+        """x_T of shallow diffusion in the library: [norm_spec] (diffusion.py:224, :315-316) then q_sample (:120-127, :226-232)."""
+        B, M, T = x.shape
+        smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
+        smax = self.spec_max.detach().reshape(-1).to("cpu", torch.float32).contiguous()
+        if normalise and smin.numel() not in (1, T):   # the reference broadcasts [1, 1, n] against [B, M, T]: the LAST axis
+            raise RuntimeError(f"The size of tensor a ({T}) must match the size of tensor b ({smin.numel()}) at non-singleton dimension 2")
+        a = b = 0.0
+        if skip_steps:
+            t = self.num_timesteps - skip_steps
+            a, b = float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t])
+        out = torch.empty_like(x)
+        with eng.lock:
+            _lib.check(_lib.lib().fdx_q_sample(eng.h, _lib.ptr(x), B, M, T, int(normalise), C.c_void_p(smin.data_ptr()),
+                                               C.c_void_p(smax.data_ptr()), smin.numel(), a, b, _lib.ptr(noise), _lib.ptr(out), st), eng.h)
+        return out
 
     def train_step(self, *a, **k):
         raise NotImplementedError("fish_diffusion_amd implements the inference hot path only; use the reference "
@@ -115,26 +134,31 @@ class GaussianDiffusion(nn.Module):
         _lib.require_gpu(features, "GaussianDiffusion features")
         device = features.device
         cond = features.transpose(1, 2)
-
+        st = _lib.stream_ptr(device)
+        eng = self.denoise_fn.engine(device)
         if x_init is not None:
-            x = x_init
+            x = x_init.to(torch.float32).contiguous().clone()
         else:
+            # diffusion.py:217-232, same draw order as the reference: x_T ~ N(0,1) unless an original mel is given, then the
+            # q_sample noise.  The arithmetic (norm_spec, q_sample) runs in the library (fdx_q_sample).
             if original_mel is None:
                 temp = cond if x_masks is None else x_masks
                 x = torch.randn((temp.shape[0], self.mel_bins, temp.shape[-1]), device=device)
             else:
-                x = self.norm_spec(original_mel)
-            if skip_steps:
-                t = torch.tensor([self.num_timesteps - skip_steps], device=device, dtype=torch.long)
-                x = self.q_sample(x_start=x, t=t, noise=torch.randn_like(x))
-        x = x.to(torch.float32).contiguous().clone()
+                x = original_mel.to(device=device, dtype=torch.float32).contiguous()
+            if original_mel is not None or skip_steps:
+                noise = torch.randn_like(x) if skip_steps else None
+                x = self._shallow_init(eng, x, original_mel is not None, skip_steps, noise, st)
         B, M, T = x.shape
 
         kind, table = schedule.sampler_table(noise_predictor, interval=sampler_interval, skip_steps=skip_steps,
                                              **self._sched)
         n_rows = table.shape[0]
-        if kind == _lib.SAMPLER_NAIVE and step_noise is None and self.step_rng == "torch":
-            step_noise = torch.randn((n_rows, B, M, T), device=device)
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        if kind == _lib.SAMPLER_NAIVE:   # the clamp bounds are loadable buffers in the reference (noise_predictor.py:30-31,90)
+            table = table.copy()
+            table[:, 6] = float(self.naive_noise_predictor.clip_min)
+            table[:, 7] = float(self.naive_noise_predictor.clip_max)
         if step_noise is not None:
             step_noise = step_noise.to(torch.float32).contiguous()
             if kind == _lib.SAMPLER_NAIVE and tuple(step_noise.shape) != (n_rows, B, M, T):
@@ -142,16 +166,30 @@ class GaussianDiffusion(nn.Module):
         xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if step_noise is None else 0
 
-        table = np.ascontiguousarray(table, dtype=np.float32)
         mel = torch.empty((B, T, M), device=device, dtype=torch.float32)
         smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         smax = self.spec_max.detach().reshape(-1).to("cpu", torch.float32).contiguous()
-        st = _lib.stream_ptr(device)
-        eng = self.denoise_fn.engine(device)
+        # The DDPM sampler with the reference's RNG stream ("torch"): one `randn_like(x)` per step (noise_predictor.py:101), drawn
+        # here in the same order with the same shape -- `buf[i].normal_()` is what `torch.randn_like` runs -- but only a bounded
+        # chunk of steps ahead of the device loop (1000 steps x [B, M, T] up front would be 0.44 GB per 10 s utterance).
+        chunk = n_rows
+        if kind == _lib.SAMPLER_NAIVE and step_noise is None and self.step_rng == "torch":
+            chunk = max(1, min(n_rows, self.naive_noise_chunk_bytes // max(1, B * M * T * 4)))
+            noise_buf = torch.empty((chunk, B, M, T), device=device, dtype=torch.float32)
         with eng.lock:   # prepare + sampler run as one critical section (the reference's flask server calls from several threads)
             self.denoise_fn.prepare(cond, cond_masks)
-            _lib.check(_lib.lib().fdx_sampler_run(eng.h, kind, C.c_void_p(table.ctypes.data), n_rows, _lib.ptr(x),
-                                                  _lib.ptr(step_noise), seed, _lib.ptr(xm), st), eng.h)
+            for r0 in range(0, n_rows, chunk):
+                r1 = min(n_rows, r0 + chunk)
+                sn = step_noise
+                if kind == _lib.SAMPLER_NAIVE and step_noise is None and self.step_rng == "torch":
+                    for i in range(r1 - r0):
+                        noise_buf[i].normal_()
+                    sn = noise_buf
+                elif step_noise is not None and chunk != n_rows:
+                    sn = step_noise[r0:r1]
+                tab = table[r0:r1]
+                _lib.check(_lib.lib().fdx_sampler_run(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x),
+                                                      _lib.ptr(sn), seed + r0, _lib.ptr(xm), st), eng.h)
             _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x), B, M, T, C.c_void_p(smin.data_ptr()),
                                                   C.c_void_p(smax.data_ptr()), smin.numel(), _lib.ptr(mel), st), eng.h)
         return mel

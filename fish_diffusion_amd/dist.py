@@ -109,6 +109,15 @@ def gather_stats(values: Sequence[float], device: torch.device) -> torch.Tensor:
     return torch.stack(out).cpu()
 
 
+def sum_over_ranks(value: float, device: torch.device) -> float:
+    """SUM over ranks of a scalar (fp64)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def barrier_max(seconds: float, device: torch.device) -> float:
     """MAX over ranks of a wall-time measurement."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -54,7 +54,7 @@ def naive_table(betas: np.ndarray, chunks) -> np.ndarray:
     for r, t in enumerate(chunks):
         nonzero = torch.tensor(1.0 if t > 0 else 0.0)
         scale = nonzero * (0.5 * logvar[t]).exp()  # noise_predictor.py:102-104
-        tab[r, :6] = [float(v) for v in (t, sr[t], srm1[t], c1[t], c2[t], scale)]
+        tab[r, :8] = [float(v) for v in (t, sr[t], srm1[t], c1[t], c2[t], scale, -1.0, 1.0)]   # [6:8] = clip_min / clip_max (:30-31)
     return tab
 
 

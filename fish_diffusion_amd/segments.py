@@ -145,7 +145,9 @@ def convert_segments(model, vocoder, total_len: int, segments: Sequence[Tuple[in
     a float mix [1, E])."""
     feats, f0s, keep = [], [], []
     for i, (start, end) in enumerate(segments):
-        mel_len = (end - start) // hop
+        # the reference slices audio[start:end], which clips at the end of the audio, and takes mel_len from the CLIPPED
+        # segment (inference.py:104); slice_audio's last chunk may run past the interval (and the audio) end
+        mel_len = (min(end, total_len) - start) // hop
         if mel_len <= 0:
             continue
         p = pitches[i].to(torch.float32).reshape(1, -1)

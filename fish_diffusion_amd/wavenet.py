@@ -230,13 +230,13 @@ class WaveNet(HipDenoiser):
     def _after_attach(self):
         l = _lib.lib()
         if self._storage == "bf16":
+            # Derived on the device from the ATTACHED fp32 arena, never from this module's own parameters: after
+            # dist.broadcast_model_weights a non-source rank's parameters are whatever they were initialised with.
             nb = C.c_size_t()
             _lib.check(l.fdx_wavenet_bf16_packed_bytes(C.byref(self._desc), C.byref(nb)))
-            keep, arr = _lib.host_ptr_array(self._params())
-            host = torch.empty(nb.value, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-            _lib.check(l.fdx_wavenet_bf16_pack(C.byref(self._desc), arr, len(keep), C.c_void_p(host.data_ptr()), nb))
-            del keep
-            self._arena_bf16 = host.to(self._handle.device)
+            dev = self._handle.device
+            self._arena_bf16 = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+            _lib.check(l.fdx_wavenet_bf16_from_arena(self._handle.h, _lib.ptr(self._arena_bf16), nb.value, _lib.stream_ptr(dev)), self._handle.h)
             _lib.check(l.fdx_wavenet_bf16_attach(self._handle.h, _lib.ptr(self._arena_bf16), self._arena_bf16.numel()), self._handle.h)
         elif self._arena_bf16 is not None:
             _lib.check(l.fdx_wavenet_bf16_attach(self._handle.h, None, 0), self._handle.h)

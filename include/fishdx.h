@@ -88,6 +88,9 @@ int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const void* dev_
 int fdx_wavenet_bf16_packed_bytes(const fdx_wavenet_desc* d, size_t* bytes);
 int fdx_wavenet_bf16_pack(const fdx_wavenet_desc* d, const float* const* host_weights, int n_weights, void* host_packed, size_t bytes);
 int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev_packed, size_t bytes);
+/* The same bf16 arena, derived on the device from the fp32 arena attached to `h` (bit-identical to fdx_wavenet_bf16_pack of the
+ * tensors that arena was packed from): for ranks that received their weights as a broadcast arena and hold no tensors. */
+int fdx_wavenet_bf16_from_arena(fdx_handle h, void* dev_out, size_t bytes, fdx_stream s);
 
 /* Step-invariant work for one batch of utterances (conditioner slabs for all layers, wavenet.py:108).
  * cond: dev [B][d_encoder][T]; cond_mask: dev [B][T] bytes (1 = masked, wavenet.py:220-221) or NULL. */
@@ -167,7 +170,7 @@ enum { FDX_SAMPLER_NAIVE = 0, FDX_SAMPLER_UNIPC = 1, FDX_SAMPLER_PLMS = 2 };
  *  UNIPC row 0      : {t_input, sigma_t, alpha_t}                                  (initial model call)
  *  UNIPC row r>=1   : {t_input, sigma_t, alpha_t, c_x = sigma_t/sigma_prev, c_m = alpha_t*h_phi_1,
  *                      aB = alpha_t*B_h, rk, order(1|2), use_corrector(0|1), rho_c0, rho_c1}
- *  NAIVE row        : {t, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, noise_scale}
+ *  NAIVE row        : {t, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, noise_scale, clip_min, clip_max}
  *  PLMS  row        : {t, t_prev, A = a_prev - a_t, P, Q}   (noise_predictor.py:118-131)
  */
 /* x: dev [B][M][T], in = x_T (initial noise or q_sample'd mel), out = x_0 (normalised mel).
@@ -175,6 +178,14 @@ enum { FDX_SAMPLER_NAIVE = 0, FDX_SAMPLER_UNIPC = 1, FDX_SAMPLER_PLMS = 2 };
  * x_mask as in fdx_wavenet_forward.  fdx_wavenet_prepare must have been called for this batch. */
 int fdx_sampler_run(fdx_handle h, int kind, const float* host_table, int n_rows, float* x,
                     const float* step_noise, uint64_t seed, const uint8_t* x_mask, fdx_stream s);
+/* The start of shallow diffusion, diffusion.py:223-232: out = q_sample(norm_spec(src), t, noise).
+ *   normalise != 0: v = (src - spec_min) / (spec_max - spec_min) * 2 - 1 (diffusion.py:315-316).  spec_min/max are host arrays of
+ *   n_spec floats; the reference's [1,1,n] buffers broadcast against the LAST axis of the [B,M,T] tensor, so n_spec is 1 or T.
+ *   noise != NULL: out = sqrt_ac * v + sqrt_1m_ac * noise (q_sample :120-127 with extract() :34-37 done by the caller: the two
+ *   scalars are sqrt_alphas_cumprod[t], sqrt_one_minus_alphas_cumprod[t] for t = timesteps - skip_steps).
+ * src, noise, out: dev [B][M][T]; out may alias src. */
+int fdx_q_sample(fdx_handle h, const float* src, int B, int M, int T, int normalise, const float* spec_min, const float* spec_max,
+                 int n_spec, float sqrt_ac, float sqrt_1m_ac, const float* noise, float* out, fdx_stream s);
 /* norm_spec / denorm_spec + the [B,M,T] <-> [B,T,M] transposes, diffusion.py:315-319,217.
  * spec_min/max: host arrays of n_spec (1 or M) floats.  denorm: x [B][M][T] -> mel [B][T][M]. */
 int fdx_denorm_spec(fdx_handle h, const float* x, int B, int M, int T, const float* spec_min,
@@ -345,6 +356,10 @@ int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, int T, const 
 /* on = 0: off (and forget); 1: every launch; N > 1: every N-th launch (sampling keeps the probe effect negligible);
  * -1: pause -- stop recording but keep the recorded launches for fdx_prof_read. */
 int fdx_prof_enable(fdx_handle h, int on);
+/* Which kernel family fdx_prof_enable times: 0 = WaveNet dilated conv + gate (default), 1 = WaveNet out-projection + residual/skip,
+ * 2 = NSF-HiFiGAN ResBlock convs (the no-split 64-row instantiation, i.e. the stages with >= 64 channels).  fdx_prof_read's
+ * flops_per_launch is the mean algorithmic FLOP count of the recorded launches (they differ per stage for family 2). */
+int fdx_prof_select(fdx_handle h, int kind);
 int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch);
 /* Median elapsed time (ms) of an EMPTY hipEventRecord start/stop pair on stream s (diagnostic: what
  * bracketing a launch with plain recorded events would add; fdx_prof_* does not use that method). */

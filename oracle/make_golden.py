@@ -261,6 +261,85 @@ def golden_tfdec(R):
 
 
 @torch.no_grad()
+def golden_round2(R):
+    """Round-2 fixtures.
+    (a) nsf_v1_256_full: the vocoder layout configs/vocoder_nsf_hifigan.py:9,31 points at (tools/nsf_hifigan/config_v1_256.json)
+        at FULL size -- 10 s, T = 1722 frames, 440 832 samples -- from the real `Generator` (models.py:353-448).
+    (b) chain_c1 / chain_c2: the chain tools/diffusion/inference.py:140-160 runs -- features -> GaussianDiffusion (UniPC) -> mel
+        -> `* 2.30259` (nsf_hifigan.py:79-80) -> Generator -> waveform -- on the real reference classes in fp32 (`wav`, `mel`), and
+        the same chain with an fp64 DATA PATH (`wav64`, `mel64`: oracle restatement, weights / inputs / activations in float64, the
+        schedule coefficients the reference's own fp32 values).  The fp64 run is the yardstick of the chained-parity test: an
+        fp32 implementation cannot be asked to sit closer to another fp32 implementation than either sits to the exact result.
+    """
+    print("round 2: hop-256 full-size generator")
+    h, seed, T = nsf_hifigan_ref.CONFIG_V1_256, 56, 1722
+    gsd = nsf_hifigan_ref.seeded_generator_state(seed, h)
+    gen = R["Generator"](R["AttrDict"](h))
+    gen.remove_weight_norm()
+    gen.eval()
+    gen.load_state_dict(gsd, strict=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    mel = torch.randn(1, 128, T, generator=g) * 0.5 - 2.0
+    f0 = synth_f0(T, h["sampling_rate"] / h["hop_size"])[None]
+    L = T * h["hop_size"]
+    torch.manual_seed(seed + 2)
+    ref = gen(mel, f0)
+    torch.manual_seed(seed + 2)
+    rand_ini = torch.rand(1, 9)
+    rand_ini[:, 0] = 0
+    src_noise = torch.randn(1, L, 9)
+    mine = nsf_hifigan_ref.generator_forward(gsd, h, mel, f0, rand_ini, src_noise)
+    assert torch.equal(mine, ref), "oracle generator v1_256_full != reference"
+    save("nsf_v1_256_full", mel=mel, f0=f0, rand_ini=rand_ini, wav=ref, seed=np.int64(seed), noise_seed=np.int64(seed + 2),
+         weights_sha1=np.array(state_sha1(gsd)), src_noise_sha1=np.array(sha1_of([src_noise])), config=np.array(json.dumps(h)))
+
+    print("round 2: chained features -> waveform (fp32 reference + fp64 data path)")
+    sd = wavenet_ref.seeded_wavenet_state(1234, **{k: v for k, v in WN_FULL.items() if k != "dilation_cycle"})
+    diff = build_ref_diffusion(R, WN_FULL, sd)
+    hv = nsf_hifigan_ref.CONFIG_V1
+    vsd = nsf_hifigan_ref.seeded_generator_state(55, hv)
+    gen = R["Generator"](R["AttrDict"](hv))
+    gen.remove_weight_norm()
+    gen.eval()
+    gen.load_state_dict(vsd, strict=True)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    vsd64 = {k: v.double() for k, v in vsd.items()}
+    den64_ = oracle_denoiser(sd64, WN_FULL)
+    den64 = lambda x, t, c, xm, cm: den64_(x, t.double(), c, xm, cm)   # noqa: E731  (step embedding in fp64 as well)
+    for tag, T, interval, seed in (("c1", 430, 50, 1234), ("c2", 861, 10, 1235)):
+        gg = torch.Generator().manual_seed(seed)
+        feats = torch.randn(1, T, 256, generator=gg)
+        f0 = synth_f0(T)[None]
+        torch.manual_seed(seed + 100)
+        mel_ref = diff(feats, sampler_interval=interval)                      # [1, T, 128], log10 scale (diff_svc_v2)
+        torch.manual_seed(seed + 200)
+        wav_ref = gen(2.30259 * mel_ref.transpose(1, 2), f0)                  # spec2wav: use_natural_log=False rescale
+        torch.manual_seed(seed + 100)
+        x_init = torch.randn(1, 128, T)
+        torch.manual_seed(seed + 200)
+        rand_ini = torch.rand(1, 9)
+        rand_ini[:, 0] = 0
+        src_noise = torch.randn(1, T * hv["hop_size"], 9)
+        mel64 = sampler_ref.diffusion_sample(den64, feats.double(), x_init=x_init.double(), sampler_interval=interval)
+        assert mel64.dtype == torch.float64
+        wav64 = nsf_hifigan_ref.generator_forward(vsd64, hv, 2.30259 * mel64.transpose(1, 2), f0.double(), rand_ini.double(),
+                                                  src_noise.double())
+        assert wav64.dtype == torch.float64
+        # the vocoder alone on the REFERENCE's fp32 mel, fp64 data path: separates "mel noise amplified by the vocoder" from vocoder noise
+        wav64_of_ref_mel = nsf_hifigan_ref.generator_forward(vsd64, hv, (2.30259 * mel_ref.transpose(1, 2)).double(), f0.double(),
+                                                             rand_ini.double(), src_noise.double())
+        e_mel = float((mel_ref.double() - mel64).abs().max() / mel64.abs().max())
+        e_wav = float((wav_ref.double() - wav64).abs().max())
+        print(f"  chain_{tag}: reference fp32 vs fp64 data path: mel rel {e_mel:.3e}, wav abs {e_wav:.3e} "
+              f"(vocoder alone on the same mel: {float((wav_ref.double() - wav64_of_ref_mel).abs().max()):.3e})")
+        save(f"chain_{tag}", features=feats, f0=f0, x_init=x_init, rand_ini=rand_ini, mel=mel_ref, wav=wav_ref,
+             mel64=mel64.float(), wav64=wav64.float(),   # the fp64 results, STORED as fp32 (6e-8 of storage rounding against errors of 1e-5..1e-4)
+             interval=np.int64(interval), noise_seed=np.int64(seed + 200),
+             src_noise_sha1=np.array(sha1_of([src_noise])), wn_sha1=np.array(state_sha1(sd)), voc_sha1=np.array(state_sha1(vsd)),
+             ref_vs_f64_wav_abs=np.float64(e_wav), ref_vs_f64_mel_rel=np.float64(e_mel))
+
+
+@torch.no_grad()
 def main():
     os.makedirs(GOLD, exist_ok=True)
     R = _ref_import.load()
@@ -561,6 +640,7 @@ def main():
     golden_convnext(R)
     golden_frontend_expand(R)
     golden_tfdec(R)
+    golden_round2(R)
 
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
@@ -568,7 +648,7 @@ def main():
 
 
 if __name__ == "__main__":
-    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec}
+    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2}
     if len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(os.cpu_count())

@@ -18,17 +18,33 @@ def test_algorithmic_flops_match_the_survey():
     # 95.18 MFLOP per frame per step (incl. 0.02 T-independent), 1.2737 MFLOP per output sample (config_v1)
     assert abs(b.wavenet_flops_per_frame() / 1e6 - 95.16) < 0.05
     assert abs(b.nsf_flops_per_sample() / 1e6 - 1.2737) < 1e-3
-    h256 = dict(b.NSF_V1, upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], hop_size=256)
-    assert abs(b.nsf_flops_per_sample(h256) / 1e6 - 2.402) < 5e-3        # config_v1_256: 2.402 MFLOP per sample
+    assert abs(b.nsf_flops_per_sample(b.NSF_V1_256) / 1e6 - 2.402) < 5e-3   # config_v1_256: 2.402 MFLOP per sample
     total = b.wavenet_flops_per_frame() * 861 * 100 + b.nsf_flops_per_sample() * 861 * 512
     assert abs(total / 1e12 - 8.755) < 0.01                               # one 10 s utterance, 100 steps
+    # executed vs algorithmic (SURVEY 8d "never count hoisted work as achieved"): the 20 conditioner projections are
+    # 10.49 MFLOP per frame and run once per utterance instead of once per step
+    assert abs(b.wavenet_hoisted_flops_per_frame() / 1e6 - 10.49) < 0.01
+    alg, exe = b.e2e_flops(861, 100, 861 * 512, 861)
+    assert alg == total and abs((alg - exe) / 1e12 - 0.894) < 0.002       # 99 x 9.03 GFLOP
+    a2, e2 = b.e2e_flops(0, 0, 32 * 1722 * 256, 0, b.NSF_V1_256, denoise=False)
+    assert a2 == e2 and abs(a2 / 1e12 - 33.88) < 0.05                     # configs[2]: 32 x 1058.9 GFLOP
+
+
+def test_config_aliases_cover_every_baseline_config():
+    b = _bench()
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert b.BASELINE_METRIC == base["metric"]
+    assert {b.ALIASES[str(i)] for i in range(1, len(base["configs"]))} == {"headline", "vocoder", "sharded", "ddpm1000"}
+    assert b.ALIASES["c2"] == "vocoder" and b.ALIASES["c3"] == "sharded" and b.ALIASES["c5"] == "ddpm1000"
+    assert set(b.DEFAULT_STEPS) == set(b.ALIASES.values())
 
 
 def test_usable_cores_and_traffic_file():
     b = _bench()
     n = b.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
-    traffic, src = b.pmc_traffic(1, 861)
+    traffic, src = b.pmc_traffic("headline", "convgate", {"config": "headline", "batch": 1, "frames": 861})
     assert src is None or os.path.exists(os.path.join(ROOT, src))
     if traffic is not None:
         with open(os.path.join(ROOT, src)) as f:
@@ -36,7 +52,8 @@ def test_usable_cores_and_traffic_file():
         k = next(v for name, v in d["kernels"].items() if "EpiGate" in name)
         assert traffic == k["fetch_bytes"] + k["write_bytes"]
         assert abs(k["fetch_bytes"] - 2 * k["FETCH_SIZE"] * 1024) < 2048    # FETCH_SIZE is stored rounded to 0.1 KiB
-    assert b.pmc_traffic(4, 861) == (None, None)                          # counters are only valid for the config they were taken on
+    # counters are only valid for the workload they were taken on
+    assert b.pmc_traffic("headline", "convgate", {"config": "headline", "batch": 4, "frames": 861}) == (None, None)
 
 
 def test_make_batches_rules():
