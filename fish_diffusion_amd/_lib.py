@@ -125,6 +125,7 @@ _SIGS = {
     "fdx_prof_enable": (C.c_int, [_P, C.c_int]),
     "fdx_prof_select": (C.c_int, [_P, C.c_int]),
     "fdx_prof_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fdx_graph_stats": (C.c_int, [_P, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)]),
     "fdx_prof_calibrate": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
 }
 EXPORTS = tuple(_SIGS)
@@ -186,6 +187,12 @@ class Handle:
         self.h = C.c_void_p()
         self.lock = threading.RLock()
         check(lib().fdx_create(self.device.index, C.byref(self.h)))
+
+    def graph_stats(self):
+        """(captures, launches, cached) of this handle's recorded sampler graphs."""
+        a, b, c = C.c_long(), C.c_long(), C.c_int()
+        check(lib().fdx_graph_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)
+        return a.value, b.value, c.value
 
     _shared = {}
 

@@ -126,8 +126,11 @@ struct fdx_ctx {
   fdx::DevBuf tdev, E, Hm, S0, S;      // step-embedding pipeline; ldn below
   int n_emb = 0, ldn = 0;
   // ---- sampler body as a cached hipGraph (wavenet.hip: fdx_sampler_run)
-  struct GraphEntry { uint64_t key; hipGraphExec_t exec; };
-  std::vector<GraphEntry> graphs;
+  struct GraphEntry { uint64_t key; hipGraphExec_t exec; uint64_t last_use; };
+  std::vector<GraphEntry> graphs;   // LRU, at most graph_cap entries (FDX_GRAPH_CACHE overrides)
+  int graph_cap = 48;
+  uint64_t graph_clock = 0;
+  long graph_captures = 0, graph_launches = 0;
   hipStream_t cap_stream = nullptr;
   bool use_graphs = true;
   // ---- sampler state (padded [B][M][ld])

@@ -467,7 +467,12 @@ constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result tra
 
 // (PRE_LN keeps its statistics in registers across the K loop: the second launch-bounds argument holds that instantiation to
 // the 256 VGPRs that let two workgroups share a CU, like every other instantiation already does unprompted.)
-template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32>
+// VAR: tuning variants (bit flags).  VAR_XCD_RECT: the tile -> XCD map deals 2-D rectangles (4 row groups x 2 column groups) instead of
+// runs of whole rows -- for GEMMs whose weight tile is small next to the activation tile (the out-projection: K = C, one tap) the
+// rectangle halves what every XCD's private L2 must fetch of the activation operand.  VAR_LATE_EPI: the epilogue's global reads
+// are issued after the first pass over the register ring instead of in front of the K loop (they ride behind the start-up burst).
+constexpr int VAR_XCD_RECT = 1, VAR_LATE_EPI = 2;
+template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32, int VAR = 0>
 __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
   a.tiles_per_item = (a.T + (SPLITK ? 63 : 255)) / (SPLITK ? 64 : 256);
@@ -489,8 +494,19 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
   const int G = a.n_tiles_n * (a.n_mtiles / MT), bid = blockIdx.x;   // == gridDim.x, from preloaded arguments
   const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
   const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int mtg = L / a.n_tiles_n;            // group of MT consecutive packed m-tiles
-  const int nt = L - mtg * a.n_tiles_n;
+  int mtg = L / a.n_tiles_n;                  // group of MT consecutive packed m-tiles
+  int nt = L - mtg * a.n_tiles_n;
+  if constexpr ((VAR & VAR_XCD_RECT) != 0 && MT == 1) {
+    // 8 equal rectangles of (n_mtiles / 4) x (n_tiles_n / 2) tiles when both divide (G = 8 rectangles => q8 tiles each, r8 = 0:
+    // XCD x owns exactly rectangle x); any other shape keeps the row-run order above
+    if ((a.n_mtiles & 3) == 0 && (a.n_tiles_n & 1) == 0) {
+      const int H = a.n_mtiles >> 2, W = a.n_tiles_n >> 1, per = H * W;
+      const int rect = L / per, within = L - rect * per;
+      const int wr = within / W;
+      mtg = (rect >> 1) * H + wr;
+      nt = (rect & 1) * W + (within - wr * W);
+    }
+  }
   const int item = nt / a.tiles_per_item;
   const int tile_in_item = nt - item * a.tiles_per_item;
   constexpr int COLS = SPLITK ? 64 : 256;
@@ -730,10 +746,17 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) load(st[d]);
     __builtin_amdgcn_sched_barrier(0);
+    int done = 0;
+    if constexpr ((VAR & VAR_LATE_EPI) != 0) {
+      if (D <= n) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
+        done = D;
+      }
+    }
     prefetch_epilogue();
     ln_prefetch();
     __builtin_amdgcn_sched_barrier(0);
-    int done = 0;
     for (; done + D <= n; done += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
@@ -867,7 +890,7 @@ struct ConvGeom {   // everything the launcher needs besides pointers
   int n_mtiles;     // row tiles of 32*RB logical rows (32 pairs for paired epilogues)
 };
 
-template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32>
+template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32, int VAR = 0>
 inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx,
                                   float in_slope, const Epi& epi, hipStream_t s, hipEvent_t ev_start = nullptr,
                                   hipEvent_t ev_stop = nullptr, const float* col_stats = nullptr, const float* ln_R = nullptr,
@@ -891,10 +914,10 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
-    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0,
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK, VAR>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0,
                           FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK>), dim3(grid), dim3(NW * 64), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK, VAR>), dim3(grid), dim3(NW * 64), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 

@@ -93,7 +93,7 @@ struct EpiResSkip16 {  // wavenet.py:117-120 + the skip sum of :228
 };
 
 // ------------------------------------------------------------------------------------------ kernel
-template <class Epi>
+template <class Epi, int VAR = 0>
 __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
   a.tiles_per_item = (a.T + 63) / 64;
@@ -197,9 +197,16 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) load(st[d]);
     __builtin_amdgcn_sched_barrier(0);
+    int done = 0;
+    if constexpr ((VAR & VAR_LATE_EPI) != 0) {
+      if (D <= n) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
+        done = D;
+      }
+    }
     prefetch_epilogue();
     __builtin_amdgcn_sched_barrier(0);
-    int done = 0;
     for (; done + D <= n; done += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
   FDX_STAMP(5);
 }
 
-template <class Epi>
+template <class Epi, int VAR = 0>
 inline hipError_t launch_convgemm16(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx, const Epi& epi,
                                     hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   ConvArgs a;
@@ -258,9 +265,9 @@ inline hipError_t launch_convgemm16(const ConvGeom& g, const float4* Wp, const f
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)
-    hipExtLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipExtLaunchKernelGGL((convgemm16_kernel<Epi, VAR>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipLaunchKernelGGL((convgemm16_kernel<Epi, VAR>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 

@@ -35,6 +35,7 @@ extern "C" int fdx_create(int device, fdx_handle* out) {
   if (!h) return fail(nullptr, FDX_E_NOMEM, "out of host memory");
   h->device = device;
   if (const char* e = getenv("FDX_NO_GRAPH")) h->use_graphs = !(e[0] && e[0] != '0');
+  if (const char* e = getenv("FDX_GRAPH_CACHE")) { const int n = atoi(e); if (n > 0) h->graph_cap = n; }
   *out = h;
   return FDX_OK;
 }

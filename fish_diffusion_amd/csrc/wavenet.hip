@@ -563,7 +563,9 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     if (conv16()) {
       const ConvGeom gc{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles};
       EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
-      FDX_HIP(h, launch_convgemm16(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
+      static const int conv_var = [] { const char* e = getenv("FDX_CONV_VAR"); return e ? atoi(e) : 0; }();   // tuning experiments
+      if (conv_var == 2) FDX_HIP(h, (launch_convgemm16<EpiGate16, 2>(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1)));
+      else FDX_HIP(h, launch_convgemm16(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
     } else {
       EpiGate g{};
       g.out = Z; g.o_bs = bsC; g.ldo = ld;
@@ -582,7 +584,15 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       r.sb = sbn; r.sb_ld = ldn; r.sb_bs = sb_bs;
       r.skip_mode = skip_mode;
       r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
-      FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s, eo0, eo1)));
+      static const int outp_var = [] { const char* e = getenv("FDX_OUTP_VAR"); return e ? atoi(e) : 0; }();   // tuning experiments
+      const ConvGeom go{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles};
+      const float4* Wo = reinterpret_cast<const float4*>(A + l.outp[i].w_off);
+      switch (outp_var) {
+        case 1: FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkip, 4, 1, OPK_F32, 1>(go, Wo, Z, bsC, ld, 1.f, r, s, eo0, eo1))); break;
+        case 2: FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkip, 4, 1, OPK_F32, 2>(go, Wo, Z, bsC, ld, 1.f, r, s, eo0, eo1))); break;
+        case 3: FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkip, 4, 1, OPK_F32, 3>(go, Wo, Z, bsC, ld, 1.f, r, s, eo0, eo1))); break;
+        default: FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s, eo0, eo1)));
+      }
     }
   }
   {
@@ -803,19 +813,35 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
       hipGraphExec_t exec = nullptr;
       FDX_HIP(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
-      if (h->graphs.size() >= 4) {   // small FIFO cache: keys change only with geometry / schedule / reallocation
-        (void)hipGraphExecDestroy(h->graphs.front().exec);
-        h->graphs.erase(h->graphs.begin());
+      // LRU cache.  Keys change with geometry / schedule / reallocation; ragged serving (pipeline.synthesize pads every micro-batch
+      // to a 64-frame bucket) cycles through (batch size, bucket) pairs -- a few dozen for 6-10 s utterances in batches of <= 8 --
+      // so the cache holds that many (an instantiated sampler graph is ~4 k kernel nodes of host memory, no device memory).
+      if (h->graphs.size() >= (size_t)h->graph_cap) {
+        size_t lru = 0;
+        for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+        (void)hipGraphExecDestroy(h->graphs[lru].exec);
+        h->graphs.erase(h->graphs.begin() + lru);
       }
-      h->graphs.push_back({key, exec});
+      h->graphs.push_back({key, exec, 0});
       hit = &h->graphs.back();
+      ++h->graph_captures;
     }
+    hit->last_use = ++h->graph_clock;
+    ++h->graph_launches;
     FDX_HIP(h, hipGraphLaunch(hit->exec, s));
   }
 
   // ---------------------------------------------------------------- finish (eager): sx -> x
   hipLaunchKernelGGL(k_copy_rows, grid, blk, 0, s, x, (long)M * T, T, h->sx.f() + kHalo, bs, ld, M, T, 1.f, (const uint8_t*)nullptr);
   FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
+}
+
+extern "C" int fdx_graph_stats(fdx_handle h, long* captures, long* launches, int* cached) {
+  if (!h) return FDX_E_ARG;
+  if (captures) *captures = h->graph_captures;
+  if (launches) *launches = h->graph_launches;
+  if (cached) *cached = (int)h->graphs.size();
   return FDX_OK;
 }
 

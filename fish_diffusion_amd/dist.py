@@ -77,7 +77,12 @@ def broadcast_arena(desc, kind: str, tensors: Optional[Sequence[torch.Tensor]], 
     if arena.numel() != nbytes:
         raise RuntimeError(f"{kind} arena is {arena.numel()} bytes, expected {nbytes}")
     if dist.is_initialized():
-        dist.broadcast(arena, src=src)
+        if device.type == "cuda" and dist.get_backend() == "gloo":   # CPU collective, device arena (tests: two ranks on one GPU)
+            host = arena.cpu() if rank == src else torch.empty(nbytes, dtype=torch.uint8)
+            dist.broadcast(host, src=src)
+            arena = arena if rank == src else host.to(device)
+        else:
+            dist.broadcast(arena, src=src)   # "nccl" = RCCL over xGMI
     return arena
 
 

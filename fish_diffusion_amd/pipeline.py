@@ -6,10 +6,13 @@ dimension always 1) and shards across GPUs by rank-strided file lists (tools/pre
 this module does for a list of utterances per process:
 
   * `dist.shard_utterances`: longest-first round-robin over ranks (no collective);
-  * micro-batches of similar length, padded to the longest member, with `x_masks` / `cond_masks`
+  * micro-batches of similar length, padded to the longest member rounded UP to a 64-frame bucket (the kernels' column tile: the
+    padding costs no extra tiles), with `x_masks` / `cond_masks`
     (`DiffSinger.get_mask_from_lengths`, diffsinger.py:42-55) so that padding never leaks into valid frames
     (masked conditioner, masked denoiser input/output: wavenet.py:217-221,233-234);
-  * one `GaussianDiffusion` call (a recorded hipGraph per geometry) per micro-batch -- the reference's own batched +
+  * one `GaussianDiffusion` call per micro-batch; the sampler body is a recorded hipGraph per (batch size, padded length), and the
+    buckets keep the number of distinct geometries a ragged stream produces to a few dozen, all of which stay cached: a serving
+    loop re-captures nothing in steady state -- the reference's own batched +
     masked semantics (what its validation loop runs); frames within the receptive field of an utterance's end see the
     masked tail's activations instead of zero padding, exactly as in the reference, so they are not bit-identical to a
     one-by-one run;
@@ -76,10 +79,11 @@ def make_batches(lengths: Sequence[int], max_batch: int, max_pad_ratio: Optional
 def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequence[torch.Tensor], *, max_batch: int = 8,
                sampler_interval: Optional[int] = None, noise_predictor: Optional[str] = None, rank: int = 0, world: int = 1,
                mel_scale: Optional[float] = None, x_init_fn: Optional[Callable] = None,
-               source_noise_fn: Optional[Callable] = None) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
+               source_noise_fn: Optional[Callable] = None, bucket: int = 64) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
     """features[i]: [T_i, E] device tensors; f0s[i]: [T_i].  Returns [(index, mel [T_i, M], wav [T_i * hop])] for the
     utterances this rank owns.  `x_init_fn(idx_list, M, T)` / `source_noise_fn(idx_list, L)` let tests inject the random
-    draws (initial x_T; (rand_ini, src_noise)) -- by default they are drawn on the device."""
+    draws (initial x_T; (rand_ini, src_noise)) -- by default they are drawn on the device.  `bucket`: every micro-batch is padded
+    to a multiple of this many frames (masked like any other padding; 0 / 1 = pad to the longest member only)."""
     if len(features) != len(f0s):
         raise ValueError("features and f0s must have the same length")
     lengths = [int(f.shape[0]) for f in features]
@@ -95,6 +99,8 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     for group in make_batches([lengths[i] for i in mine], max_batch):
         idx = [mine[g] for g in group]
         T = max(lengths[i] for i in idx)
+        if bucket and bucket > 1:
+            T = (T + bucket - 1) // bucket * bucket
         B = len(idx)
         feat = torch.zeros((B, T, features[idx[0]].shape[1]), device=dev, dtype=torch.float32)
         f0 = torch.zeros((B, T), device=dev, dtype=torch.float32)

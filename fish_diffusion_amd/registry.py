@@ -56,7 +56,7 @@ def install(override: bool = True) -> bool:
     from .tfdec import TransformerDecoderDenoiser
     from .wavenet import WaveNet
 
-    try:  # pragma: no cover - needs the reference package + mmengine
+    try:   # needs the reference package (+ mmengine or a stand-in): tests/test_install.py
         from fish_diffusion.archs.diffsinger.diffusions.builder import DENOISERS as R_DEN, DIFFUSIONS as R_DIF
         from fish_diffusion.modules.vocoders.builder import VOCODERS as R_VOC
     except Exception:

@@ -363,6 +363,9 @@ int fdx_prof_select(fdx_handle h, int kind);
 int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch);
 /* Median elapsed time (ms) of an EMPTY hipEventRecord start/stop pair on stream s (diagnostic: what
  * bracketing a launch with plain recorded events would add; fdx_prof_* does not use that method). */
+/* Recorded-sampler-graph cache of this handle: graphs captured so far, graph launches so far, graphs currently cached
+ * (LRU of 48, FDX_GRAPH_CACHE=<n> overrides).  A serving loop in steady state shows launches growing and captures flat. */
+int fdx_graph_stats(fdx_handle h, long* captures, long* launches, int* cached);
 int fdx_prof_calibrate(fdx_handle h, fdx_stream s, double* empty_pair_ms);
 
 #ifdef __cplusplus

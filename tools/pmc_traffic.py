@@ -2,7 +2,10 @@
 """HBM traffic per launch of the dominant kernels from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected
 in SEPARATE runs: they do not fit one pass on gfx950's 4 TCC counters).
 
-    python tools/pmc_traffic.py <fetch_db> <write_db> > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py <fetch_db> <write_db> [config] > profiles/rNN_<config>_pmc_traffic.json
+
+`config` (headline | vocoder | sharded | ddpm1000 | ddpm1000_bf16, default headline) is recorded as the file's "workload" -- the
+bench.py configuration the passes were collected on; bench.py only quotes a file's numbers for that workload.
 
 Units and corrections, per /opt/skills/guides/MI355X_MICROARCH.md section HBM: both counters are in KiB-like units of
 1024 B as reported by rocprofv3; on gfx950 FETCH_SIZE counts 128-byte requests at 64 B, i.e. reports half of the bytes
@@ -22,7 +25,11 @@ def per_kernel(db, counter):
 
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"source": {"fetch_db": sys.argv[1], "write_db": sys.argv[2]},
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "headline"
+    workloads = {"headline": {"config": "headline", "batch": 1, "frames": 861}, "vocoder": {"config": "vocoder", "batch": 32, "frames": 1722},
+                 "sharded": {"config": "sharded", "batch": 8, "frames": 861}, "ddpm1000": {"config": "ddpm1000", "batch": 16, "frames": 861},
+                 "ddpm1000_bf16": {"config": "ddpm1000_bf16", "batch": 16, "frames": 861}}
+    out = {"source": {"fetch_db": sys.argv[1], "write_db": sys.argv[2]}, "workload": workloads[cfg],
            "note": "bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024",
            "kernels": {}}
     for k in fetch:
