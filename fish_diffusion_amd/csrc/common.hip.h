@@ -119,6 +119,10 @@ struct fdx_ctx {
   int B = 0, T = 0, ld = 0;            // prepared geometry
   bool prepared = false;
   fdx::DevBuf xin, X, Y, Z, SK, H, EPS, P, condp, condraw, P2;
+  fdx::DevBuf wn_nr2;                    // dilated-conv weights in the NR = 2 fragment order (convgemm16s.hip.h), derived at attach
+  std::vector<size_t> wn_nr2_off;        // per layer, in floats
+  bool wn_nr2_ok = false;
+  int conv_shape_nr = 4, conv_shape_nm = 4;   // tile shape of the dilated conv + gate for the prepared geometry
   const void* wn_arena_bf16 = nullptr;   // opt-in bf16 storage mode: residual-block weights as bf16 fragments (wavenet.hip)
   fdx::DevBuf Yb, Zb;                    // ... and the two GEMM operands in C8-blocked bf16
   int bf16_B = 0, bf16_T = 0;            // geometry Yb / Zb were last zeroed for

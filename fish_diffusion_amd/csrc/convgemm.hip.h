@@ -760,6 +760,9 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
     for (; done + D <= n; done += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
+#ifdef FDX_KTRACE
+      if (done == 0) FDX_STAMP(6);   // first pass over the ring done: (t6 - t1) - D slots of MFMA issue = the pipeline's fill time
+#endif
     }
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)

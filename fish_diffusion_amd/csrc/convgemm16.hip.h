@@ -210,6 +210,9 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
     for (; done + D <= n; done += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
+#ifdef FDX_KTRACE
+      if (done == 0) FDX_STAMP(6);
+#endif
     }
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)

@@ -1,0 +1,377 @@
+// convgemm16s.hip.h -- the residual-block pair of the denoiser on `v_mfma_f32_16x16x4_f32` with a SHAPE-ADAPTIVE workgroup tile.
+//
+// The denoiser's two GEMMs are small at batch 1 (1024 rows x ~861 columns): with a fixed 64 x 64 tile they give 224 workgroups
+// for 256 CUs, and at 5 s (T = 430) only 112.  Per-element arithmetic on this MFMA does not depend on the tile a workgroup
+// owns (every output is the same k-ordered fp32 fma chain, split over the same four K ranges and summed in the same order), so
+// the tile shape is a pure scheduling choice -- made per launch by `pick_shape16` from (rows, batch, frames):
+//
+//   tile = NR 16-row blocks  x  NM*16 columns          NR in {2, 4},  NM in {4 .. 8}
+//   lane l: lj = l & 15 owns the NM ADJACENT columns t0 + NM*lj .. +NM-1 (one 16-byte load + one tail load per k-row feeds NM
+//   MFMAs of interleaved column sets {NM*j + m}), lk = l >> 4 is the k-row of B / k of A / row quad of D.
+//   T = 861:  NR = 2, NM = 7  ->  32 x 8 = 256 workgroups of 32 x 112 (was 16 x 14 = 224 of 64 x 64): 7/8 of the MFMA work
+//   per workgroup and every CU busy.   T = 430: NR = 2, NM = 4 -> 224 workgroups (was 112).
+//
+// Same contraction, split-K workgroup (4 waves, fixed-order LDS reduction), operand pipeline and epilogue arithmetic as
+// convgemm16.hip.h (whose NR = 4, NM = 4 instance this file generalises).
+//
+// A fragments are host-packed for NR = 4 (`pack_convgemm16`: one float4 per lane = the four 16-row blocks of a 64-row tile);
+// the NR = 2 order (one float2 per lane) is derived from it on the device at attach time (`k_repack16_nr2`), so the packed
+// arena -- what the RCCL broadcast ships -- does not change.
+#pragma once
+#include "convgemm16.hip.h"
+
+namespace fdx {
+
+template <int N> struct VecN { float v[N]; };
+struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
+
+// N adjacent floats at any dword alignment (sources are the library's own padded rows: >= kTailPad floats of slack right of T)
+template <int N> __device__ __forceinline__ VecN<N> ldN(const float* p) {
+  static_assert(N >= 4 && N <= 8, "4..8 columns per lane");
+  VecN<N> r;
+  const f4u a = *reinterpret_cast<const f4u*>(p);
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  if constexpr (N == 5) { r.v[4] = p[4]; }
+  if constexpr (N == 6) { const f2u b = *reinterpret_cast<const f2u*>(p + 4); r.v[4] = b.x; r.v[5] = b.y; }
+  if constexpr (N == 7) { const f3u b = *reinterpret_cast<const f3u*>(p + 4); r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; }
+  if constexpr (N == 8) { const f4u b = *reinterpret_cast<const f4u*>(p + 4); r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w; }
+  return r;
+}
+// store into a padded row: columns >= T (at most N-1, inside the right pad) receive 0 -- what the pad must hold anyway.
+// NT: non-temporal (tiles read next by other XCDs), else normal caching (tiles the same workgroup re-reads next layer).
+template <int N, bool NT> __device__ __forceinline__ void stNp(float* p, VecN<N> v, int nvalid) {
+#pragma unroll
+  for (int i = 1; i < N; ++i) v.v[i] = nvalid > i ? v.v[i] : 0.f;
+  typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f3nt __attribute__((ext_vector_type(3), aligned(4)));
+  typedef float f2nt __attribute__((ext_vector_type(2), aligned(4)));
+  if constexpr (NT) {
+    __builtin_nontemporal_store(f4nt{v.v[0], v.v[1], v.v[2], v.v[3]}, reinterpret_cast<f4nt*>(p));
+    if constexpr (N == 5) __builtin_nontemporal_store(v.v[4], p + 4);
+    if constexpr (N == 6) __builtin_nontemporal_store(f2nt{v.v[4], v.v[5]}, reinterpret_cast<f2nt*>(p + 4));
+    if constexpr (N == 7) __builtin_nontemporal_store(f3nt{v.v[4], v.v[5], v.v[6]}, reinterpret_cast<f3nt*>(p + 4));
+    if constexpr (N == 8) __builtin_nontemporal_store(f4nt{v.v[4], v.v[5], v.v[6], v.v[7]}, reinterpret_cast<f4nt*>(p + 4));
+  } else {
+    f4u a; a.x = v.v[0]; a.y = v.v[1]; a.z = v.v[2]; a.w = v.v[3];
+    *reinterpret_cast<f4u*>(p) = a;
+    if constexpr (N == 5) p[4] = v.v[4];
+    if constexpr (N == 6) { f2u b; b.x = v.v[4]; b.y = v.v[5]; *reinterpret_cast<f2u*>(p + 4) = b; }
+    if constexpr (N == 7) { f3u b; b.x = v.v[4]; b.y = v.v[5]; b.z = v.v[6]; *reinterpret_cast<f3u*>(p + 4) = b; }
+    if constexpr (N == 8) { f4u b; b.x = v.v[4]; b.y = v.v[5]; b.z = v.v[6]; b.w = v.v[7]; *reinterpret_cast<f4u*>(p + 4) = b; }
+  }
+}
+
+// Right pad (floats) every row of the denoiser's activation buffers needs for these tiles: the last tile may overhang T by up to
+// 16*8 - 1 columns and a dilated tap reads up to 16 columns further.
+constexpr int kTailPad = 160;
+
+template <int NM> struct EpiGate16S {  // wavenet.py:112-115 (EpiGate16 for NM columns per lane)
+  static constexpr bool kPaired = true;
+  float* out; long o_bs; int ldo;
+  const float* P; long p_bs; int ldp;
+  int C;
+  struct Pre { VecN<NM> pg, pf; };
+  __device__ __forceinline__ Pre load(int b, int row, int t) const {
+    const float* q = P + b * p_bs + t;
+    return Pre{ldN<NM>(q + (long)row * ldp), ldN<NM>(q + (long)(row + C) * ldp)};
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, int nvalid, const VecN<NM>& g, const VecN<NM>& f, const Pre& p) const {
+    VecN<NM> z;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) z.v[m] = EpiGate::gate1(g.v[m] + p.pg.v[m], f.v[m] + p.pf.v[m]);
+    stNp<NM, true>(out + b * o_bs + (long)row * ldo + t, z, nvalid);
+  }
+};
+
+template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum of :228 (EpiResSkip16 for NM columns per lane)
+  static constexpr bool kPaired = false;
+  float* X; float* Y; float* SK; long bs; int ld;
+  const float* bias;
+  const float* sb; int sb_ld, sb_bs;
+  int C, skip_mode;
+  float inv_div, r_inv_div;
+  struct Pre { VecN<NM> old; float bias, sb; };
+  __device__ __forceinline__ bool is_res(int row) const { return __builtin_amdgcn_readfirstlane(row) < C; }
+  __device__ __forceinline__ Pre load(int b, int row, int t) const {
+    Pre p;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) p.old.v[m] = 0.f;
+    p.bias = bias[row]; p.sb = 0.f;
+    if (is_res(row)) {
+      p.old = ldN<NM>(X + b * bs + (long)row * ld + t);
+      if (Y) p.sb = sb[(long)row * sb_ld + b * sb_bs];
+    } else if (skip_mode == 1 || skip_mode == 2) {
+      p.old = ldN<NM>(SK + b * bs + (long)(row - C) * ld + t);
+    }
+    return p;
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, int nvalid, VecN<NM> v, const Pre& p) const {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) v.v[m] += p.bias;
+    if (is_res(row)) {
+      const long o = b * bs + (long)row * ld + t;
+      VecN<NM> xn, yn;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        xn.v[m] = div_const(p.old.v[m] + v.v[m], 1.41421356237309504880f, 0.70710678118654752440f);
+        yn.v[m] = xn.v[m] + p.sb;
+      }
+      stNp<NM, false>(X + o, xn, nvalid);
+      if (Y) stNp<NM, true>(Y + o, yn, nvalid);
+    } else {
+      const long o = b * bs + (long)(row - C) * ld + t;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        float s = v.v[m];
+        if (skip_mode == 1 || skip_mode == 2) s = p.old.v[m] + s;
+        if (skip_mode >= 2) s = div_const(s, inv_div, r_inv_div);
+        v.v[m] = s;
+      }
+      stNp<NM, false>(SK + o, v, nvalid);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------ kernel
+// Packed A: NR = 4: [m64-tile][it][h][lane] float4 (pack_convgemm16);  NR = 2: [m32-tile][it][h][lane] float2 (k_repack16_nr2).
+// Paired epilogues: blocks 0 .. NR/2-1 hold the tile's gate rows (16 channels each), blocks NR/2 .. NR-1 the matching filter rows.
+template <class Epi, int NR, int NM>
+__global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
+  FDX_CONV_ARGS_FROM_HOT(cold);
+  static_assert(NR == 2 || NR == 4, "2 or 4 row blocks");
+  constexpr int NW = 4, COLS = 16 * NM, STR = NM <= 4 ? 4 : 8;      // LDS stride (floats) of a lane's NM partial sums
+  a.tiles_per_item = (a.T + COLS - 1) / COLS;
+  __shared__ float red[NW * NR * 4 * kWave * STR];                  // [wave][x*4 + reg][lane][m]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lj = lane & 15, lk = lane >> 4;
+  FDX_STAMP(0);
+
+  const int G = a.n_tiles_n * a.n_mtiles, bid = blockIdx.x;         // == gridDim.x, from preloaded arguments
+  const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
+  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int mt = L / a.n_tiles_n;
+  const int nt = L - mt * a.n_tiles_n;
+  const int item = nt / a.tiles_per_item;
+  const int t0 = (nt - item * a.tiles_per_item) * COLS;
+  const int tc = t0 + NM * lj;                                        // this lane's first column
+  const int nvalid = min(NM, a.T - tc);                               // <= 0: all of the lane's columns are overhang
+  constexpr int ROWS = Epi::kPaired ? NR * 8 : NR * 16;               // logical rows (pairs) per tile
+  const int row_base = mt * ROWS;
+
+  const int per = (a.n_it + NW - 1) / NW;
+  const int it_begin = wave * per, it_end = min(a.n_it, it_begin + per);
+
+  // epilogue sites of the tile: paired: (gate block gb, reg) -> NR/2 * 4;  unpaired: (block x, reg) -> NR * 4; NS per wave
+  constexpr int NSITES = Epi::kPaired ? NR * 2 : NR * 4, NS = NSITES / NW;
+  static_assert(NS >= 1, "at least one site per wave");
+  auto site_row = [&](int sidx) { return row_base + (sidx >> 2) * 16 + lk * 4 + (sidx & 3); };
+  typename Epi::Pre pre[NS];
+  auto prefetch_epilogue = [&]() {
+    if (nvalid > 0) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) pre[i] = epi.load(item, site_row(wave * NS + i), tc);
+    }
+  };
+
+  f4 acc[NR][NM];
+#pragma unroll
+  for (int x = 0; x < NR; ++x)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[x][m] = f4{0.f, 0.f, 0.f, 0.f};
+
+  if (it_begin < it_end) {
+    struct Stage { float a[2][NR]; VecN<NM> b[2]; };                  // two K = 4 sub-steps = 8 channels
+    const int n = it_end - it_begin;
+    const int cb0 = it_begin / a.taps, tap0 = it_begin - cb0 * a.taps;
+    constexpr unsigned ASTEP = 2u * 64u * NR * 4u;                      // bytes of A per K iteration
+    const char* Abase = reinterpret_cast<const char*>(a.Wp) + ((size_t)mt * a.n_it + it_begin) * ASTEP;
+    const char* Xbase = reinterpret_cast<const char*>(a.X + item * a.x_bstride + a.shift0 + t0);
+    const unsigned rs = (unsigned)a.ldx * 4u;
+    const unsigned d_tap = (unsigned)a.dshift * 4u;
+    const unsigned d_wrap = 8u * rs - (unsigned)(a.taps - 1) * d_tap;
+    const int itl = it_end - 1, cbl = itl / a.taps, tapl = itl - cbl * a.taps;
+    const unsigned a_last = (unsigned)(n - 1) * ASTEP;
+    const unsigned x_last = (unsigned)cbl * 8u * rs + (unsigned)tapl * d_tap;
+    unsigned a_off = 0, x_off = (unsigned)cb0 * 8u * rs + (unsigned)tap0 * d_tap;
+    int tap = tap0;
+    const unsigned a_lane = lane * (NR * 4u);
+    const unsigned x_lane0 = (unsigned)lk * rs + (unsigned)lj * (NM * 4u), x_lane1 = x_lane0 + 4u * rs;
+
+    auto load = [&](Stage& s) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const char* pa = Abase + (a_off + a_lane + h * (64u * NR * 4u));
+        if constexpr (NR == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(pa);
+          s.a[h][0] = v.x; s.a[h][1] = v.y; s.a[h][2] = v.z; s.a[h][3] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(pa);
+          s.a[h][0] = v.x; s.a[h][1] = v.y;
+        }
+      }
+      s.b[0] = ldN<NM>(reinterpret_cast<const float*>(Xbase + (x_off + x_lane0)));
+      s.b[1] = ldN<NM>(reinterpret_cast<const float*>(Xbase + (x_off + x_lane1)));
+      const bool wrap = tap + 1 == a.taps;
+      a_off = min(a_off + ASTEP, a_last);
+      x_off = min(x_off + (wrap ? d_wrap : d_tap), x_last);
+      tap = wrap ? 0 : tap + 1;
+    };
+    auto compute = [&](Stage& s) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+          for (int x = 0; x < NR; ++x) acc[x][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.a[h][x], s.b[h].v[m], acc[x][m], 0, 0, 0);
+    };
+    constexpr int NLOADS = 2 + (NM == 4 ? 2 : 4);                       // vector loads per slot
+    constexpr int NMFMA = 2 * NM * NR;
+    auto slot = [&](Stage& Ld, Stage& C) {
+      load(Ld);
+      compute(C);
+#pragma unroll
+      for (int k = 0; k < NLOADS; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMAs (2 x 32 cycles)
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // a few VALU / SALU
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NLOADS, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    constexpr int D = 4;
+    Stage st[D];
+    FDX_STAMP(1);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load(st[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_epilogue();
+    __builtin_amdgcn_sched_barrier(0);
+    int done = 0;
+    for (; done + D <= n; done += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
+#ifdef FDX_KTRACE
+      if (done == 0) FDX_STAMP(6);
+#endif
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (done + d < n) compute(st[d]);
+  } else {
+    prefetch_epilogue();
+  }
+  FDX_STAMP(2);
+
+  // ---- cross-wave K reduction through LDS, fixed order w0 + w1 + w2 + w3
+  f4* redv = reinterpret_cast<f4*>(red);
+  constexpr int Q = STR / 4;                                            // float4 slots per (row, lane)
+#pragma unroll
+  for (int x = 0; x < NR; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int base = ((wave * (NR * 4) + x * 4 + r) * kWave + lane) * Q;
+      float t[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) t[m] = 0.f;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) t[m] = acc[x][m][r];
+      redv[base] = f4{t[0], t[1], t[2], t[3]};
+      if constexpr (NM > 4) redv[base + 1] = f4{t[4], t[5], t[6], t[7]};
+    }
+  FDX_STAMP(3);
+  __syncthreads();
+  FDX_STAMP(4);
+  if (nvalid <= 0) return;
+  auto rsum = [&](int s) {   // s = x*4 + reg
+    VecN<NM> out;
+    f4 lo = redv[((0 * (NR * 4) + s) * kWave + lane) * Q];
+    f4 hi = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NM > 4) hi = redv[((0 * (NR * 4) + s) * kWave + lane) * Q + 1];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      lo += redv[((w * (NR * 4) + s) * kWave + lane) * Q];
+      if constexpr (NM > 4) hi += redv[((w * (NR * 4) + s) * kWave + lane) * Q + 1];
+    }
+    out.v[0] = lo[0]; out.v[1] = lo[1]; out.v[2] = lo[2]; out.v[3] = lo[3];
+#pragma unroll
+    for (int m = 4; m < NM; ++m) out.v[m] = hi[m - 4];
+    return out;
+  };
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int sidx = wave * NS + i;
+    if constexpr (Epi::kPaired) epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), rsum(sidx + NR * 2), pre[i]);
+    else epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), pre[i]);
+  }
+  FDX_STAMP(5);
+}
+
+template <class Epi, int NR, int NM>
+inline hipError_t launch_convgemm16s(const ConvGeom& g, const void* Wp, const float* X, long x_bstride, int ldx, const Epi& epi,
+                                     hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+  ConvArgs a;
+  a.Wp = static_cast<const float4*>(Wp); a.X = X; a.x_bstride = x_bstride; a.ldx = ldx;
+  a.n_it = g.cin8 * g.taps; a.taps = g.taps; a.shift0 = g.shift0; a.dshift = g.dshift;
+  a.T = g.T;
+  a.tiles_per_item = (g.T + 16 * NM - 1) / (16 * NM);
+  a.n_tiles_n = g.B * a.tiles_per_item;
+  a.n_mtiles = g.n_mtiles;             // tiles of NR 16-row blocks
+  a.in_slope = 1.f;
+  a.col_stats = nullptr; a.ln_R = nullptr; a.n_groups = 0; a.ln_eps = 0.f;
+  const int grid = a.n_tiles_n * a.n_mtiles;
+  if (grid <= 0) return hipSuccess;
+#ifdef FDX_KTRACE
+  a.trace = nullptr;
+  if (g_trace.buf && g_trace.n < g_trace.max_launches && grid <= g_trace.blocks_cap)
+    a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
+#endif
+  if (ev_start)
+    hipExtLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+  else
+    hipLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ shape choice
+struct Shape16 { int NR, NM; };
+// rows16: 16-row blocks of the GEMM (paired: 16-pair blocks x 2).  Cost model: workgroups run in rounds of one per CU (256);
+// a workgroup's time = its MFMA issue (2 * NM * NR MFMAs of 32 cycles per K iteration; the K loop is the same for every shape,
+// so only the per-iteration count matters) + a fixed ~12 k cycles of set-up / pipeline fill / reduction / epilogue measured with
+// tools/ktrace.py, expressed in MFMA-equivalents of this launch's K loop by the caller (fixed_per_k).  NR = 4 reads a third fewer
+// operand bytes per MFMA, so it wins ties (2 % margin).
+inline Shape16 pick_shape16(int rows16, int B, int T, double fixed_mfma_equiv, int n_cu = 256) {
+  Shape16 best{4, 4};
+  double best_cost = 1e300;
+  for (int NR = 4; NR >= 2; NR -= 2) {
+    if (rows16 % NR) continue;
+    for (int NM = 4; NM <= 8; ++NM) {
+      const long wgs = (long)(rows16 / NR) * B * ((T + 16 * NM - 1) / (16 * NM));
+      const long rounds = (wgs + n_cu - 1) / n_cu;
+      double cost = (double)rounds * (2.0 * NM * NR + fixed_mfma_equiv);
+      if (NR == 2) cost *= 1.02;
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = Shape16{NR, NM}; }
+    }
+  }
+  return best;
+}
+
+// NR = 2 fragment order from the NR = 4 one:  dst[2*mt + b][it][h][lane][half] = src[mt][it][h][lane][half*2 + b]
+// (paired layout: rbk 0,1 = gate blocks, 2,3 = filter blocks of a 32-pair tile; unpaired: rbk = consecutive 16-row blocks, for
+// which the same formula yields tiles {rbk 0, 2} and {1, 3} -- so unpaired weights use `pairs_mode = 0`: dst[2*mt + b][..][half] =
+// src[mt][..][2*b + half]).
+static __global__ void k_repack16_nr2(float2* __restrict__ dst, const float4* __restrict__ src, size_t n_src, int n_it, int paired) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // index of a source float4 = ((mt*n_it + it)*2 + h)*64 + lane
+  if (i >= n_src) return;
+  const float4 v = src[i];
+  const size_t per_mt = (size_t)n_it * 128;
+  const size_t mt = i / per_mt, rem = i - mt * per_mt;
+  const float2 b0 = paired ? float2{v.x, v.z} : float2{v.x, v.y};
+  const float2 b1 = paired ? float2{v.y, v.w} : float2{v.z, v.w};
+  dst[(2 * mt) * per_mt + rem] = b0;
+  dst[(2 * mt + 1) * per_mt + rem] = b1;
+}
+
+}  // namespace fdx

@@ -14,7 +14,7 @@
 // all timesteps at once.
 #include "common.hip.h"
 #include "elementwise.hip.h"
-#include "convgemm16.hip.h"
+#include "convgemm16s.hip.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -40,6 +40,13 @@ static bool conv16() { return resblock_mode() & 1; }
 static bool outp16() { return resblock_mode() & 2; }
 
 static long kMinTilesMT2 = 1L << 60;   // disabled; FDX_MT2_MIN_TILES overrides (read in fdx_wavenet_attach)
+// Shape-adaptive tiles for the dilated conv + gate (convgemm16s.hip.h).  FDX_CONV_SHAPE=0 disables (always the 64 x 64 tile),
+// FDX_CONV_SHAPE=<NR><NM> (e.g. 27) forces one shape for A/B runs.
+static int conv_shape_env() {
+  static const int v = [] { const char* e = getenv("FDX_CONV_SHAPE"); return e ? atoi(e) : -1; }();
+  return v;
+}
+static bool shapes_enabled() { return conv_shape_env() != 0; }
 
 
 // ================================================================================================ layout
@@ -198,6 +205,28 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
   h->wn_arena = static_cast<const float*>(dev);
   h->wn_ok = true;
   h->prepared = false;
+  ++h->alloc_gen;   // recorded graphs bake the arena (and the derived buffer below) in
+  // Shape-adaptive tiles (convgemm16s.hip.h): the dilated conv's weights once more in the NR = 2 fragment order, derived on the
+  // device from the packed (NR = 4) arena.  One-off at model load: default stream, synchronous.
+  h->wn_nr2_ok = false;
+  if (conv16() && shapes_enabled()) {
+    FDX_HIP(h, hipSetDevice(h->device));
+    size_t total = 0;
+    for (const auto& p : l.conv) total += packed_floats(p.n_mtiles, 2, p.cin8, p.taps);
+    FDX_HIP(h, h->wn_nr2.ensure(total * sizeof(float), false, nullptr));
+    size_t cur = 0;
+    h->wn_nr2_off.clear();
+    for (const auto& p : l.conv) {
+      const size_t n_src = packed_floats(p.n_mtiles, 2, p.cin8, p.taps) / 4;   // float4 count
+      h->wn_nr2_off.push_back(cur);
+      hipLaunchKernelGGL(k_repack16_nr2, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, nullptr, reinterpret_cast<float2*>(h->wn_nr2.f() + cur),
+                         reinterpret_cast<const float4*>(h->wn_arena + p.w_off), n_src, p.cin8 * p.taps, 1);
+      cur += n_src * 4;
+    }
+    FDX_HIP(h, hipGetLastError());
+    FDX_HIP(h, hipStreamSynchronize(nullptr));
+    h->wn_nr2_ok = true;
+  }
   return FDX_OK;
 }
 
@@ -419,9 +448,21 @@ static EpiBias epi_bias(float* out, long o_bs, int ldo, const float* bias, int M
 static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   const auto& d = h->wd;
   const int C = d.residual_channels, L = d.residual_layers, M = d.mel_channels, E = d.d_encoder;
-  const int ld = padded_ld(T, 64);
+  // rows: kHalo zeros, T values, zeros up to the next multiple of 64 + kTailPad (the shape-adaptive tiles may overhang by up to
+  // 127 columns, a dilated tap reads 16 further)
+  const int ld = kHalo + round_up(T, 64) + kTailPad;
   const bool geom = (B != h->B || T != h->T || h->den_kind != 0);
   h->B = B; h->T = T; h->ld = ld;
+  {  // tile shape of the dilated conv + gate for this geometry
+    const int rows16 = 2 * C / 16, n_per_wave = (C / 8 * 3 + 3) / 4;
+    Shape16 sh{4, 4};
+    const long wg44 = (long)(rows16 / 4) * B * ((T + 63) / 64);
+    if (h->wn_nr2_ok && wg44 < 2 * 256) sh = pick_shape16(rows16, B, T, 12000.0 / (32.0 * n_per_wave));
+    const int forced = conv_shape_env();
+    if (forced > 0) sh = Shape16{forced / 10, forced % 10};
+    if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8 || (sh.NR == 2 && !h->wn_nr2_ok)) sh = Shape16{4, 4};
+    h->conv_shape_nr = sh.NR; h->conv_shape_nm = sh.NM;
+  }
   auto sz = [&](int ch) { return (size_t)B * ch * ld * sizeof(float); };
   // every buffer that is read with column shifts must have zero halos => re-zero on geometry change
   FDX_HIP(h, h->xin.ensure(sz(M), geom, s));
@@ -563,9 +604,24 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     if (conv16()) {
       const ConvGeom gc{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles};
       EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
-      static const int conv_var = [] { const char* e = getenv("FDX_CONV_VAR"); return e ? atoi(e) : 0; }();   // tuning experiments
-      if (conv_var == 2) FDX_HIP(h, (launch_convgemm16<EpiGate16, 2>(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1)));
-      else FDX_HIP(h, launch_convgemm16(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
+      const int NRs = h->conv_shape_nr, NMs = h->conv_shape_nm;
+      if (NRs == 4 && NMs == 4) {
+        FDX_HIP(h, launch_convgemm16(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
+      } else {
+        const void* W4 = A + l.conv[i].w_off;
+        const void* W2 = h->wn_nr2_ok ? h->wn_nr2.f() + h->wn_nr2_off[i] : nullptr;
+        const ConvGeom g4{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles}, g2{B, T, l.conv[i].cin8, 3, -dil, dil, 2 * l.conv[i].n_mtiles};
+        hipError_t e = hipErrorInvalidValue;
+#define FDX_GATE_SHAPE(NR_, NM_)                                                                                              \
+  if (NRs == NR_ && NMs == NM_) {                                                                                             \
+    const EpiGate16S<NM_> gs{Z, bsC, ld, Pl, p_bs, ld, C};                                                                    \
+    e = launch_convgemm16s<EpiGate16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Y, bsC, ld, gs, s, ev0, ev1);   \
+  }
+        FDX_GATE_SHAPE(4, 5) FDX_GATE_SHAPE(4, 6) FDX_GATE_SHAPE(4, 7) FDX_GATE_SHAPE(4, 8)
+        FDX_GATE_SHAPE(2, 4) FDX_GATE_SHAPE(2, 5) FDX_GATE_SHAPE(2, 6) FDX_GATE_SHAPE(2, 7) FDX_GATE_SHAPE(2, 8)
+#undef FDX_GATE_SHAPE
+        FDX_HIP(h, e);
+      }
     } else {
       EpiGate g{};
       g.out = Z; g.o_bs = bsC; g.ldo = ld;

@@ -263,22 +263,29 @@ def test_ragged_stream_of_40_lengths_recaptures_nothing_after_warmup(dev):
     print(f"graphs: captured {c1} in the first pass, {c2 - c1} in the second; launches {l1} -> {l2}; cached {n2}")
     assert c2 == c1 and l2 == 2 * l1 and n2 <= 48 and c1 <= 10      # batch sizes {1, 2} x buckets {64 .. 320}
     assert len(res) == 40 and all(torch.isfinite(w).all() for _, _, w in res)
-    # bucketed + masked == the oracle on the same padded batch
-    x_all = torch.randn(2, 128, 128, generator=g)
-    idx = [i for i in range(40) if 64 < lens[i] <= 128][:2]
-    if len(idx) == 2:
-        r = pipeline.synthesize(diff, voc, [feats[i] for i in idx], [f0s[i] for i in idx], max_batch=2, sampler_interval=100,
-                                x_init_fn=lambda ii, M, T: x_all[:len(ii), :, :T].to(dev))
-        order = sorted(range(2), key=lambda k: (-lens[idx[k]], k))
-        fb = torch.zeros(2, 128, 256)
-        for b, k in enumerate(order):
-            fb[b, :lens[idx[k]]] = feats[idx[k]].cpu()
-        masks = torch.arange(128)[None] >= torch.tensor([lens[idx[k]] for k in order])[:, None]
+    # bucketed + masked == the oracle on the same padded batches (same sharding / batching decisions, reference semantics)
+    from fish_diffusion_amd.dist import shard_utterances
+    sel = [i for i in range(40) if 64 < lens[i] <= 192][:5]
+    sl = [lens[i] for i in sel]
+    x_all = torch.randn(len(sel), 128, 192, generator=g)
+    r = pipeline.synthesize(diff, voc, [feats[i] for i in sel], [f0s[i] for i in sel], max_batch=2, sampler_interval=100,
+                            x_init_fn=lambda ii, M, T: torch.stack([x_all[i, :, :T] for i in ii]).to(dev))
+    by = {i: m.cpu() for i, m, _ in r}
+    mine = shard_utterances(sl, 0, 1)
+    den = _oracle_den(sd, WN_SMALL)
+    for group in pipeline.make_batches([sl[i] for i in mine], 2):
+        ii = [mine[k] for k in group]
+        T = (max(sl[i] for i in ii) + 63) // 64 * 64
+        fb = torch.zeros(len(ii), T, 256)
+        for b, i in enumerate(ii):
+            fb[b, :sl[i]] = feats[sel[i]].cpu()
+        masks = torch.arange(T)[None] >= torch.tensor([sl[i] for i in ii])[:, None]
+        assert masks.any()                        # no length is a multiple of 64 here: even the longest member is padded
         with torch.no_grad():
-            ref = sampler_ref.diffusion_sample(_oracle_den(sd, WN_SMALL), fb, x_init=x_all, sampler_interval=100, x_masks=masks, cond_masks=masks)
-        by = {i: m for i, m, _ in r}
-        for b, k in enumerate(order):
-            assert rel_err(by[k].cpu(), ref[b, :lens[idx[k]]]) < MEL_REL
+            ref = sampler_ref.diffusion_sample(den, fb, x_init=torch.stack([x_all[i, :, :T] for i in ii]), sampler_interval=100,
+                                               x_masks=masks, cond_masks=masks)
+        for b, i in enumerate(ii):
+            assert rel_err(by[i], ref[b, :sl[i]]) < MEL_REL, (i, sl[i], T)
 
 
 # ------------------------------------------------------------------------------------------------ broadcast onto a rank with other weights
@@ -322,3 +329,46 @@ dist.destroy_process_group()
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
     assert "OK" in outs[0][0]
+
+
+# ------------------------------------------------------------------------------------------------ shape-adaptive tiles
+def test_every_conv_tile_shape_is_bit_identical_to_the_64x64_tile(dev):
+    """convgemm16s.hip.h: the workgroup tile of the dilated conv + gate (NR 16-row blocks x NM*16 columns) is a scheduling choice --
+    every output element is the same k-ordered fp32 fma chain over the same four K ranges.  Each of the nine non-default shapes,
+    forced through FDX_CONV_SHAPE in its own process, must reproduce the fixed 64 x 64 tile's result BIT FOR BIT on ragged
+    geometries (tile overhang, T < one tile, odd T, batch > 1, masks), and the automatic choice must as well."""
+    code = r'''
+import os, sys, hashlib, torch
+sys.path.insert(0, %r)
+from fish_diffusion_amd import DENOISERS
+from tests.helpers import WN_SMALL, wavenet_sd
+dev = torch.device("cuda", 0)
+cfg = dict(WN_SMALL, residual_channels=128, residual_layers=5)
+net = DENOISERS.build(dict(type="WaveNetDenoiser", **cfg))
+torch.manual_seed(5)
+for p in net.parameters():
+    torch.nn.init.normal_(p, std=0.08)
+net = net.to(dev).eval()
+h = hashlib.sha1()
+g = torch.Generator().manual_seed(1)
+for B, T in ((1, 1), (1, 37), (2, 113), (1, 257), (3, 430), (1, 861)):
+    x, c, t = torch.randn(B, 128, T, generator=g).to(dev), torch.randn(B, 256, T, generator=g).to(dev), (torch.rand(B, generator=g) * 999).to(dev)
+    m = torch.zeros(B, T, dtype=torch.bool, device=dev)
+    m[-1, T - T // 5:] = True
+    for masks in (None, m):
+        y = net(x, t, c, x_masks=masks, cond_masks=masks)
+        assert torch.isfinite(y).all()
+        h.update(y.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+''' % ROOT
+    digests = {}
+    for shape in ("0", "auto", "45", "46", "47", "48", "24", "25", "26", "27", "28"):
+        env = dict(os.environ)
+        env.pop("FDX_CONV_SHAPE", None)
+        if shape != "auto":
+            env["FDX_CONV_SHAPE"] = shape
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DIGEST" in r.stdout, shape + "\n" + r.stdout + r.stderr
+        digests[shape] = r.stdout.split("DIGEST")[1].split()[0]
+    print(digests)
+    assert len(set(digests.values())) == 1, digests

@@ -34,7 +34,7 @@ torch.cuda.synchronize()
 lib.fdx_debug_trace(None, 0, 0)
 tr = buf.cpu().numpy().reshape(NL, CAP * 4, 8)  # 4 waves per workgroup
 names = ["setup+prefetch", "K loop", "LDS write", "barrier wait", "epilogue"]
-print(f"{'launch':>6} {'waves':>6} {'span':>8} | " + " ".join(f"{n:>14}" for n in names) + " | total/wave   (shader cycles, mean over waves; span = last end - first start)")
+print(f"{'launch':>6} {'waves':>6} {'span':>8} | " + " ".join(f"{n:>14}" for n in names) + " | total/wave  first 4 slots (shader cycles, mean over waves; span = last end - first start; first 4 slots = t6 - t1: fill + 4 slots of MFMA issue)")
 for l in range(NL):
     w = tr[l].reshape(-1, 8)
     w = w[w[:, 0] != 0]
@@ -42,4 +42,6 @@ for l in range(NL):
         continue
     d = np.diff(w[:, :6].astype(np.int64), axis=1)
     span = int(w[:, 5].max() - w[:, 0].min())
-    print(f"{l:>6} {len(w):>6} {span:>8} | " + " ".join(f"{d[:, i].mean():>14.0f}" for i in range(5)) + f" | {d.sum(1).mean():>10.0f}")
+    first = (w[:, 6].astype(np.int64) - w[:, 1].astype(np.int64))
+    first = first[w[:, 6] != 0]
+    print(f"{l:>6} {len(w):>6} {span:>8} | " + " ".join(f"{d[:, i].mean():>14.0f}" for i in range(5)) + f" | {d.sum(1).mean():>10.0f} {first.mean() if len(first) else 0:>10.0f}")
