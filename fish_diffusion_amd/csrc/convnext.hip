@@ -1,5 +1,5 @@
 // convnext.hip -- the ConvNext denoiser: fish_diffusion/modules/convnext.py:12-92 (ConvNeXtBlock),
-// :155-262 (ConvNext, cross_attention = False), registered as DENOISERS "ConvNextDenoiser"
+// :95-152 (CrossAttentionBlock), :155-262 (ConvNext, with and without cross_attention), registered as DENOISERS "ConvNextDenoiser"
 // (archs/diffsinger/diffusions/builder.py:12).  Same call contract as the WaveNet denoiser, so the sampler loop of
 // wavenet.hip drives it through the two hooks fdx_cn_embed / fdx_cn_forward_core.
 //
@@ -13,10 +13,16 @@
 // Hoisted, exactly as for the WaveNet: the conditioner path (conditioner_projection MLP, then the L condition_projection
 // 1x1 convs as ONE [L*D x D] GEMM) runs once per utterance batch (fdx_convnext_prepare); the step-embedding MLP and the L
 // diffusion_step_projection 1x1 convs run once per sampler run for all timesteps.
+//
+// cross_attention = True (convnext.py:186-193,246-250): a CrossAttentionBlock -- one nn.TransformerDecoderLayer (declayer.hip.h)
+// on x + diffusion_step_projection(step) + pos * scale_q, attending to condition + pos * scale_k -- in front of every
+// `cross_every_n_layers`-th ConvNeXt block, and the ConvNeXt blocks then run WITHOUT the condition term.  The memory of every
+// cross block is step-invariant, so its key / value projection is hoisted into fdx_convnext_prepare as well.
 #include "common.hip.h"
 #include "convplan.hip.h"
 #include "gemmplan.hip.h"
 #include "elementwise.hip.h"
+#include "declayer.hip.h"
 
 #include <cmath>
 
@@ -29,8 +35,16 @@ struct CnLayout {
   std::vector<PackedW> pw1, pw2, pw2w;   // pw2: 32-row tiles (small grids), pw2w: the same weights in 64-row tiles (large grids)
   std::vector<size_t> dw_w, dw_b, gamma, lnR;   // (norm.weight / norm.bias live folded inside pw1; lnR: [round_up(H, 64)][16] group row sums)
   std::vector<int> dil;
+  // cross-attention variant: one entry per CrossAttentionBlock, in front of ConvNeXt block `at_layer`
+  struct Cross { TdLayer dec; size_t scale_q, scale_k; int at_layer; };
+  std::vector<Cross> cross;
+  size_t pos = 0;            // positional_embedding [kCnPositions][D] (one copy: the blocks' buffers are identical, checked at pack time)
   size_t total_floats = 0;
 };
+constexpr int kCnPositions = 4096;   // CrossAttentionBlock.get_embedding(num_embeddings=4096), convnext.py:114
+constexpr int kCrossTensors = 3 + 18 + 2;
+
+int cn_n_cross(const fdx_convnext_desc& d) { return d.cross_attention > 0 ? (d.num_layers + d.cross_attention - 1) / d.cross_attention : 0; }
 
 int cn_validate(const fdx_convnext_desc* d) {
   if (!d) return fail(nullptr, FDX_E_ARG, "null convnext desc");
@@ -40,7 +54,9 @@ int cn_validate(const fdx_convnext_desc* d) {
     return fail(nullptr, FDX_E_ARG, "convnext: mel_channels and condition_dim must be multiples of 8");
   if (d->num_layers <= 0) return fail(nullptr, FDX_E_ARG, "convnext: num_layers must be positive");
   if (d->dilation_cycle < 1 || d->dilation_cycle > 4) return fail(nullptr, FDX_E_ARG, "convnext: dilation_cycle %d unsupported (3 * dilation must fit the %d-column halo)", d->dilation_cycle, kHalo);
-  if (d->cross_attention) return fail(nullptr, FDX_E_NOIMPL, "convnext: cross_attention=True is not built");
+  if (d->cross_attention < 0) return fail(nullptr, FDX_E_ARG, "convnext: cross_attention (= cross_every_n_layers, 0 = off) must be >= 0");
+  if (d->cross_attention > 0 && d->dim != 128 && d->dim != 256 && d->dim != 512)
+    return fail(nullptr, FDX_E_ARG, "convnext: cross-attention needs dim 128, 256 or 512 (8 heads of 16 / 32 / 64), got %d", d->dim);
   return FDX_OK;
 }
 
@@ -52,7 +68,8 @@ void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
   l.emb3 = plan64(cur, D, H);
   l.cond0 = plan64(cur, H, d.condition_dim);
   l.cond2 = plan64(cur, D, H);
-  l.dsp = plan64(cur, L * D, D);
+  const int NC = cn_n_cross(d);
+  l.dsp = plan64(cur, (L + NC) * D, D);      // rows [L*D, (L+NC)*D): the cross blocks' own diffusion_step_projection
   l.cproj = plan64(cur, L * D, D);
   l.pw1.clear(); l.pw2.clear(); l.pw2w.clear(); l.dw_w.clear(); l.dw_b.clear(); l.gamma.clear(); l.lnR.clear(); l.dil.clear();
   for (int i = 0; i < L; ++i) {
@@ -64,9 +81,33 @@ void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
     l.lnR.push_back(cur); cur += (size_t)round_up(H, 64) * 16;
     l.dil.push_back(1 << (i % d.dilation_cycle));
   }
+  l.cross.clear();
+  l.pos = cur;
+  if (NC) cur += (size_t)round_up(kCnPositions * D, 64);
+  for (int c = 0; c < NC; ++c) {
+    CnLayout::Cross x{};
+    x.at_layer = c * d.cross_attention;
+    plan_declayer(cur, x.dec, D, H);
+    x.scale_q = cur; cur += 64;
+    x.scale_k = cur; cur += 64;
+    l.cross.push_back(x);
+  }
   l.out0 = plan32(cur, D, D);
   l.out2 = plan32(cur, d.mel_channels, D);
   l.total_floats = cur;
+}
+
+// X[b][c][t] += (sb ? sb[c] : 0) + pos[t][c] * scale    (CrossAttentionBlock.forward: x + diffusion_step_projection(step), then
+// + positional_embedding * position_scale_query, convnext.py:127-136; with sb == null and out != in: condition + pos * scale_key)
+__global__ void k_cn_addpos(float* out, const float* in, long bs, int ld, const float* __restrict__ sb, int sb_ld,
+                            int sb_bs, const float* __restrict__ pos, const float* __restrict__ scale, int D, int T) {
+  const int t = blockIdx.x * kEwBlock + threadIdx.x;
+  if (t >= T) return;
+  const int b = blockIdx.y / D, c = blockIdx.y - b * D;
+  const long o = b * bs + (long)c * ld + t;
+  float v = in[o];
+  if (sb) v = v + sb[(long)c * sb_ld + b * sb_bs];
+  out[o] = v + pos[(long)t * D + c] * scale[0];
 }
 
 // ------------------------------------------------------------------------------------------------ dwconv + LayerNorm
@@ -113,14 +154,14 @@ __global__ __launch_bounds__(256) void k_dwconv_stats(float* __restrict__ U, flo
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       xv[j][q] = xb[(long)c * ld + tq[q]];
-      cv[j][q] = cb[(long)c * ld + tq[q]];
+      cv[j][q] = CP ? cb[(long)c * ld + tq[q]] : 0.f;
     }
   }
 #pragma unroll
   for (int j = 0; j < kCnCh / 4; ++j)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      if (col[q] < W) v[wv + 4 * j][col[q]] = ok[q] ? (xv[j][q] + sbv[j]) + cv[j][q] : 0.f;
+      if (col[q] < W) v[wv + 4 * j][col[q]] = ok[q] ? (CP ? (xv[j][q] + sbv[j]) + cv[j][q] : xv[j][q] + sbv[j]) : 0.f;   // CP == null: no condition term
   __syncthreads();
   // ---- conv from LDS: thread (lane = frame, wave = 8 channels)
   const int t = t0 + lane;
@@ -159,6 +200,7 @@ struct CnBufs {
   DevBuf X, N, G, H2, condp, c1, c2, CP, ST;
   DevBuf c2raw, CP2;   // PLMS + cond_masks: condition / per-layer projections of the UNMASKED conditioner (diffusion.py:285)
   DevBuf E, Hm, S0, SB;
+  DevBuf QKV, O, MEM, KVc, KVc2, cmask;   // cross-attention variant: decoder-layer scratch; hoisted keys / values per cross block ([NC][2D] rows)
   int ldn = 0, n_emb = 0;
 };
 
@@ -180,7 +222,7 @@ void fdx_cn_free(void* p) { delete static_cast<fdx_cn_state*>(p); }
 
 extern "C" int fdx_convnext_num_weights(const fdx_convnext_desc* d) {
   if (cn_validate(d)) return FDX_E_ARG;
-  return 10 + d->num_layers * 13 + 4;
+  return 10 + d->num_layers * 13 + cn_n_cross(*d) * kCrossTensors + 4;
 }
 
 extern "C" int fdx_convnext_packed_bytes(const fdx_convnext_desc* d, size_t* bytes) {
@@ -195,6 +237,9 @@ extern "C" int fdx_convnext_packed_bytes(const fdx_convnext_desc* d, size_t* byt
 // diffusion_embedding.1.*, diffusion_embedding.3.*, conditioner_projection.0.*, conditioner_projection.2.*, then per layer:
 // gamma, dwconv.{weight,bias}, norm.{weight,bias}, pwconv1.*, pwconv2.*, diffusion_step_projection.*, condition_projection.*;
 // then output_projection.0.*, output_projection.2.*.
+// cross_attention = n > 0: `residual_layers` of the reference is [Cross_0, Block_0 .. Block_{n-1}, Cross_1, Block_n, ...]; a cross block
+// contributes, in its own state_dict order, position_scale_query, position_scale_key, positional_embedding, the 18 tensors of
+// nn.TransformerDecoderLayer (declayer.hip.h), diffusion_step_projection.{weight,bias}.
 extern "C" int fdx_convnext_pack(const fdx_convnext_desc* d, const float* const* w, int n, void* out, size_t bytes) {
   if (cn_validate(d)) return FDX_E_ARG;
   if (!w || !out) return fail(nullptr, FDX_E_ARG, "null pointer");
@@ -211,7 +256,19 @@ extern "C" int fdx_convnext_pack(const fdx_convnext_desc* d, const float* const*
   pack_lin(A, l.emb3, w[k], D, H, w[k + 1]); k += 2;
   pack_lin(A, l.cond0, w[k], H, d->condition_dim, w[k + 1]); k += 2;
   pack_lin(A, l.cond2, w[k], D, H, w[k + 1]); k += 2;
+  const int NC = cn_n_cross(*d);
   for (int i = 0; i < L; ++i) {
+    if (NC && i % d->cross_attention == 0) {
+      const int c = i / d->cross_attention;
+      const CnLayout::Cross& x = l.cross[c];
+      A[x.scale_q] = w[k][0]; A[x.scale_k] = w[k + 1][0];
+      if (c == 0) memcpy(A + l.pos, w[k + 2], (size_t)kCnPositions * D * sizeof(float));
+      else if (memcmp(A + l.pos, w[k + 2], (size_t)kCnPositions * D * sizeof(float)) != 0)
+        return fail(nullptr, FDX_E_NOIMPL, "convnext: the cross blocks' positional_embedding buffers differ (one shared table is packed)");
+      k += 3;
+      k += pack_declayer(A, x.dec, w + k, D, H);
+      pack_lin(A, l.dsp, w[k], D, D, w[k + 1], (L + c) * D); k += 2;
+    }
     memcpy(A + l.gamma[i], w[k], D * sizeof(float)); k += 1;
     memcpy(A + l.dw_w[i], w[k], (size_t)D * 7 * sizeof(float)); memcpy(A + l.dw_b[i], w[k + 1], D * sizeof(float)); k += 2;
     k += 2;   // norm.weight, norm.bias: folded into pwconv1 below
@@ -293,9 +350,29 @@ extern "C" int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int 
     FDX_HIP(h, gemm(A, l.cond2, B, T, b.c1.f() + kHalo, (long)H * ld, ld,
                     bias_epi(b.c2raw.f() + kHalo, (long)D * ld, ld, A + l.cond2.b_off, D, ACT_NONE), s));
   }
-  // per-layer condition_projection(condition) for all layers in one GEMM (convnext.py:72)
-  FDX_HIP(h, gemm(A, l.cproj, B, T, b.c2.f() + kHalo, (long)D * ld, ld,
-                  bias_epi(b.CP.f() + kHalo, (long)L * D * ld, ld, A + l.cproj.b_off, L * D, ACT_NONE), s));
+  const int NC = cn_n_cross(d);
+  if (!NC) {
+    // per-layer condition_projection(condition) for all layers in one GEMM (convnext.py:72)
+    FDX_HIP(h, gemm(A, l.cproj, B, T, b.c2.f() + kHalo, (long)D * ld, ld,
+                    bias_epi(b.CP.f() + kHalo, (long)L * D * ld, ld, A + l.cproj.b_off, L * D, ACT_NONE), s));
+  } else {
+    // cross-attention variant: the ConvNeXt blocks get no condition (convnext.py:246-250); every cross block's memory
+    // condition + pos * scale_key (:137-141) is step-invariant -> its key / value projection is hoisted here
+    if (T > kCnPositions) return fail(h, FDX_E_ARG, "fdx_convnext_prepare: %d frames exceed the positional table (%d)", T, kCnPositions);
+    FDX_HIP(h, b.QKV.ensure(sz(3 * D), geom, s)); FDX_HIP(h, b.O.ensure(sz(D), geom, s)); FDX_HIP(h, b.MEM.ensure(sz(D), geom, s));
+    FDX_HIP(h, b.KVc.ensure(sz(NC * 2 * D), geom, s));
+    for (int c = 0; c < NC; ++c) {
+      const auto& x = l.cross[c];
+      hipLaunchKernelGGL(k_cn_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, b.MEM.f() + kHalo, b.c2.f() + kHalo, (long)D * ld, ld,
+                         (const float*)nullptr, 0, 0, A + l.pos, A + x.scale_k, D, T);
+      FDX_HIP(h, gemm(A, x.dec.ca_kv, B, T, b.MEM.f() + kHalo, (long)D * ld, ld,
+                      bias_epi(b.KVc.f() + kHalo + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, ld, A + x.dec.ca_kv.b_off, 2 * D, ACT_NONE), s));
+    }
+    if (cond_mask) {   // key-padding mask of the memory: private copy (stable address for recorded graphs)
+      FDX_HIP(h, b.cmask.ensure((size_t)B * T, false, s));
+      FDX_HIP(h, hipMemcpyAsync(b.cmask.p, cond_mask, (size_t)B * T, hipMemcpyDeviceToDevice, s));
+    }
+  }
   h->cond_masked = cond_mask != nullptr;
   h->prepared = true;
   return FDX_OK;
@@ -316,11 +393,12 @@ int fdx_cn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s) {
   FDX_HIP(h, b.E.ensure((size_t)D * ldn * 4, geom, s));
   FDX_HIP(h, b.Hm.ensure((size_t)H * ldn * 4, geom, s));
   FDX_HIP(h, b.S0.ensure((size_t)D * ldn * 4, geom, s));
-  FDX_HIP(h, b.SB.ensure((size_t)L * D * ldn * 4, geom, s));
+  const int NC = cn_n_cross(d);
+  FDX_HIP(h, b.SB.ensure((size_t)(L + NC) * D * ldn * 4, geom, s));
   hipLaunchKernelGGL(k_step_embed, ew_grid(n, D), dim3(kEwBlock), 0, s, b.E.f() + kHalo, ldn, t_dev, n, D);
   FDX_HIP(h, gemm(A, l.emb1, 1, n, b.E.f() + kHalo, 0, ldn, bias_epi(b.Hm.f() + kHalo, 0, ldn, A + l.emb1.b_off, H, ACT_GELU), s));
   FDX_HIP(h, gemm(A, l.emb3, 1, n, b.Hm.f() + kHalo, 0, ldn, bias_epi(b.S0.f() + kHalo, 0, ldn, A + l.emb3.b_off, D, ACT_NONE), s));
-  FDX_HIP(h, gemm(A, l.dsp, 1, n, b.S0.f() + kHalo, 0, ldn, bias_epi(b.SB.f() + kHalo, 0, ldn, A + l.dsp.b_off, L * D, ACT_NONE), s));
+  FDX_HIP(h, gemm(A, l.dsp, 1, n, b.S0.f() + kHalo, 0, ldn, bias_epi(b.SB.f() + kHalo, 0, ldn, A + l.dsp.b_off, (L + NC) * D, ACT_NONE), s));
   return FDX_OK;
 }
 
@@ -329,6 +407,19 @@ int fdx_cn_plms_setup(fdx_ctx* h, hipStream_t s) {
   fdx_cn_state* S = cn(h);
   const auto& l = S->l;
   const int D = S->d.dim, L = S->d.num_layers, ld = h->ld;
+  const int NC = cn_n_cross(S->d);
+  if (NC) {   // cross-attention variant: keys / values of the UNMASKED condition for the one unmasked call
+    const float* A = S->arena;
+    FDX_HIP(h, S->b.KVc2.ensure((size_t)h->B * NC * 2 * D * ld * sizeof(float), false, s));
+    for (int c = 0; c < NC; ++c) {
+      const auto& x = l.cross[c];
+      hipLaunchKernelGGL(k_cn_addpos, ew_grid(h->T, h->B * D), dim3(kEwBlock), 0, s, S->b.MEM.f() + kHalo, S->b.c2raw.f() + kHalo, (long)D * ld, ld,
+                         (const float*)nullptr, 0, 0, A + l.pos, A + x.scale_k, D, h->T);
+      FDX_HIP(h, gemm(A, x.dec.ca_kv, h->B, h->T, S->b.MEM.f() + kHalo, (long)D * ld, ld,
+                      bias_epi(S->b.KVc2.f() + kHalo + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, ld, A + x.dec.ca_kv.b_off, 2 * D, ACT_NONE), s));
+    }
+    return FDX_OK;
+  }
   FDX_HIP(h, S->b.CP2.ensure((size_t)h->B * L * D * ld * sizeof(float), false, s));
   FDX_HIP(h, gemm(S->arena, l.cproj, h->B, h->T, S->b.c2raw.f() + kHalo, (long)D * ld, ld,
                   bias_epi(S->b.CP2.f() + kHalo, (long)L * D * ld, ld, S->arena + l.cproj.b_off, L * D, ACT_NONE), s));
@@ -348,7 +439,10 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
   const long bsD = (long)D * ld, bsH = (long)H * ld;
   float* X = b.X.f() + kHalo; float* N = b.N.f() + kHalo; float* G = b.G.f() + kHalo; float* H2 = b.H2.f() + kHalo;
   const float* SB = b.SB.f() + kHalo + col0;
-  const float* CP = (unmasked_cond ? b.CP2.f() : b.CP.f()) + kHalo;
+  const int NC = cn_n_cross(d);
+  const float* CP = NC ? nullptr : (unmasked_cond ? b.CP2.f() : b.CP.f()) + kHalo;
+  const float* KVc = NC ? (unmasked_cond ? b.KVc2.f() : b.KVc.f()) + kHalo : nullptr;
+  const uint8_t* cmask = (NC && h->cond_masked && !unmasked_cond) ? static_cast<const uint8_t*>(b.cmask.p) : nullptr;
   // pwconv2 has only D rows: 32-row tiles double the workgroup count when 64-row tiles would not fill the 256 CUs (batch 1-2 at
   // 10 s); above that the 64-row tiles' higher operand reuse wins
   const bool wide_pw2 = (long)B * ((T + 63) / 64) * ((D + 63) / 64) >= 256;
@@ -358,8 +452,16 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
     FDX_HIP(h, gemm(A, l.in_proj, B, T, xin, (long)M * ld, ld, e, s));
   }
   for (int i = 0; i < L; ++i) {
+    if (NC && i % d.cross_attention == 0) {   // CrossAttentionBlock (convnext.py:127-152)
+      const int c = i / d.cross_attention;
+      const auto& x = l.cross[c];
+      hipLaunchKernelGGL(k_cn_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, X, X, bsD, ld, SB + (size_t)(L + c) * D * b.ldn, b.ldn, sb_bs,
+                         A + l.pos, A + x.scale_q, D, T);
+      const DecScratch sc{b.QKV.f() + kHalo, b.O.f() + kHalo, G};
+      FDX_HIP(h, run_declayer(A, x.dec, B, T, D, H, ld, X, KVc + (size_t)c * 2 * D * ld, sc, mask, cmask, s));
+    }
     const dim3 grid((T + 63) / 64, D / kCnCh, B);
-    hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, N, b.ST.f(), X, bsD, ld, CP + (size_t)i * D * ld, (long)L * D * ld,
+    hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, N, b.ST.f(), X, bsD, ld, CP ? CP + (size_t)i * D * ld : nullptr, (long)L * D * ld,
                        SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, mask, A + l.dw_w[i], A + l.dw_b[i], D, T, l.dil[i]);
     {  // pwconv1 over LayerNorm(u): centring + rstd inside the GEMM, affine folded into the packed weights
       const PackedW& p = l.pw1[i];

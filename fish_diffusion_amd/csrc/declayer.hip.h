@@ -1,0 +1,348 @@
+// declayer.hip.h -- one `torch.nn.TransformerDecoderLayer(d_model, nhead=8, dim_feedforward, activation="gelu", batch_first=True)`
+// (post-norm; eval mode) on channel-major activations [B][D][ld], shared by the two denoisers that contain such layers:
+//   tfdec.hip     TransformerDecoderDenoiser        fish_diffusion/modules/convnext.py:263-379  (12 layers)
+//   convnext.hip  ConvNext(cross_attention=True)    fish_diffusion/modules/convnext.py:95-152   (a CrossAttentionBlock every 5th layer)
+// Every Linear is a convgemm launch on packed weights; attention is the fp32 MFMA flash kernel below (S^T = K^T Q so that the
+// softmax axis runs over the accumulator registers of one lane; P^T feeds the second product in place; see tfdec.hip's header).
+#pragma once
+#include "common.hip.h"
+#include "elementwise.hip.h"
+#include "gemmplan.hip.h"
+
+#include <cmath>
+
+namespace fdx {
+namespace {
+
+constexpr int kHeads = 8;   // nn.TransformerDecoderLayer(nhead=8), convnext.py:300
+
+struct TdLayer {
+  PackedW sa_in, sa_out, ca_q, ca_kv, ca_out, lin1, lin2;
+  size_t n1w, n1b, n2w, n2b, n3w, n3b;
+};
+
+inline void plan_declayer(size_t& cur, TdLayer& y, int D, int H) {
+  y.sa_in = plan64(cur, 3 * D, D);
+  y.sa_out = plan32(cur, D, D);
+  y.ca_q = plan32(cur, D, D);
+  y.ca_kv = plan64(cur, 2 * D, D);
+  y.ca_out = plan32(cur, D, D);
+  y.lin1 = plan64(cur, H, D);
+  y.lin2 = plan32(cur, D, H);
+  for (size_t* p : {&y.n1w, &y.n1b, &y.n2w, &y.n2b, &y.n3w, &y.n3b}) { *p = cur; cur += round_up(D, 64); }
+}
+
+// 18 tensors in nn.TransformerDecoderLayer's state_dict order: self_attn.{in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias},
+// multihead_attn.(same four), linear1.{weight, bias}, linear2.{weight, bias}, norm1.{weight, bias}, norm2.*, norm3.*.  Returns 18.
+inline int pack_declayer(float* A, const TdLayer& y, const float* const* w, int D, int H) {
+  int k = 0;
+  pack_lin(A, y.sa_in, w[k], 3 * D, D, w[k + 1]); k += 2;
+  pack_lin(A, y.sa_out, w[k], D, D, w[k + 1]); k += 2;
+  pack_lin(A, y.ca_q, w[k], D, D, w[k + 1]);                                        // in_proj rows [0, D): the query projection
+  pack_lin(A, y.ca_kv, w[k] + (size_t)D * D, 2 * D, D, w[k + 1] + D); k += 2;       // rows [D, 3D): key and value
+  pack_lin(A, y.ca_out, w[k], D, D, w[k + 1]); k += 2;
+  pack_lin(A, y.lin1, w[k], H, D, w[k + 1]); k += 2;
+  pack_lin(A, y.lin2, w[k], D, H, w[k + 1]); k += 2;
+  for (size_t off : {y.n1w, y.n1b, y.n2w, y.n2b, y.n3w, y.n3b}) memcpy(A + off, w[k++], D * sizeof(float));
+  return k;
+}
+
+// X[b][c][t] = masked ? 0 : X[b][c][t] + pos[t][c] * scale        (convnext.py:344-346,356-357 / :348,353)
+__global__ void k_td_addpos(float* __restrict__ X, long bs, int ld, const float* __restrict__ pos, const float* __restrict__ scale,
+                            const uint8_t* __restrict__ mask, int D, int T) {
+  const int t = blockIdx.x * kEwBlock + threadIdx.x;
+  if (t >= T) return;
+  const int b = blockIdx.y / D, c = blockIdx.y - b * D;
+  const long o = b * bs + (long)c * ld + t;
+  const float v = X[o] + pos[(long)t * D + c] * scale[0];
+  X[o] = (mask && mask[(long)b * T + t]) ? 0.f : v;
+}
+
+
+// LayerNorm over channels, in place: 8 frames x 32 channel groups per workgroup (T/8 workgroups: latency-bound, wants many),
+// values in registers, two-pass statistics
+constexpr int kLnFr = 8, kLnCg = 32, kLnCpt = 16;
+__global__ __launch_bounds__(256) void k_td_layernorm(float* __restrict__ X, long bs, int ld, const float* __restrict__ w,
+                                                      const float* __restrict__ bia, int D, int T, float eps) {
+  __shared__ float red[kLnCg][kLnFr];
+  const int tc = threadIdx.x & (kLnFr - 1), cg = threadIdx.x / kLnFr;
+  const int b = blockIdx.y, t = blockIdx.x * kLnFr + tc;
+  const int cpt = D / kLnCg;
+  const bool live = t < T;
+  float* xb = X + b * bs + (live ? t : T - 1);
+  float u[kLnCpt];
+  float s1 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < kLnCpt; ++ci) {
+    u[ci] = 0.f;
+    if (ci < cpt) { u[ci] = xb[(long)(cg * cpt + ci) * ld]; s1 += u[ci]; }
+  }
+  auto total = [&](float v) {
+    __syncthreads();
+    red[cg][tc] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kLnCg; ++g) s += red[g][tc];
+    return s;
+  };
+  const float mean = total(s1) / (float)D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < kLnCpt; ++ci)
+    if (ci < cpt) { const float dl = u[ci] - mean; s2 += dl * dl; }
+  const float rstd = 1.f / sqrtf(total(s2) / (float)D + eps);
+  if (!live) return;
+#pragma unroll
+  for (int ci = 0; ci < kLnCpt; ++ci)
+    if (ci < cpt) { const int c = cg * cpt + ci; xb[(long)c * ld] = (u[ci] - mean) * rstd * w[c] + bia[c]; }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+struct AttnArgs {
+  const float* Q; long q_bs; int ldq;     // head h, channel d, frame t at Q[b*q_bs + (h*DH + d)*ldq + t]
+  const float* K; long k_bs; int ldk;
+  const float* V; long v_bs; int ldv;
+  float* O; long o_bs; int ldo;
+  const uint8_t* kmask;                   // [B][Tk] bytes, 1 = key ignored (key_padding_mask), or null
+  int Tq, Tk;
+  float scale;                            // 1 / sqrt(DH)
+};
+
+// NQ = 32-query blocks per workgroup: 2 (64 queries) when that already fills the chip, 1 to double the workgroup count
+template <int DH, int NQ>
+__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+  constexpr int KS = DH / 2;                 // MFMA k-steps of the score product
+  constexpr int RBD = (DH + 31) / 32;        // 32-row blocks of O^T
+  constexpr int VLD = 65;                    // padded row of the staged V tile
+  constexpr int NBLK = RBD * NQ;
+  constexpr int LDS_F = (4 * DH * VLD > 4 * NBLK * 16 * 64 + 4 * 2 * NQ * 64) ? 4 * DH * VLD : 4 * NBLK * 16 * 64 + 4 * 2 * NQ * 64;
+  __shared__ float lds[LDS_F];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, n = lane & 31;
+  const int q0 = blockIdx.x * (32 * NQ), h = blockIdx.y, b = blockIdx.z;
+  const float* Qh = a.Q + b * a.q_bs + (long)h * DH * a.ldq;
+  const float* Kh = a.K + b * a.k_bs + (long)h * DH * a.ldk;
+  const float* Vh = a.V + b * a.v_bs + (long)h * DH * a.ldv;
+  const float NEG = -__builtin_inff();
+
+  // B operand of the score product: this lane's slice of Q, for the whole launch
+  float qreg[KS][NQ];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int nb = 0; nb < NQ; ++nb) qreg[ks][nb] = Qh[(long)(2 * ks + half) * a.ldq + min(q0 + nb * 32 + n, a.Tq - 1)];
+
+  f32x16 o[RBD][NQ];
+#pragma unroll
+  for (int x = 0; x < RBD; ++x)
+#pragma unroll
+    for (int nb = 0; nb < NQ; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[x][nb][r] = 0.f;
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int nb = 0; nb < NQ; ++nb) { m[nb] = NEG; l[nb] = 0.f; }
+  float* vt = lds + wave * DH * VLD;
+
+  // The K and V operands of a tile are fetched into registers one tile ahead: right after the score MFMAs have consumed the
+  // current ones, so that their fabric latency runs behind the softmax and the second product instead of in front of the first.
+  const int n_kt = (a.Tk + 63) / 64;
+  float kreg[KS][2], vreg[DH];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) kreg[ks][rb] = Kh[(long)(2 * ks + half) * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) vreg[d] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
+  };
+  // (not for 64-query x 64-channel workgroups: their accumulators leave no room for a second operand set in 512 VGPRs)
+  constexpr bool PF = !(DH == 64 && NQ == 2);
+  if (PF && wave < n_kt) fetch(wave);
+  for (int kt = wave; kt < n_kt; kt += 4) {
+    const int k0 = kt * 64;
+    // ---- stage this tile of V (coalesced rows) for the second product
+    if constexpr (PF) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = vreg[d];
+    } else {
+#pragma unroll 8
+      for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
+    }
+    // ---- S^T = K^T Q
+    f32x16 s[2][NQ];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < NQ; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[rb][nb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float ak[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+        ak[rb] = PF ? kreg[ks][rb] : Kh[(long)(2 * ks + half) * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < NQ; ++nb) s[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rb], qreg[ks][nb], s[rb][nb], 0, 0, 0);
+    }
+    if (PF && kt + 4 < n_kt) fetch(kt + 4);
+    // ---- scale, key mask (padding keys and the tile overhang), online softmax over the key axis
+    float mx[NQ];
+#pragma unroll
+    for (int nb = 0; nb < NQ; ++nb) mx[nb] = NEG;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + rb * 32 + acc_row(r, half);
+        const bool ok = key < a.Tk && !(a.kmask && a.kmask[(long)b * a.Tk + min(key, a.Tk - 1)]);
+#pragma unroll
+        for (int nb = 0; nb < NQ; ++nb) {
+          const float v = ok ? s[rb][nb][r] * a.scale : NEG;
+          s[rb][nb][r] = v;
+          mx[nb] = fmaxf(mx[nb], v);
+        }
+      }
+#pragma unroll
+    for (int nb = 0; nb < NQ; ++nb) {
+      mx[nb] = fmaxf(mx[nb], __shfl_xor(mx[nb], 32));
+      const float m_new = fmaxf(m[nb], mx[nb]);
+      const float m_use = m_new == NEG ? 0.f : m_new;      // every key so far masked: keep exp() finite, all weights 0
+      const float alpha = expf(m[nb] - m_use);
+      float sum = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __expf(s[rb][nb][r] - m_use);
+          s[rb][nb][r] = p;
+          sum += p;
+        }
+      sum += __shfl_xor(sum, 32);
+      l[nb] = l[nb] * alpha + sum;
+      m[nb] = m_new;
+#pragma unroll
+      for (int x = 0; x < RBD; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[x][nb][r] *= alpha;
+    }
+    // ---- O^T += V P^T : the k-pair of step (rb, r) is the key pair the two lane halves hold in s[rb][.][r]
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = rb * 32 + acc_row(r, half);
+#pragma unroll
+        for (int x = 0; x < RBD; ++x) {
+          const int d = x * 32 + n;
+          const float av = d < DH ? vt[d * VLD + kl] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NQ; ++nb) o[x][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[rb][nb][r], o[x][nb], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- merge the 4 waves' (m, l, O) through LDS; wave w finishes accumulator rows r = 4w .. 4w+3 of every block
+  __syncthreads();
+  float* ob = lds;                                   // [wave][blk][r][lane]
+  float* ml = lds + 4 * NBLK * 16 * 64;              // [wave][{m,l}][nb][lane]
+#pragma unroll
+  for (int x = 0; x < RBD; ++x)
+#pragma unroll
+    for (int nb = 0; nb < NQ; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[((wave * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] = o[x][nb][r];
+#pragma unroll
+  for (int nb = 0; nb < NQ; ++nb) {
+    ml[((wave * 2 + 0) * NQ + nb) * 64 + lane] = m[nb];
+    ml[((wave * 2 + 1) * NQ + nb) * 64 + lane] = l[nb];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nb = 0; nb < NQ; ++nb) {
+    float mw[4], M = NEG, L = 0.f, wg[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = ml[((w * 2 + 0) * NQ + nb) * 64 + lane]; M = fmaxf(M, mw[w]); }
+    const float M_use = M == NEG ? 0.f : M;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { wg[w] = expf(mw[w] - M_use); L += ml[((w * 2 + 1) * NQ + nb) * 64 + lane] * wg[w]; }
+    const int q = q0 + nb * 32 + n;
+    if (q >= a.Tq) continue;
+#pragma unroll
+    for (int x = 0; x < RBD; ++x)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        const int d = x * 32 + acc_row(r, half);
+        if (d >= DH) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += ob[((w * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] * wg[w];
+        a.O[b * a.o_bs + (long)(h * DH + d) * a.ldo + q] = acc / L;
+      }
+  }
+}
+
+template <int NQ>
+hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s) {
+  const dim3 grid((a.Tq + 32 * NQ - 1) / (32 * NQ), kHeads, B), blk(256);
+  if (DH == 64) hipLaunchKernelGGL((k_attn<64, NQ>), grid, blk, 0, s, a);
+  else if (DH == 32) hipLaunchKernelGGL((k_attn<32, NQ>), grid, blk, 0, s, a);
+  else hipLaunchKernelGGL((k_attn<16, NQ>), grid, blk, 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s) {
+  // 64-query workgroups only when they already give every CU one (B * heads * T/64 >= 256); else 32-query ones
+  if ((long)B * kHeads * ((a.Tq + 63) / 64) >= 256) return launch_attn_nq<2>(DH, a, B, s);
+  return launch_attn_nq<1>(DH, a, B, s);
+}
+
+// Scratch of one decoder layer (owned by the caller; padded rows [B][ch][ld], pointers past the left halo)
+struct DecScratch { float* QKV; float* O; float* G; };   // [3D], [D], [H]
+
+// x = norm1(x + out_proj(attn(in_proj(x)))); x = norm2(x + out_proj(attn(q(x), K, V))); x = norm3(x + linear2(gelu(linear1(x)))), in place
+// on X.  The cross-attention keys / values come from `KV` [B][2D][ld] (already projected with y.ca_kv: the caller decides whether
+// that projection is per call or hoisted).  tgt_kpm / mem_kpm: [B][T] key-padding masks (1 = ignored) or null.
+inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV,
+                               const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s) {
+  const long bsD = (long)D * ld, bsH = (long)H * ld;
+  const int DH = D / kHeads;
+  const dim3 ln_grid((T + kLnFr - 1) / kLnFr, B);
+  auto residual = [&](const PackedW& p, const float* in, long in_bs) {   // X += W in + b
+    EpiScaleRes e{};
+    e.X = X; e.bs = bsD; e.ld = ld; e.bias = A + p.b_off; e.gamma = nullptr; e.M = D; e.mask = nullptr; e.mask_ld = T;
+    return gemm(A, p, B, T, in, in_bs, ld, e, s);
+  };
+  hipError_t e;
+  AttnArgs at{};
+  at.O = sc.O; at.o_bs = bsD; at.ldo = ld; at.Tq = T; at.Tk = T; at.scale = 1.f / sqrtf((float)DH);
+  // ---- self-attention block
+  if ((e = gemm(A, y.sa_in, B, T, X, bsD, ld, bias_epi(sc.QKV, 3 * bsD, ld, A + y.sa_in.b_off, 3 * D, ACT_NONE), s)) != hipSuccess) return e;
+  at.Q = sc.QKV; at.q_bs = 3 * bsD; at.ldq = ld;
+  at.K = sc.QKV + (size_t)D * ld; at.k_bs = 3 * bsD; at.ldk = ld;
+  at.V = sc.QKV + (size_t)2 * D * ld; at.v_bs = 3 * bsD; at.ldv = ld;
+  at.kmask = tgt_kpm;
+  if ((e = launch_attn(DH, at, B, s)) != hipSuccess) return e;
+  if ((e = residual(y.sa_out, sc.O, bsD)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_td_layernorm, ln_grid, dim3(256), 0, s, X, bsD, ld, A + y.n1w, A + y.n1b, D, T, 1e-5f);
+  // ---- cross-attention block
+  if ((e = gemm(A, y.ca_q, B, T, X, bsD, ld, bias_epi(sc.QKV, 3 * bsD, ld, A + y.ca_q.b_off, D, ACT_NONE), s)) != hipSuccess) return e;
+  at.K = KV; at.k_bs = 2 * bsD; at.V = KV + (size_t)D * ld; at.v_bs = 2 * bsD;
+  at.kmask = mem_kpm;
+  if ((e = launch_attn(DH, at, B, s)) != hipSuccess) return e;
+  if ((e = residual(y.ca_out, sc.O, bsD)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_td_layernorm, ln_grid, dim3(256), 0, s, X, bsD, ld, A + y.n2w, A + y.n2b, D, T, 1e-5f);
+  // ---- feed-forward block
+  if ((e = gemm(A, y.lin1, B, T, X, bsD, ld, bias_epi(sc.G, bsH, ld, A + y.lin1.b_off, H, ACT_GELU), s)) != hipSuccess) return e;
+  if ((e = residual(y.lin2, sc.G, bsH)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_td_layernorm, ln_grid, dim3(256), 0, s, X, bsD, ld, A + y.n3w, A + y.n3b, D, T, 1e-5f);
+  return hipGetLastError();
+}
+
+}  // namespace
+}  // namespace fdx

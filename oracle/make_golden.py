@@ -260,6 +260,72 @@ def golden_tfdec(R):
              interval=np.int64(interval))
 
 
+CNX_SMALL = dict(mel_channels=128, dim=128, mlp_factor=2, condition_dim=256, num_layers=6, dilation_cycle=4)     # cross blocks in front of layers 0 and 5
+CNX_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=20, dilation_cycle=4)     # ... 0, 5, 10, 15
+
+
+@torch.no_grad()
+def golden_convnext_cross(R):
+    """ConvNext(cross_attention=True) (convnext.py:95-152,186-193,246-250): forward (small / full-size, masked, long t) and the
+    reference's sampler loop driving it (UniPC / PLMS with masks: PLMS's one unmasked call sees the unmasked condition as the
+    attention memory).  Outputs from the real classes; the oracle restatement is pinned to 3e-6 abs (attention, see tfdec)."""
+    print("convnext, cross-attention variant")
+    EVERY = 5
+
+    def oracle_den(sd, cfg):
+        return lambda x, t, c, xm, cm: convnext_ref.convnext_forward(sd, x, t, c, xm, cm, num_layers=cfg["num_layers"],
+                                                                     dilation_cycle=cfg["dilation_cycle"], cross_every=EVERY)
+
+    def shapes_kw(cfg):
+        return dict({k: v for k, v in cfg.items() if k != "dilation_cycle"}, cross_every=EVERY)
+
+    def close(a, b, tol=5e-6):
+        return float((a - b).abs().max()) < tol
+
+    for tag, cfg, seed, (B, T) in (("small", CNX_SMALL, 311, (2, 50)), ("full", CNX_FULL, 4331, (2, 96))):
+        sd = convnext_ref.seeded_state(seed, **shapes_kw(cfg))
+        net = R["ConvNext"](cross_attention=True, cross_every_n_layers=EVERY, **cfg).eval()
+        net.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(B, 128, T, generator=g)
+        cond = torch.randn(B, 256, T, generator=g)
+        t = torch.tensor([37.0, 912.5])[:B]
+        masks = torch.zeros(B, T, dtype=torch.bool)
+        masks[1, T - T // 4:] = True
+        eps = net(x, t, cond)
+        eps_masked = net(x, t, cond, x_masks=masks, cond_masks=masks)
+        eps_long = net(x, torch.tensor([400], dtype=torch.long), cond)
+        den = oracle_den(sd, cfg)
+        assert close(den(x, t, cond, None, None), eps), "oracle ConvNext(cross) != reference"
+        assert close(den(x, t, cond, masks, masks), eps_masked), "oracle ConvNext(cross, masked) != reference"
+        save(f"convnext_cross_{tag}", x=x, cond=cond, t=t, masks=masks, eps=eps, eps_masked=eps_masked, eps_long=eps_long, seed=np.int64(seed),
+             weights_sha1=np.array(state_sha1(sd)))
+
+    sd = convnext_ref.seeded_state(311, **shapes_kw(CNX_SMALL))
+    diff = R["GaussianDiffusion"](denoiser=dict(type="ConvNextDenoiser", cross_attention=True, cross_every_n_layers=EVERY, **CNX_SMALL),
+                                  spec_min=[-5], spec_max=[0]).eval()
+    diff.denoise_fn.load_state_dict(sd, strict=True)
+    den = oracle_den(sd, CNX_SMALL)
+    B, T = 2, 40
+    g = torch.Generator().manual_seed(19)
+    feats = torch.randn(B, T, 256, generator=g)
+    masks = torch.zeros(B, T, dtype=torch.bool)
+    masks[1, 30:] = True
+    for pred, interval in (("unipc", 50), ("plms", 50)):
+        seed = 3100 + interval
+        torch.manual_seed(seed)
+        ref = diff(feats, sampler_interval=interval, noise_predictor=pred, x_masks=masks, cond_masks=masks)
+        torch.manual_seed(seed)
+        x_init = torch.randn(B, 128, T)
+        mine = sampler_ref.diffusion_sample(den, feats, x_init=x_init, sampler_interval=interval, predictor=pred, x_masks=masks, cond_masks=masks)
+        assert rel(mine, ref) < 1e-4, f"oracle sampler over ConvNext(cross) {pred}/{interval} != reference: {rel(mine, ref)}"
+        save(f"convnext_cross_sampler_small_{pred}_i{interval}", features=feats, masks=masks, x_init=x_init, mel=ref, interval=np.int64(interval))
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
 @torch.no_grad()
 def golden_round2(R):
     """Round-2 fixtures.
@@ -641,6 +707,7 @@ def main():
     golden_frontend_expand(R)
     golden_tfdec(R)
     golden_round2(R)
+    golden_convnext_cross(R)
 
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
@@ -648,7 +715,7 @@ def main():
 
 
 if __name__ == "__main__":
-    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2}
+    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2, "convnext_cross": golden_convnext_cross}
     if len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(os.cpu_count())

@@ -372,3 +372,64 @@ print("DIGEST", h.hexdigest())
         digests[shape] = r.stdout.split("DIGEST")[1].split()[0]
     print(digests)
     assert len(set(digests.values())) == 1, digests
+
+
+# ------------------------------------------------------------------------------------------------ ConvNext(cross_attention=True)
+def _cnx(cfg, sd, dev):
+    from fish_diffusion_amd import DENOISERS
+    net = DENOISERS.build(dict(type="ConvNextDenoiser", cross_attention=True, cross_every_n_layers=5, **cfg))
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_convnext_cross_attention_forward_matches_reference_golden(dev, tag):
+    """SURVEY 8f row 4, the branch round 1 left out: fish_diffusion/modules/convnext.py:95-152 (CrossAttentionBlock in front of every
+    5th ConvNeXt block, :186-193; the ConvNeXt blocks then run without the condition term, :246-250) against the REAL module's
+    outputs: plain, masked (key-padding masks on both attentions), long t, 4-D input."""
+    from tests.test_oracle_golden import CNX_FULL, CNX_SMALL, _cnx_den, _cnx_sd
+    cfg = CNX_SMALL if tag == "small" else CNX_FULL
+    g = load(f"convnext_cross_{tag}")
+    sd = _cnx_sd(cfg, int(g["seed"]))
+    assert sha1_state(sd) == str(g["weights_sha1"])
+    net = _cnx(cfg, sd, dev)
+    x, cond, t, m = g["x"].to(dev), g["cond"].to(dev), g["t"].to(dev), g["masks"].bool().to(dev)
+    eps = net(x, t, cond)
+    print(f"convnext cross {tag}: eps rel err {rel_err(eps.cpu(), g['eps']):.3e}")
+    assert rel_err(eps.cpu(), g["eps"]) < 2e-5
+    eps_m = net(x, t, cond, x_masks=m, cond_masks=m)
+    assert rel_err(eps_m.cpu(), g["eps_masked"]) < 2e-5
+    assert (eps_m[1, :, g["masks"][1].bool()] == 0).all()
+    assert rel_err(net(x, torch.tensor([400], device=dev), cond).cpu(), g["eps_long"]) < 2e-5
+    eps4 = net(x[:, None], t, cond)
+    assert eps4.shape == (x.shape[0], 1, 128, x.shape[2]) and torch.equal(eps4[:, 0], eps)
+    if tag == "small":   # ragged lengths vs the oracle, masks on one side only
+        den = _cnx_den(sd, cfg)
+        for B, T in ((1, 1), (3, 7), (2, 65), (1, 257)):
+            gg = torch.Generator().manual_seed(T)
+            xx, cc, tt = torch.randn(B, 128, T, generator=gg), torch.randn(B, 256, T, generator=gg), torch.rand(B, generator=gg) * 999
+            xm = torch.zeros(B, T, dtype=torch.bool)
+            xm[-1, T - T // 3:] = True
+            with torch.no_grad():
+                ref, ref_m = den(xx, tt, cc, None, None), den(xx, tt, cc, None, xm)
+            assert rel_err(net(xx.to(dev), tt.to(dev), cc.to(dev)).cpu(), ref) < 2e-5, (B, T)
+            if T > 1:
+                assert rel_err(net(xx.to(dev), tt.to(dev), cc.to(dev), cond_masks=xm.to(dev)).cpu(), ref_m) < 2e-5, (B, T)
+
+
+@pytest.mark.parametrize("name", ["unipc_i50", "plms_i50"])
+def test_sampler_over_convnext_cross_attention_matches_reference_golden(dev, name):
+    """GaussianDiffusion driving ConvNext(cross_attention=True): the hoisted per-block keys / values, PLMS's one unmasked call (its
+    attention memory is the UNMASKED condition, diffusion.py:285), recorded graphs (second run)."""
+    from fish_diffusion_amd import DIFFUSIONS
+    from tests.test_oracle_golden import CNX_SMALL, _cnx_sd
+    g = load(f"convnext_cross_sampler_small_{name}")
+    diff = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="ConvNextDenoiser", cross_attention=True, **CNX_SMALL),
+                                 spec_min=[-5], spec_max=[0]))
+    diff.denoise_fn.load_state_dict(_cnx_sd(CNX_SMALL, 311), strict=True)
+    diff = diff.to(dev).eval()
+    m = g["masks"].bool().to(dev)
+    for _ in range(2):
+        mel = diff(g["features"].to(dev), sampler_interval=int(g["interval"]), noise_predictor=name.split("_")[0], x_masks=m, cond_masks=m,
+                   x_init=g["x_init"].to(dev))
+        assert rel_err(mel.cpu(), g["mel"]) < MEL_REL, name

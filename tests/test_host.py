@@ -426,8 +426,17 @@ def test_convnext_contract_and_bad_configs(lib):
     want = [k for k, _ in convnext_ref.param_shapes(mel_channels=16, dim=64, mlp_factor=2, condition_dim=24, num_layers=3)]
     assert list(net.state_dict().keys()) == want
     assert float(net.state_dict()["residual_layers.0.gamma"][0]) == pytest.approx(1e-6)   # layer_scale_init_value, convnext.py:29
+    # cross_attention=True (convnext.py:95-152,186-193): the reference's mixed residual_layers list, key for key, packable
+    cx = ConvNext(mel_channels=16, dim=128, mlp_factor=2, condition_dim=24, num_layers=6, cross_attention=True)
+    want_x = [k for k, _ in convnext_ref.param_shapes(mel_channels=16, dim=128, mlp_factor=2, condition_dim=24, num_layers=6, cross_every=5)]
+    assert list(cx._keys) == want_x and set(cx.state_dict()) == set(want_x)
+    assert "residual_layers.0.multihead_attn.in_proj_weight" in cx.state_dict() and "residual_layers.6.positional_embedding" in cx.state_dict()
+    assert "residual_layers.7.gamma" in cx.state_dict() and "residual_layers.8.gamma" not in cx.state_dict()   # 2 cross + 6 ConvNeXt blocks
+    from fish_diffusion_amd import _lib
+    arena = _lib.pack_on_host(cx._desc, cx._params(), "convnext")
+    assert np.isfinite(arena).all() and arena.size * 4 > 4096 * 128 * 4
     with pytest.raises(NotImplementedError):
-        ConvNext(cross_attention=True)
+        ConvNext(dim=96, cross_attention=True)              # 8 heads of 12: no attention kernel for that head size
     with pytest.raises(ValueError):
         ConvNext(dim=100)                                   # not a multiple of 32: fails at construction
     d = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="ConvNextDenoiser", dim=64, num_layers=2), spec_min=[-5], spec_max=[0]))
