@@ -46,7 +46,7 @@ class NsfDesc(C.Structure):
 class RefineGanDesc(C.Structure):
     _fields_ = [("sampling_rate", C.c_int), ("hop_length", C.c_int), ("n_down", C.c_int), ("downsample_rates", C.c_int * MAX_STAGES),
                 ("n_up", C.c_int), ("upsample_rates", C.c_int * MAX_STAGES), ("num_mels", C.c_int), ("start_channels", C.c_int),
-                ("leaky_relu_slope", C.c_float)]
+                ("leaky_relu_slope", C.c_float), ("template_sine", C.c_int)]
 
 
 class FeatureTerm(C.Structure):

@@ -458,7 +458,7 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
       hipLaunchKernelGGL(k_cn_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, X, X, bsD, ld, SB + (size_t)(L + c) * D * b.ldn, b.ldn, sb_bs,
                          A + l.pos, A + x.scale_q, D, T);
       const DecScratch sc{b.QKV.f() + kHalo, b.O.f() + kHalo, G};
-      FDX_HIP(h, run_declayer(A, x.dec, B, T, D, H, ld, X, KVc + (size_t)c * 2 * D * ld, sc, mask, cmask, s));
+      FDX_HIP(h, run_declayer(A, x.dec, B, T, D, H, ld, X, KVc + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, sc, mask, cmask, s));
     }
     const dim3 grid((T + 63) / 64, D / kCnCh, B);
     hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, N, b.ST.f(), X, bsD, ld, CP ? CP + (size_t)i * D * ld : nullptr, (long)L * D * ld,

@@ -307,8 +307,8 @@ struct DecScratch { float* QKV; float* O; float* G; };   // [3D], [D], [H]
 
 // x = norm1(x + out_proj(attn(in_proj(x)))); x = norm2(x + out_proj(attn(q(x), K, V))); x = norm3(x + linear2(gelu(linear1(x)))), in place
 // on X.  The cross-attention keys / values come from `KV` [B][2D][ld] (already projected with y.ca_kv: the caller decides whether
-// that projection is per call or hoisted).  tgt_kpm / mem_kpm: [B][T] key-padding masks (1 = ignored) or null.
-inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV,
+// that projection is per call or hoisted; kv_bs = floats between batch items of KV).  tgt_kpm / mem_kpm: [B][T] key-padding masks (1 = ignored) or null.
+inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV, long kv_bs,
                                const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s) {
   const long bsD = (long)D * ld, bsH = (long)H * ld;
   const int DH = D / kHeads;
@@ -332,7 +332,7 @@ inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, i
   hipLaunchKernelGGL(k_td_layernorm, ln_grid, dim3(256), 0, s, X, bsD, ld, A + y.n1w, A + y.n1b, D, T, 1e-5f);
   // ---- cross-attention block
   if ((e = gemm(A, y.ca_q, B, T, X, bsD, ld, bias_epi(sc.QKV, 3 * bsD, ld, A + y.ca_q.b_off, D, ACT_NONE), s)) != hipSuccess) return e;
-  at.K = KV; at.k_bs = 2 * bsD; at.V = KV + (size_t)D * ld; at.v_bs = 2 * bsD;
+  at.K = KV; at.k_bs = kv_bs; at.V = KV + (size_t)D * ld; at.v_bs = kv_bs;
   at.kmask = mem_kpm;
   if ((e = launch_attn(DH, at, B, s)) != hipSuccess) return e;
   if ((e = residual(y.ca_out, sc.O, bsD)) != hipSuccess) return e;

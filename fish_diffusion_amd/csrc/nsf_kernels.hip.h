@@ -136,7 +136,7 @@ static __global__ __launch_bounds__(kScanThreads) void k_source_final(float* __r
                                                                const float* __restrict__ rand_ini, const float* __restrict__ noise,
                                                                const float* __restrict__ lin_w, const float* __restrict__ lin_b,
                                                                int L, int H, int n_chunks, float sr, float sine_amp,
-                                                               float noise_std) {
+                                                               float noise_std, float nyquist = 0.f) {   // nyquist > 0: harmonics above it are cleared (RefineGAN's SineGen, generator.py:277-278)
   __shared__ double lds[4];
   const int chunk = blockIdx.x, b = blockIdx.y;
   const float* f = f0up + (long)b * L;
@@ -164,7 +164,9 @@ static __global__ __launch_bounds__(kScanThreads) void k_source_final(float* __r
       run += (double)v[k];
       if (n < L) {
         const float f0v = f[n];
-        const float sine = sinf((float)run * 2.f * 3.14159265358979323846f) * sine_amp;
+        float sine = sinf((float)run * 2.f * 3.14159265358979323846f);
+        if (nyquist > 0.f && f0v * (float)(h + 1) > nyquist) sine = 0.f;
+        sine = sine * sine_amp;
         const float uv = f0v > 0.f ? 1.f : 0.f;
         const float namp = uv * noise_std + (1.f - uv) * sine_amp / 3.f;
         const float sw = sine * uv + namp * noise[((long)b * L + n) * H + h];

@@ -11,7 +11,9 @@
 //
 // Every Conv1d with more than one input channel runs on the convgemm MFMA family (leaky-relu fused on the B operand,
 // residual add fused in the epilogue); torch.cat never materialises: producers write straight into channel slices of
-// the consumer's input buffer.  Only template_generator="comb" (the default, and what the shipped configs use).
+// the consumer's input buffer.  template_generator = "comb" (the default, what the shipped configs use) or "sine": the latter is
+// SineGen (generator.py:197-310) with no overtones -- the NSF-HiFiGAN source module's arithmetic (nsf_kernels.hip.h: two blocked
+// fp64 scans for the wrap-safe phase, sin, uv / noise mix, Linear(1,1) + tanh) plus the Nyquist clean-up of :277-278.
 #include "common.hip.h"
 #include "convplan.hip.h"
 #include "elementwise.hip.h"
@@ -29,6 +31,7 @@ const int kDil[3] = {1, 3, 5};
 struct RgRes { PackedW c1[3], c2[3]; };
 struct RgLayout {
   size_t tmpl_w = 0, tmpl_b = 0; int c0 = 0;                      // template_conv raw [c0][1][7]
+  size_t sine_w = 0, sine_b = 0;                                   // template_gen.merge.0 (Linear(1, 1)), template_sine only
   std::vector<RgRes> down; std::vector<int> down_cin;
   PackedW mel_conv; int c_bott = 0;                                // channels after the down path (= mel_conv out)
   size_t src_w = 0, src_b = 0; int src_c = 0, src_k = 0, src_stride = 1;
@@ -64,6 +67,8 @@ void rg_layout(const fdx_refinegan_desc& d, RgLayout& l) {
   size_t cur = 0;
   int c = d.start_channels;
   l.c0 = c;
+  l.sine_w = cur; cur += 64;
+  l.sine_b = cur; cur += 64;
   l.tmpl_w = cur; cur += round_up(c * 7, 64);
   l.tmpl_b = cur; cur += round_up(c, 64);
   l.down.clear(); l.down_cin.clear();
@@ -107,7 +112,7 @@ void rg_layout(const fdx_refinegan_desc& d, RgLayout& l) {
 }
 
 struct RgBufs {   // lives in fdx_ctx as an opaque block (see common.hip.h: rg_state)
-  DevBuf f0up, tmpl, part, noise, bott, mel;
+  DevBuf f0up, tmpl, part, noise, bott, mel, scan, zero;
   // One buffer set PER STAGE: padded rows rely on their halos staying zero, which a buffer re-used with another row
   // pitch would not guarantee.  [0, n): down stages (ds, ra, tm); [n, 2n): up stages (cat, xi, a1, ra, tm, xm).
   std::vector<DevBuf> cat, ds, ra, tm, xi, a1, xm;
@@ -132,7 +137,7 @@ void fdx_rg_free(void* p) { delete static_cast<fdx_rg_state*>(p); }
 
 extern "C" int fdx_refinegan_num_weights(const fdx_refinegan_desc* d) {
   if (rg_validate(d)) return FDX_E_ARG;
-  return 2 + d->n_down * 12 + 2 + 2 + d->n_up * (2 + 3 * (1 + 12 + 1)) + 2;
+  return (d->template_sine ? 2 : 0) + 2 + d->n_down * 12 + 2 + 2 + d->n_up * (2 + 3 * (1 + 12 + 1)) + 2;
 }
 
 extern "C" int fdx_refinegan_num_noises(const fdx_refinegan_desc* d) {
@@ -162,6 +167,7 @@ extern "C" int fdx_refinegan_pack(const fdx_refinegan_desc* d, const float* cons
   float* A = static_cast<float*>(out);
   memset(A, 0, bytes);
   int k = 0;
+  if (d->template_sine) { A[l.sine_w] = w[0][0]; A[l.sine_b] = w[1][0]; k += 2; }
   memcpy(A + l.tmpl_w, w[k], (size_t)l.c0 * 7 * sizeof(float));
   memcpy(A + l.tmpl_b, w[k + 1], (size_t)l.c0 * sizeof(float));
   k += 2;
@@ -305,11 +311,28 @@ extern "C" int fdx_refinegan_forward(fdx_handle h, const float* mel, const float
   // ---- template (generator.py:446-447)
   hipLaunchKernelGGL(k_f0_upsample, dim3((L + 255) / 256, B), dim3(256), 0, s, b.f0up.f(), f0, T, L);
   double* part = reinterpret_cast<double*>(b.part.p);
-  hipLaunchKernelGGL(k_comb_partial, dim3(n_chunks, B), dim3(kScanThreads), 0, s, part, b.f0up.f(), L, n_chunks, sr);
-  hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
   float* tmpl = b.tmpl.f() + kHalo;
-  hipLaunchKernelGGL(k_comb_final, dim3(n_chunks, B), dim3(kScanThreads), 0, s, tmpl, (long)ldL, part, b.f0up.f(),
-                     next_noise((size_t)B * L), L, n_chunks, sr, 0.1f, 0.003f);
+  if (!d.template_sine) {
+    hipLaunchKernelGGL(k_comb_partial, dim3(n_chunks, B), dim3(kScanThreads), 0, s, part, b.f0up.f(), L, n_chunks, sr);
+    hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
+    hipLaunchKernelGGL(k_comb_final, dim3(n_chunks, B), dim3(kScanThreads), 0, s, tmpl, (long)ldL, part, b.f0up.f(),
+                       next_noise((size_t)B * L), L, n_chunks, sr, 0.1f, 0.003f);
+  } else {
+    // SineGen with harmonic_num = 0 (generator.py:246-310): rand_ini is drawn and then zeroed for the fundamental (:254-258), so
+    // the initial phase is 0; cumsum(rad) % 1 -> wrap shifts -> sin(2 pi cumsum(rad + shift)); sines above sr // 2 cleared (:277-278);
+    // sine * uv + noise_amp * randn; merge = Linear(1, 1) + tanh.  Same kernels as the NSF-HiFiGAN source module with H = 1.
+    FDX_HIP(h, b.scan.ensure((size_t)B * L * 4, false, s));
+    FDX_HIP(h, b.zero.ensure((size_t)B * 4 + 64, true, s));
+    const float* rini = b.zero.f();
+    const dim3 g3(n_chunks, 1, B);
+    hipLaunchKernelGGL(k_scan_partial<1>, g3, dim3(kScanThreads), 0, s, part, b.f0up.f(), (const float*)nullptr, rini, L, 1, n_chunks, sr);
+    hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
+    hipLaunchKernelGGL(k_scan_tmp, g3, dim3(kScanThreads), 0, s, b.scan.f(), part, b.f0up.f(), rini, L, 1, n_chunks, sr);
+    hipLaunchKernelGGL(k_scan_partial<2>, g3, dim3(kScanThreads), 0, s, part, b.f0up.f(), b.scan.f(), rini, L, 1, n_chunks, sr);
+    hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
+    hipLaunchKernelGGL(k_source_final, dim3(n_chunks, B), dim3(kScanThreads), 0, s, tmpl, (long)ldL, part, b.f0up.f(), b.scan.f(), rini,
+                       next_noise((size_t)B * L), A + l.sine_w, A + l.sine_b, L, 1, n_chunks, sr, 0.1f, 0.003f, (float)(d.sampling_rate / 2));
+  }
 
   // View of channel slice [c0, ..) of cat buffer i
   auto cat_view = [&](int i, int c0) {

@@ -22,7 +22,10 @@ from .wavenet import _attach
 def generator_param_table(cfg: dict):
     """(key, shape, weight_normed) in libfishdx's canonical order (include/fishdx.h); names from generator.py:333-423."""
     c = cfg["start_channels"]
-    rows = [("template_conv.weight", (c, 1, 7), True), ("template_conv.bias", (c,), False)]
+    rows = []
+    if cfg.get("template_generator", "comb") == "sine":   # SineGen.merge = Sequential(Linear(1, 1), Tanh), generator.py:233-236
+        rows += [("template_gen.merge.0.weight", (1, 1), False), ("template_gen.merge.0.bias", (1,), False)]
+    rows += [("template_conv.weight", (c, 1, 7), True), ("template_conv.bias", (c,), False)]
     for i, _ in enumerate(cfg["downsample_rates"]):
         n = 2 * c
         for j in range(3):
@@ -57,17 +60,16 @@ class RefineGANGenerator(nn.Module):
                  upsample_rates=(8, 8, 2, 2), leaky_relu_slope: float = 0.2, num_mels: int = 128, start_channels: int = 16,
                  template_generator: str = "comb"):
         super().__init__()
-        if template_generator != "comb":
-            if template_generator == "sine":
-                raise NotImplementedError('template_generator="sine" is not built (no shipped config uses it)')
+        if template_generator not in ("comb", "sine"):
             raise ValueError(f"Unknown template generator: {template_generator}")
+        self.template_generator = template_generator
         assert np.prod(downsample_rates) == np.prod(upsample_rates) == hop_length
         self.sampling_rate, self.hop_length = sampling_rate, hop_length
         self.downsample_rates, self.upsample_rates = tuple(downsample_rates), tuple(upsample_rates)
         self.leaky_relu_slope = leaky_relu_slope
         self.cfg = dict(sampling_rate=sampling_rate, hop_length=hop_length, downsample_rates=self.downsample_rates,
                         upsample_rates=self.upsample_rates, leaky_relu_slope=leaky_relu_slope, num_mels=num_mels,
-                        start_channels=start_channels)
+                        start_channels=start_channels, template_generator=template_generator)
         self._table = generator_param_table(self.cfg)
         self._weight_normed = True
         for key, shape, wn in self._table:
@@ -83,6 +85,7 @@ class RefineGANGenerator(nn.Module):
         d = _lib.RefineGanDesc()
         d.sampling_rate, d.hop_length, d.num_mels, d.start_channels = sampling_rate, hop_length, num_mels, start_channels
         d.leaky_relu_slope = leaky_relu_slope
+        d.template_sine = 1 if template_generator == "sine" else 0
         if len(self.downsample_rates) > _lib.MAX_STAGES:
             raise ValueError("too many stages")
         d.n_down, d.n_up = len(self.downsample_rates), len(self.upsample_rates)
@@ -177,6 +180,8 @@ class RefineGANGenerator(nn.Module):
         shapes = self.noise_shapes(B, T)
         seed = 0
         if noises is None and self.rng == "torch":
+            if self.template_generator == "sine":   # SineGen draws (and then zeroes) the initial phases first: keep the RNG stream aligned
+                torch.rand(B, 1, device=mel.device)   # generator.py:254-257
             noises = [torch.randn(s, device=mel.device) for s in shapes]   # same draw order as the reference's randn_like calls
         arr = None
         if noises is not None:

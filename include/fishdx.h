@@ -253,8 +253,9 @@ typedef struct {
   int num_mels;                 /* 128 (256 inside HiFiSinger) */
   int start_channels;           /* 16 */
   float leaky_relu_slope;       /* 0.2 */
+  int template_sine;            /* 0: template_generator="comb" (CombToothGen, generator.py:159-194); 1: "sine" (SineGen, :197-310) */
 } fdx_refinegan_desc;
-/* Canonical order = the module's state_dict order with weight norm folded: template_conv.{weight,bias};
+/* Canonical order = the module's state_dict order with weight norm folded: [template_sine: template_gen.merge.0.{weight,bias};] template_conv.{weight,bias};
  * per down stage i, per j<3: downsample_blocks.i.1.convs1.j.{weight,bias}, convs2.j.{weight,bias}; mel_conv.*;
  * source_conv.*; per up stage i: upsample_conv_blocks.i.input_conv.*, per branch b<3: blocks.b.0.weight,
  * per j<3: blocks.b.1.convs1.j.*, convs2.j.*, then blocks.b.2.weight; output_conv.*. */

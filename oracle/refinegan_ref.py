@@ -5,8 +5,8 @@ fish_diffusion/modules/vocoders/refinegan/generator.py:
   ``RefineGANGenerator.forward`` :437-478 (ctor geometry :314-423), ``ResBlock.forward`` :63-75,
   ``AdaIN.forward`` :104-107, ``ParallelResBlock.forward`` :147-152, ``CombToothGen.forward`` :174-194
 and of the scalar glue of ``RefineGAN.spec2wav`` (refinegan.py:67-78).
-Only the default ``template_generator="comb"`` is restated (what configs/_base_/archs/hifi_svc_v2.py and
-configs/vocoder_refinegan.py use).
+Both template generators are restated: "comb" (the default; what configs/_base_/archs/hifi_svc_v2.py and
+configs/vocoder_refinegan.py use) and "sine" (``SineGen`` without overtones, :197-310).
 
 All random draws are explicit inputs, in the order the reference draws them:
   noises[0]        [B, 1, L]        comb-tooth noise (generator.py:191)
@@ -34,7 +34,10 @@ def _pad(k, d=1):
 def param_shapes(cfg: dict):
     """Folded (no weight_g / weight_v) parameter list with the reference's names."""
     c = cfg["start_channels"]
-    out = [("template_conv.weight", (c, 1, 7)), ("template_conv.bias", (c,))]
+    out = []
+    if cfg.get("template_generator", "comb") == "sine":
+        out += [("template_gen.merge.0.weight", (1, 1)), ("template_gen.merge.0.bias", (1,))]
+    out += [("template_conv.weight", (c, 1, 7)), ("template_conv.bias", (c,))]
     for i, _ in enumerate(cfg["downsample_rates"]):
         n = 2 * c
         for j in range(3):
@@ -68,6 +71,8 @@ def seeded_state(seed: int, cfg: dict) -> SD:
     for key, shape in param_shapes(cfg):
         if key.endswith("bias"):
             sd[key] = torch.randn(shape, generator=g) * 0.02
+        elif key == "template_gen.merge.0.weight":
+            sd[key] = 4.0 + 2.0 * torch.rand(shape, generator=g)      # O(1) template from a 0.1-amplitude sine
         elif len(shape) == 1:
             sd[key] = 0.05 + 0.15 * torch.rand(shape, generator=g)
         else:
@@ -89,6 +94,23 @@ def comb_tooth(f0_up: torch.Tensor, noise: torch.Tensor, sr: int, wave_amp=0.1, 
     return comb * uv + noise_amp * noise
 
 
+def sine_template(sd: SD, f0_up: torch.Tensor, noise: torch.Tensor, sr: int, sine_amp=0.1, noise_std=0.003) -> torch.Tensor:
+    """SineGen.forward with harmonic_num = 0 (generator.py:246-310).  f0_up [B,1,L]; noise [B,1,L] (the reference draws it as
+    [B,L,1]: same values, transposed).  rand_ini is drawn and zeroed for the fundamental (:254-258): the initial phase is 0."""
+    f0 = f0_up.transpose(1, 2)                                   # [B, L, 1]
+    rad = (f0 / sr) % 1
+    tmp = torch.cumsum(rad, 1) % 1
+    shift = torch.zeros_like(rad)
+    shift[:, 1:, :] = ((tmp[:, 1:, :] - tmp[:, :-1, :]) < 0) * -1.0
+    sines = torch.sin(torch.cumsum(rad + shift, dim=1) * 2 * np.pi)
+    sines[f0 > sr // 2] = 0
+    sine_waves = sines * sine_amp
+    uv = (f0 > 0).to(f0.dtype)
+    noise_amp = uv * noise_std + (1 - uv) * sine_amp / 3
+    sine_waves = sine_waves * uv + noise_amp * noise.transpose(1, 2)
+    return torch.tanh(F.linear(sine_waves, sd["template_gen.merge.0.weight"], sd["template_gen.merge.0.bias"])).transpose(1, 2)
+
+
 def _resblock(sd: SD, prefix: str, x, k: int, slope: float, same: bool):
     for j, d in enumerate((1, 3, 5)):
         xt = F.leaky_relu(x, slope)
@@ -105,7 +127,10 @@ def generator_forward(sd: SD, cfg: dict, mel: torch.Tensor, f0: torch.Tensor, no
     slope, sr, hop = cfg["leaky_relu_slope"], cfg["sampling_rate"], cfg["hop_length"]
     it = iter(noises)
     f0_up = F.interpolate(f0, size=mel.shape[-1] * hop, mode="linear")
-    template = comb_tooth(f0_up, next(it), sr)
+    if cfg.get("template_generator", "comb") == "sine":
+        template = sine_template(sd, f0_up, next(it), sr)
+    else:
+        template = comb_tooth(f0_up, next(it), sr)
     if taps is not None:
         taps["template"] = template
     x = F.conv1d(template, sd["template_conv.weight"], sd["template_conv.bias"], padding=3)
