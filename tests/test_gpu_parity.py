@@ -892,9 +892,9 @@ def test_refinegan_interfaces_and_device_rng(dev):
     out = voc.wav2spec(audio)
     want = mel_ref.wav2spec(load("mel")["wav"], use_natural_log=False, hop=256)
     assert out.shape == want.shape and abs_err(out.cpu(), want) < 2e-3
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                       # generator.py:341-342 (the "sine" template: tests/test_gpu_round2.py)
         from fish_diffusion_amd import RefineGANGenerator
-        RefineGANGenerator(template_generator="sine")
+        RefineGANGenerator(template_generator="saw")
     with pytest.raises(ValueError):
         voc.model(mel.to(dev)[None], f0d[None, :-1])
 
