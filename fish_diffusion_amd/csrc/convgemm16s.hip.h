@@ -374,4 +374,25 @@ static __global__ void k_repack16_nr2(float2* __restrict__ dst, const float4* __
   dst[(2 * mt + 1) * per_mt + rem] = b1;
 }
 
+
+// 16x16x4 fragment order (NR = 4: one float4 per lane, NR = 2: one float2) of a plain [rows][K] GEMM weight, derived on the device from
+// the 32x32x2 order pack_convgemm(RB = 2) wrote into the arena: src[(((mt*n_it + it)*2 + rb)*64 + hi*32 + r32)*4 + j] =
+// w(row = mt*64 + rb*32 + r32, c = it*8 + hi*4 + j).  One thread per destination lane slot.
+template <int NR>
+static __global__ void k_repack16_from32(float* __restrict__ dst, const float* __restrict__ src, int n_mt64, int n_it) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // ((mt'*n_it + it)*2 + h)*64 + lane, mt' = tile of NR blocks
+  const size_t n_dst = (size_t)n_mt64 * (4 / NR) * n_it * 128;
+  if (i >= n_dst) return;
+  const int lane = (int)(i & 63), h = (int)((i >> 6) & 1);
+  const size_t q = i >> 7;
+  const int it = (int)(q % n_it), mtp = (int)(q / n_it);
+  const int c = it * 8 + h * 4 + (lane >> 4);
+#pragma unroll
+  for (int x = 0; x < NR; ++x) {
+    const int row = mtp * (16 * NR) + x * 16 + (lane & 15);
+    const int mt = row >> 6, rb = (row >> 5) & 1, r32 = row & 31, hi = (c & 7) >> 2, j = c & 3;
+    dst[i * NR + x] = src[((((size_t)mt * n_it + (c >> 3)) * 2 + rb) * 64 + hi * 32 + r32) * 4 + j];
+  }
+}
+
 }  // namespace fdx

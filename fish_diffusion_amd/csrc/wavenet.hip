@@ -47,6 +47,10 @@ static int conv_shape_env() {
   return v;
 }
 static bool shapes_enabled() { return conv_shape_env() != 0; }
+static int outp_shape_env() {   // FDX_OUTP_SHAPE=0: always the 32x32x2 kernel; =<NR><NM>: force a 16x16x4 shape
+  static const int v = [] { const char* e = getenv("FDX_OUTP_SHAPE"); return e ? atoi(e) : -1; }();
+  return v;
+}
 
 
 // ================================================================================================ layout
@@ -222,6 +226,24 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
       hipLaunchKernelGGL(k_repack16_nr2, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, nullptr, reinterpret_cast<float2*>(h->wn_nr2.f() + cur),
                          reinterpret_cast<const float4*>(h->wn_arena + p.w_off), n_src, p.cin8 * p.taps, 1);
       cur += n_src * 4;
+    }
+    // the out-projection (packed for 32x32x2) in both 16x16x4 orders
+    if (!outp16()) {
+      size_t tot = 0;
+      for (const auto& p : l.outp) tot += 2 * packed_floats(p.n_mtiles, 2, p.cin8, 1);
+      FDX_HIP(h, h->wn_outp16.ensure(tot * sizeof(float), false, nullptr));
+      h->wn_outp16_off4.clear(); h->wn_outp16_off2.clear();
+      size_t c2 = 0;
+      for (const auto& p : l.outp) {
+        const size_t nf = packed_floats(p.n_mtiles, 2, p.cin8, 1);
+        h->wn_outp16_off4.push_back(c2); h->wn_outp16_off2.push_back(c2 + nf);
+        const size_t n4 = nf / 4, n2 = nf / 2;
+        hipLaunchKernelGGL(k_repack16_from32<4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, nullptr, h->wn_outp16.f() + c2, h->wn_arena + p.w_off,
+                           p.n_mtiles, p.cin8);
+        hipLaunchKernelGGL(k_repack16_from32<2>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, nullptr, h->wn_outp16.f() + c2 + nf, h->wn_arena + p.w_off,
+                           p.n_mtiles, p.cin8);
+        c2 += 2 * nf;
+      }
     }
     FDX_HIP(h, hipGetLastError());
     FDX_HIP(h, hipStreamSynchronize(nullptr));
@@ -462,6 +484,20 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
     if (forced > 0) sh = Shape16{forced / 10, forced % 10};
     if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8 || (sh.NR == 2 && !h->wn_nr2_ok)) sh = Shape16{4, 4};
     h->conv_shape_nr = sh.NR; h->conv_shape_nm = sh.NM;
+    // the out-projection (rows = 2C, K = C: 16 iterations per K-splitting wave) runs on the same 16x16x4 family for EVERY geometry,
+    // so that an item's result does not depend on the batch it rode in (the 32x32x2 kernel groups the k-steps differently:
+    // last-bit differences).  FDX_OUTP_SHAPE=0 restores the 32x32x2 kernel.
+    Shape16 so{0, 0};
+    const int forced_o = outp_shape_env();
+    if (h->wn_nr2_ok && !outp16() && forced_o != 0) {
+      const int n_o = (C / 8 + 3) / 4;
+      const long wgo = (long)(rows16 / 4) * B * ((T + 63) / 64);
+      so = Shape16{4, 4};
+      if (forced_o > 0) so = Shape16{forced_o / 10, forced_o % 10};
+      else if (wgo < 2 * 256) so = pick_shape16(rows16, B, T, 12000.0 / (32.0 * n_o));
+      if ((so.NR != 2 && so.NR != 4) || so.NM < 4 || so.NM > 8) so = Shape16{4, 4};
+    }
+    h->outp_shape_nr = so.NR; h->outp_shape_nm = so.NM;
   }
   auto sz = [&](int ch) { return (size_t)B * ch * ld * sizeof(float); };
   // every buffer that is read with column shifts must have zero halos => re-zero on geometry change
@@ -628,7 +664,23 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       g.P = Pl; g.p_bs = p_bs; g.ldp = ld; g.C = C;
       FDX_HIP(h, (run_gemm<true, false>(A, l.conv[i], B, T, Y, bsC, ld, -dil, dil, 1.f, g, s, ev0, ev1)));
     }
-    if (outp16()) {
+    if (h->outp_shape_nr) {   // shape-adaptive 16x16x4 tiles (weights re-ordered at attach)
+      const int NRo = h->outp_shape_nr, NMo = h->outp_shape_nm;
+      const ConvGeom g4{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles}, g2{B, T, l.outp[i].cin8, 1, 0, 0, 2 * l.outp[i].n_mtiles};
+      const void* W4 = h->wn_outp16.f() + h->wn_outp16_off4[i];
+      const void* W2 = h->wn_outp16.f() + h->wn_outp16_off2[i];
+      hipError_t e = hipErrorInvalidValue;
+#define FDX_OUTP_SHAPE(NR_, NM_)                                                                                                   \
+  if (NRo == NR_ && NMo == NM_) {                                                                                                  \
+    const EpiResSkip16S<NM_> rs{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL, \
+                                (float)(1.0 / (double)sqrtL)};                                                                     \
+    e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Z, bsC, ld, rs, s, eo0, eo1);     \
+  }
+      FDX_OUTP_SHAPE(4, 4) FDX_OUTP_SHAPE(4, 5) FDX_OUTP_SHAPE(4, 6) FDX_OUTP_SHAPE(4, 7) FDX_OUTP_SHAPE(4, 8)
+      FDX_OUTP_SHAPE(2, 4) FDX_OUTP_SHAPE(2, 5) FDX_OUTP_SHAPE(2, 6) FDX_OUTP_SHAPE(2, 7) FDX_OUTP_SHAPE(2, 8)
+#undef FDX_OUTP_SHAPE
+      FDX_HIP(h, e);
+    } else if (outp16()) {
       const ConvGeom go{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles};
       EpiResSkip16 r{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL,
                      (float)(1.0 / (double)sqrtL)};
