@@ -177,6 +177,7 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
   float* out2; long o2_bs; int ldo2;  // optional second output
   const float* sb; int sb_ld, sb_bs;  // out2 = v + sb[row*sb_ld + b*sb_bs]
   int tight;                          // 1: `out` is a caller tensor with no padding (row pitch may equal T); out2 is always padded
+  int out2_zero_masked;               // 1: masked columns of out2 get 0 instead of sb (exact-ragged mode: nothing exists beyond an item's length)
   struct Pre { float bias, sb; bool m0, m1; };
   __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
     Pre p{0.f, 0.f, false, false};
@@ -199,7 +200,11 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
     v.y = act1(v.y, p.bias, p.m1);
     if (tight) st2(out + b * o_bs + (long)row * ldo + t, v, two);
     else st2p(out + b * o_bs + (long)row * ldo + t, v, two);
-    if (out2) st2p(out2 + b * o2_bs + (long)row * ldo2 + t, f2{v.x + p.sb, v.y + p.sb}, two);
+    if (out2) {
+      f2 y{v.x + p.sb, v.y + p.sb};
+      if (out2_zero_masked) { if (p.m0) y.x = 0.f; if (p.m1) y.y = 0.f; }
+      st2p(out2 + b * o2_bs + (long)row * ldo2 + t, y, two);
+    }
   }
 };
 

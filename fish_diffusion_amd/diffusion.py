@@ -119,9 +119,13 @@ class GaussianDiffusion(nn.Module):
     def forward(self, features, sampler_interval=None, progress: bool = False, skip_steps: int = 0,
                 original_mel: Optional[torch.Tensor] = None, noise_predictor: Optional[str] = None,
                 x_masks: Optional[torch.Tensor] = None, cond_masks: Optional[torch.Tensor] = None,
-                x_init: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None):
+                x_init: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None, lengths=None):
         """features [B, T, E] -> mel [B, T, M].  `x_init` / `step_noise` (extensions, default None) inject the
-        random draws the reference takes from the global RNG (diffusion.py:222,232; noise_predictor.py:101)."""
+        random draws the reference takes from the global RNG (diffusion.py:222,232; noise_predictor.py:101).
+        `lengths` (extension): per-item valid frame counts of a padded batch -> EXACT-RAGGED mode (`fdx_sampler_run_ragged`): every
+        item's mel[:length] is bit for bit what a batch-1 call on its unpadded features returns (the reference's inference loop,
+        tools/diffusion/inference.py:336-376, runs one segment at a time); frames beyond an item's length are undefined.  Mutually
+        exclusive with x_masks / cond_masks (the reference's own padded-batch semantics)."""
         if sampler_interval is None:
             sampler_interval = self.sampler_interval
         if noise_predictor is None:
@@ -165,6 +169,13 @@ class GaussianDiffusion(nn.Module):
                 raise ValueError(f"step_noise must be {(n_rows, B, M, T)}, got {tuple(step_noise.shape)}")
         xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if step_noise is None else 0
+        lens = None
+        if lengths is not None:
+            if x_masks is not None or cond_masks is not None:
+                raise ValueError("lengths (exact-ragged batches) and x_masks / cond_masks (the reference's padded-batch semantics) are exclusive")
+            lens = np.ascontiguousarray([int(v) for v in (lengths.tolist() if torch.is_tensor(lengths) else lengths)], dtype=np.int32)
+            if lens.shape != (B,) or lens.min() < 1 or lens.max() > T:
+                raise ValueError(f"lengths must be {B} values in [1, {T}], got {lens.tolist()}")
 
         mel = torch.empty((B, T, M), device=device, dtype=torch.float32)
         smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
@@ -188,8 +199,12 @@ class GaussianDiffusion(nn.Module):
                 elif step_noise is not None and chunk != n_rows:
                     sn = step_noise[r0:r1]
                 tab = table[r0:r1]
-                _lib.check(_lib.lib().fdx_sampler_run(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x),
-                                                      _lib.ptr(sn), seed + r0, _lib.ptr(xm), st), eng.h)
+                if lens is not None:
+                    _lib.check(_lib.lib().fdx_sampler_run_ragged(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x), _lib.ptr(sn),
+                                                                 seed + r0, C.c_void_p(lens.ctypes.data), st), eng.h)
+                else:
+                    _lib.check(_lib.lib().fdx_sampler_run(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x),
+                                                          _lib.ptr(sn), seed + r0, _lib.ptr(xm), st), eng.h)
             _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x), B, M, T, C.c_void_p(smin.data_ptr()),
                                                   C.c_void_p(smax.data_ptr()), smin.numel(), _lib.ptr(mel), st), eng.h)
         return mel

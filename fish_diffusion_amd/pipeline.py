@@ -79,11 +79,16 @@ def make_batches(lengths: Sequence[int], max_batch: int, max_pad_ratio: Optional
 def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequence[torch.Tensor], *, max_batch: int = 8,
                sampler_interval: Optional[int] = None, noise_predictor: Optional[str] = None, rank: int = 0, world: int = 1,
                mel_scale: Optional[float] = None, x_init_fn: Optional[Callable] = None,
-               source_noise_fn: Optional[Callable] = None, bucket: int = 64) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
+               source_noise_fn: Optional[Callable] = None, bucket: int = 64, exact: Optional[bool] = None) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
     """features[i]: [T_i, E] device tensors; f0s[i]: [T_i].  Returns [(index, mel [T_i, M], wav [T_i * hop])] for the
     utterances this rank owns.  `x_init_fn(idx_list, M, T)` / `source_noise_fn(idx_list, L)` let tests inject the random
     draws (initial x_T; (rand_ini, src_noise)) -- by default they are drawn on the device.  `bucket`: every micro-batch is padded
-    to a multiple of this many frames (masked like any other padding; 0 / 1 = pad to the longest member only)."""
+    to a multiple of this many frames (0 / 1 = pad to the longest member only).
+    `exact` (default: True for the fp32 WaveNet denoiser): padded batches run in the library's EXACT-RAGGED mode -- every utterance's
+    result is bit for bit what a batch-1 run of it alone gives (the reference's one-segment-at-a-time loop), padding costs no
+    arithmetic (tiles beyond an item's length are skipped).  False: the reference's own padded-batch semantics with x_masks /
+    cond_masks (the masked tail stays alive inside the receptive field: the last ~75 frames of every padded item differ slightly
+    from a run alone)."""
     if len(features) != len(f0s):
         raise ValueError("features and f0s must have the same length")
     lengths = [int(f.shape[0]) for f in features]
@@ -95,6 +100,9 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     if mel_scale is None:   # nsf_hifigan.py:79-80: a log10 mel is rescaled to natural log
         mel_scale = 2.30259 if getattr(vocoder, "use_natural_log", True) is False else 1.0
     dev = features[mine[0]].device
+    if exact is None:
+        den = getattr(diffusion, "denoise_fn", None)
+        exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") == "fp32"
     out = []
     for group in make_batches([lengths[i] for i in mine], max_batch):
         idx = [mine[g] for g in group]
@@ -113,8 +121,11 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
         kw = {}
         if x_init_fn is not None:
             kw["x_init"] = x_init_fn(idx, diffusion.mel_bins, T)
-        mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor,
-                        x_masks=masks if ragged else None, cond_masks=masks if ragged else None, **kw)     # [B, T, M]
+        if ragged and exact:
+            kw["lengths"] = [lengths[i] for i in idx]
+        elif ragged:
+            kw["x_masks"] = kw["cond_masks"] = masks
+        mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
         for b, i in enumerate(idx):
             n = lengths[i]
             vkw = {}

@@ -178,6 +178,15 @@ enum { FDX_SAMPLER_NAIVE = 0, FDX_SAMPLER_UNIPC = 1, FDX_SAMPLER_PLMS = 2 };
  * x_mask as in fdx_wavenet_forward.  fdx_wavenet_prepare must have been called for this batch. */
 int fdx_sampler_run(fdx_handle h, int kind, const float* host_table, int n_rows, float* x,
                     const float* step_noise, uint64_t seed, const uint8_t* x_mask, fdx_stream s);
+/* The same sampler run over an EXACT-RAGGED batch: item b has host_lens[b] <= T valid frames (the geometry fdx_wavenet_prepare was
+ * given is the padded one).  Every item is computed exactly as if it ran alone at its own length -- bit for bit: the denoiser treats
+ * frames from an item's length on as non-existent (the dilated conv reads zeros there, like its own zero padding), and workgroup
+ * tiles that lie wholly beyond an item's length are skipped.  This is what a serving loop wants from a padded batch; the
+ * reference's own batched semantics (x_masks / cond_masks: the padded tail stays "alive" inside the receptive field,
+ * wavenet.py:217-221,233-234) remain available through fdx_sampler_run + x_mask.  x beyond an item's length is left undefined.
+ * WaveNet denoiser, fp32 kernels only.  The conditioner passed to fdx_wavenet_prepare may hold anything beyond an item's length. */
+int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* host_table, int n_rows, float* x, const float* step_noise,
+                           uint64_t seed, const int* host_lens, fdx_stream s);
 /* The start of shallow diffusion, diffusion.py:223-232: out = q_sample(norm_spec(src), t, noise).
  *   normalise != 0: v = (src - spec_min) / (spec_max - spec_min) * 2 - 1 (diffusion.py:315-316).  spec_min/max are host arrays of
  *   n_spec floats; the reference's [1,1,n] buffers broadcast against the LAST axis of the [B,M,T] tensor, so n_spec is 1 or T.

@@ -232,8 +232,9 @@ print("OK", nb.value)
 def test_ragged_stream_of_40_lengths_recaptures_nothing_after_warmup(dev):
     """tools/diffusion/inference.py:336-376 feeds segments of arbitrary length.  pipeline.synthesize pads every micro-batch to a
     64-frame bucket and the library keeps an LRU of recorded sampler graphs, so a stream of >= 32 distinct lengths settles on a
-    handful of geometries: after one pass over the stream, a second pass captures NOTHING.  Bucketed results equal the oracle run
-    of the same padded, masked batch (the reference's batched semantics)."""
+    handful of geometries: after one pass over the stream, a second pass captures NOTHING.  With `exact=False` (the reference's
+    padded-batch semantics) bucketed results equal the oracle run of the same padded, masked batch; the default exact-ragged mode
+    is covered by test_exact_ragged_batches_equal_batch_one_runs_bit_for_bit."""
     from fish_diffusion_amd import pipeline
     from oracle import nsf_hifigan_ref, sampler_ref
     from tests.test_gpu_parity import _oracle_den
@@ -268,7 +269,7 @@ def test_ragged_stream_of_40_lengths_recaptures_nothing_after_warmup(dev):
     sel = [i for i in range(40) if 64 < lens[i] <= 192][:5]
     sl = [lens[i] for i in sel]
     x_all = torch.randn(len(sel), 128, 192, generator=g)
-    r = pipeline.synthesize(diff, voc, [feats[i] for i in sel], [f0s[i] for i in sel], max_batch=2, sampler_interval=100,
+    r = pipeline.synthesize(diff, voc, [feats[i] for i in sel], [f0s[i] for i in sel], max_batch=2, sampler_interval=100, exact=False,
                             x_init_fn=lambda ii, M, T: torch.stack([x_all[i, :, :T] for i in ii]).to(dev))
     by = {i: m.cpu() for i, m, _ in r}
     mine = shard_utterances(sl, 0, 1)
@@ -470,3 +471,35 @@ def test_refinegan_sine_template_matches_reference_golden(dev, tag):
     gen.rng = "philox"
     c = gen(g["mel"].to(dev), g["f0"].to(dev))
     assert torch.isfinite(c).all() and float(c.abs().max()) <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------ exact-ragged batches
+@pytest.mark.parametrize("net", ["small", "full"])
+def test_exact_ragged_batches_equal_batch_one_runs_bit_for_bit(dev, net):
+    """`GaussianDiffusion(..., lengths=)` / fdx_sampler_run_ragged: every member of a padded batch is computed exactly as if it ran
+    alone at its own length (what tools/diffusion/inference.py:336-376 computes one segment at a time) -- BIT FOR BIT, for every
+    sampler, for lengths straddling tile edges, and whatever the same buffers held beyond the lengths before (a previous, longer
+    run).  Frames beyond an item's length are unspecified."""
+    cfg = WN_SMALL if net == "small" else WN_FULL
+    sd = wavenet_sd(cfg, 101 if net == "small" else 1234)
+    diff = _diffusion(cfg, sd, dev)
+    g = torch.Generator().manual_seed(77)
+    cases = [([130, 64, 65, 1], 192), ([200, 113], 256)] if net == "small" else [([430, 300, 129], 448)]
+    for lens, T in cases:
+        B = len(lens)
+        feats = torch.randn(B, T, 256, generator=g).to(dev)            # junk beyond the lengths on purpose
+        x0 = torch.randn(B, 128, T, generator=g).to(dev)
+        diff(feats, sampler_interval=250, x_init=x0)                    # leave full-length activations in every buffer
+        for pred, iv in (("unipc", 100), ("plms", 100), ("naive", 100)):
+            noise = torch.randn(1000 // iv, B, 128, T, generator=g).to(dev) if pred == "naive" else None
+            got = diff(feats, sampler_interval=iv, noise_predictor=pred, x_init=x0, step_noise=noise, lengths=lens)
+            again = diff(feats, sampler_interval=iv, noise_predictor=pred, x_init=x0, step_noise=noise, lengths=torch.tensor(lens))
+            assert torch.equal(got, again)                               # (recorded graph replay)
+            for b, n in enumerate(lens):
+                alone = diff(feats[b:b + 1, :n].contiguous(), sampler_interval=iv, noise_predictor=pred, x_init=x0[b:b + 1, :, :n].contiguous(),
+                             step_noise=None if noise is None else noise[:, b:b + 1, :, :n].contiguous())
+                assert torch.equal(got[b, :n], alone[0]), (net, lens, pred, b)
+    with pytest.raises(ValueError):
+        diff(feats, lengths=lens, x_masks=torch.zeros(B, T, dtype=torch.bool, device=dev))
+    with pytest.raises(ValueError):
+        diff(feats, lengths=[T + 1] * B)
