@@ -290,6 +290,8 @@ def main():
     ap.add_argument("--storage", choices=("fp32", "bf16"), default="fp32",
                     help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype")
     ap.add_argument("--prof-stride", type=int, default=None, help="time every N-th launch of the dominant kernel")
+    ap.add_argument("--no-exact", action="store_true", help="sharded config: the reference's padded-batch semantics (x_masks / cond_masks) instead of "
+                    "the library's exact-ragged batches (every utterance as if run alone; padding tiles skipped)")
     args = ap.parse_args()
     cfg = ALIASES.get(str(args.config).lower())
     if cfg is None:
@@ -387,10 +389,11 @@ def main():
         feats = [torch.randn(n, 256, generator=g).to(dev) for n in lens]
         f0s = [synth_f0(n).to(dev) for n in lens]
         mine = fdist.shard_utterances(lens, vrank, vworld)
-        batches = pipeline.make_batches([lens[i] for i in mine], 8)
+        batches = pipeline.make_batches([lens[i] for i in mine], 8, padding_free=not args.no_exact)
 
         def step(k):
-            return pipeline.synthesize(diff, voc, feats, f0s, max_batch=8, sampler_interval=interval, rank=vrank, world=vworld)
+            return pipeline.synthesize(diff, voc, feats, f0s, max_batch=8, sampler_interval=interval, rank=vrank, world=vworld,
+                                       exact=not args.no_exact)
         frames = sum(lens[i] for i in mine)
         audio_s = frames * hop / 44100.0
         alg, exe = e2e_flops(frames, n_steps, frames * hop, frames, nsf)
@@ -401,7 +404,10 @@ def main():
                     + f"; this rank: {len(mine)} utterances, {frames} frames, masked micro-batches {[len(b) for b in batches]}; {n_steps}-step UniPC + "
                     "NSF-HiFiGAN config_v1 per utterance")
         cfg_extra = {"utterances_total": 64, "utterances_this_rank": len(mine), "frames_this_rank": frames, "shards": vworld,
-                     "micro_batches": [len(b) for b in batches], "sampler": "unipc", "sampler_steps": n_steps}
+                     "micro_batches": [len(b) for b in batches], "sampler": "unipc", "sampler_steps": n_steps,
+                     "batching": "reference padded-batch semantics (x_masks / cond_masks)" if args.no_exact else
+                                 "exact-ragged (utterances laid end to end in one row with 16-frame holes: no padding to a common length; every utterance "
+                                 "bit-identical to its batch-1 run)"}
         prof_handle = lambda: diff.denoise_fn.engine(dev)   # noqa: E731
         prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 7
         alg_bytes = None
@@ -472,7 +478,7 @@ def main():
     # ------------------------------------------------------------------------------------------------ outside the timed region
     other = []
     stages = None
-    if cfg in ("headline", "ddpm1000") and do_prof and not bf16 and rank == 0:   # the second residual-block kernel, one extra step
+    if cfg in ("headline", "ddpm1000", "sharded") and do_prof and not bf16 and rank == 0:   # the second residual-block kernel, one extra step
         prof_begin(prof_handle(), _lib.PROF_WN_OUTPROJ, stride)
         step(warmup)
         torch.cuda.synchronize()

@@ -143,10 +143,9 @@ struct fdx_ctx {
   // ---- sampler state (padded [B][M][ld])
   fdx::DevBuf sx, sxt, sbase, sm[2], shist[4], seps2, snoise, maskbuf;
   std::vector<float> ts_host;
-  // exact-ragged batches (fdx_sampler_run_ragged): per-item lengths on the device, the padding mask derived from them
-  fdx::DevBuf lensbuf, lensmask;
-  std::vector<int> lens_host;
-  const int* ragged_lens = nullptr;   // non-null only while a ragged run is being enqueued / recorded
+  // exact-mask runs (fdx_sampler_run_ragged): 1 / 0 per frame in the padded row layout
+  fdx::DevBuf keepbuf;
+  const float* ragged_keep = nullptr;   // non-null only while such a run is being enqueued / recorded
 
   // ---- nsf
   bool nsf_ok = false;

@@ -70,7 +70,6 @@ template <int NM> struct EpiGate16S {  // wavenet.py:112-115 (EpiGate16 for NM c
   float* out; long o_bs; int ldo;
   const float* P; long p_bs; int ldp;
   int C;
-  const int* lens;   // exact-ragged mode: per-item valid length (device, [B]) or null; tiles at or beyond it are skipped by the kernel
   struct Pre { VecN<NM> pg, pf; };
   __device__ __forceinline__ Pre load(int b, int row, int t) const {
     const float* q = P + b * p_bs + t;
@@ -91,18 +90,23 @@ template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum o
   const float* sb; int sb_ld, sb_bs;
   int C, skip_mode;
   float inv_div, r_inv_div;
-  const int* lens;   // exact-ragged mode (see EpiGate16S): Y -- the next conv's input -- is written as 0 from an item's length on
-  struct Pre { VecN<NM> old; float bias, sb; int vlen; };
+  // exact-mask mode (fdx_sampler_run_ragged): keep[b][t] = 1 where a frame exists, 0 where it does not (padded row layout, 0 in the
+  // pads); Y -- the next dilated conv's input -- is written as 0 wherever keep is 0, so that frames next to a hole read zeros exactly
+  // like the conv's own zero padding.  null: every column of [0, T) exists.
+  const float* keep; long keep_bs;
+  struct Pre { VecN<NM> old; VecN<NM> keep; float bias, sb; };
   __device__ __forceinline__ bool is_res(int row) const { return __builtin_amdgcn_readfirstlane(row) < C; }
   __device__ __forceinline__ Pre load(int b, int row, int t) const {
     Pre p;
 #pragma unroll
     for (int m = 0; m < NM; ++m) p.old.v[m] = 0.f;
     p.bias = bias[row]; p.sb = 0.f;
-    p.vlen = lens ? lens[b] : 0x7fffffff;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) p.keep.v[m] = 1.f;
     if (is_res(row)) {
       p.old = ldN<NM>(X + b * bs + (long)row * ld + t);
       if (Y) p.sb = sb[(long)row * sb_ld + b * sb_bs];
+      if (Y && keep) p.keep = ldN<NM>(keep + b * keep_bs + t);
     } else if (skip_mode == 1 || skip_mode == 2) {
       p.old = ldN<NM>(SK + b * bs + (long)(row - C) * ld + t);
     }
@@ -117,7 +121,7 @@ template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum o
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         xn.v[m] = div_const(p.old.v[m] + v.v[m], 1.41421356237309504880f, 0.70710678118654752440f);
-        yn.v[m] = t + m < p.vlen ? xn.v[m] + p.sb : 0.f;
+        yn.v[m] = p.keep.v[m] != 0.f ? xn.v[m] + p.sb : 0.f;
       }
       stNp<NM, false>(X + o, xn, nvalid);
       if (Y) stNp<NM, true>(Y + o, yn, nvalid);
@@ -158,7 +162,6 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
   const int nt = L - mt * a.n_tiles_n;
   const int item = nt / a.tiles_per_item;
   const int t0 = (nt - item * a.tiles_per_item) * COLS;
-  if (epi.lens && t0 >= epi.lens[item]) return;                       // exact-ragged mode: the whole tile lies beyond this item's length
   const int tc = t0 + NM * lj;                                        // this lane's first column
   const int nvalid = min(NM, a.T - tc);                               // <= 0: all of the lane's columns are overhang
   constexpr int ROWS = Epi::kPaired ? NR * 8 : NR * 16;               // logical rows (pairs) per tile

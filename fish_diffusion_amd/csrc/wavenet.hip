@@ -594,15 +594,15 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   float* X = h->X.f() + kHalo; float* Y = h->Y.f() + kHalo; float* Z = h->Z.f() + kHalo;
   float* SK = h->SK.f() + kHalo; float* H = h->H.f() + kHalo;
   const float* S = h->S.f() + kHalo + col0;
-  const int* lens = h->ragged_lens;   // exact-ragged mode (fdx_sampler_run_ragged), else null
-  if (lens && (h->wn_arena_bf16 || !conv16() || !h->wn_nr2_ok || !h->outp_shape_nr))
-    return fail(h, FDX_E_NOIMPL, "exact-ragged batches need the fp32 shape-adaptive kernels (not bf16 storage / FDX_RESBLOCK_MFMA / FDX_*_SHAPE=0)");
+  const float* keep = h->ragged_keep;   // exact-mask mode (fdx_sampler_run_ragged), else null
+  if (keep && (h->wn_arena_bf16 || !h->outp_shape_nr))
+    return fail(h, FDX_E_NOIMPL, "exact-mask runs need the fp32 shape-adaptive kernels (not bf16 storage / FDX_RESBLOCK_MFMA / FDX_*_SHAPE=0)");
 
   {  // input projection + ReLU + mask; Y = X + s_0
     EpiBias e = epi_bias(X, bsC, ld, A + l.in_proj.b_off, C, ACT_RELU);
     e.mask = mask; e.mask_ld = T;
     e.out2 = Y; e.o2_bs = bsC; e.ldo2 = ld; e.sb = S; e.sb_ld = ldn; e.sb_bs = sb_bs;
-    e.out2_zero_masked = lens != nullptr;   // exact-ragged mode: the conv's input is 0 from an item's length on (as if it ran alone)
+    e.out2_zero_masked = keep != nullptr;   // exact-mask mode: the conv's input is 0 where no frame exists (as if every item ran alone)
     FDX_HIP(h, (run_gemm<true, false>(A, l.in_proj, B, T, xin, (long)M * ld, ld, 0, 0, 1.f, e, s)));
   }
   if (h->wn_arena_bf16)
@@ -645,7 +645,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       const ConvGeom gc{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles};
       EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
       const int NRs = h->conv_shape_nr, NMs = h->conv_shape_nm;
-      if (NRs == 4 && NMs == 4 && !lens) {
+      if (NRs == 4 && NMs == 4) {
         FDX_HIP(h, launch_convgemm16(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
       } else {
         const void* W4 = A + l.conv[i].w_off;
@@ -654,10 +654,10 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
         hipError_t e = hipErrorInvalidValue;
 #define FDX_GATE_SHAPE(NR_, NM_)                                                                                              \
   if (NRs == NR_ && NMs == NM_) {                                                                                             \
-    const EpiGate16S<NM_> gs{Z, bsC, ld, Pl, p_bs, ld, C, lens};                                                              \
+    const EpiGate16S<NM_> gs{Z, bsC, ld, Pl, p_bs, ld, C};                                                                    \
     e = launch_convgemm16s<EpiGate16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Y, bsC, ld, gs, s, ev0, ev1);   \
   }
-        FDX_GATE_SHAPE(4, 4) FDX_GATE_SHAPE(4, 5) FDX_GATE_SHAPE(4, 6) FDX_GATE_SHAPE(4, 7) FDX_GATE_SHAPE(4, 8)
+        FDX_GATE_SHAPE(4, 5) FDX_GATE_SHAPE(4, 6) FDX_GATE_SHAPE(4, 7) FDX_GATE_SHAPE(4, 8)
         FDX_GATE_SHAPE(2, 4) FDX_GATE_SHAPE(2, 5) FDX_GATE_SHAPE(2, 6) FDX_GATE_SHAPE(2, 7) FDX_GATE_SHAPE(2, 8)
 #undef FDX_GATE_SHAPE
         FDX_HIP(h, e);
@@ -677,7 +677,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
 #define FDX_OUTP_SHAPE(NR_, NM_)                                                                                                   \
   if (NRo == NR_ && NMo == NM_) {                                                                                                  \
     const EpiResSkip16S<NM_> rs{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL, \
-                                (float)(1.0 / (double)sqrtL), lens};                                                               \
+                                (float)(1.0 / (double)sqrtL), keep, (long)ld};                                                     \
     e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Z, bsC, ld, rs, s, eo0, eo1);     \
   }
       FDX_OUTP_SHAPE(4, 4) FDX_OUTP_SHAPE(4, 5) FDX_OUTP_SHAPE(4, 6) FDX_OUTP_SHAPE(4, 7) FDX_OUTP_SHAPE(4, 8)
@@ -766,8 +766,8 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
     if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked);
     if (h->den_kind == 2) return fdx_td_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked);
     const float* P = (!masked && h->cond_masked) ? h->P2.f() : nullptr;
-    // (exact-ragged mode: the "mask" is the items' own lengths, which an item run alone has too -- PLMS's unmasked call keeps it)
-    return wn_forward_core(h, xin, col, 0, (masked || h->ragged_lens) ? x_mask : nullptr, eps, bs, ld, s, P);
+    // (exact-mask mode: the mask marks frames that do not exist, for an item run alone as well -- PLMS's unmasked call keeps it)
+    return wn_forward_core(h, xin, col, 0, (masked || h->ragged_keep) ? x_mask : nullptr, eps, bs, ld, s, P);
   };
 
   if (kind == FDX_SAMPLER_UNIPC) {
@@ -912,7 +912,7 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
     const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
                               (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, h->alloc_gen,
                               (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn, (uint64_t)(uintptr_t)h->td,
-                              (uint64_t)(uintptr_t)h->ragged_lens};
+                              (uint64_t)(uintptr_t)h->ragged_keep};
     key = fnv1a(parts, sizeof parts, key);
     fdx_ctx::GraphEntry* hit = nullptr;
     for (auto& g : h->graphs) if (g.key == key) hit = &g;
@@ -951,35 +951,29 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   return FDX_OK;
 }
 
-// lens -> mask bytes (1 = beyond the item's length)
-static __global__ void k_mask_from_lens(uint8_t* __restrict__ mask, const int* __restrict__ lens, int B, int T) {
+// keep[b][kHalo + t] = mask[b][t] ? 0 : 1 (padded rows; the pads stay 0 from the buffer's zero fill)
+static __global__ void k_keep_from_mask(float* __restrict__ keep, int ld, const uint8_t* __restrict__ mask, int B, int T) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (t < T) mask[(long)b * T + t] = t >= lens[b] ? 1 : 0;
+  if (t < T) keep[(long)b * ld + kHalo + t] = mask[(long)b * T + t] ? 0.f : 1.f;
 }
 
 extern "C" int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* tab, int n_rows, float* x, const float* step_noise,
-                                      uint64_t seed, const int* host_lens, fdx_stream st) {
+                                      uint64_t seed, const uint8_t* x_mask, fdx_stream st) {
   GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (!h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run_ragged: call attach + prepare first");
-  if (!host_lens) return fail(h, FDX_E_ARG, "fdx_sampler_run_ragged: null lengths");
-  if (h->den_kind != 0) return fail(h, FDX_E_NOIMPL, "fdx_sampler_run_ragged: exact-ragged batches are built for the WaveNet denoiser");
-  const int B = h->B, T = h->T;
-  for (int b = 0; b < B; ++b)
-    if (host_lens[b] < 1 || host_lens[b] > T) return fail(h, FDX_E_ARG, "fdx_sampler_run_ragged: length %d of item %d outside [1, %d]", host_lens[b], b, T);
+  if (!x_mask) return fail(h, FDX_E_ARG, "fdx_sampler_run_ragged: null mask");
+  if (h->den_kind != 0) return fail(h, FDX_E_NOIMPL, "fdx_sampler_run_ragged: exact-mask runs are built for the WaveNet denoiser");
+  const int B = h->B, T = h->T, ld = h->ld;
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
-  h->lens_host.assign(host_lens, host_lens + B);          // context-owned staging for the async copy
-  FDX_HIP(h, h->lensbuf.ensure((size_t)B * sizeof(int), false, s));
-  FDX_HIP(h, hipMemcpyAsync(h->lensbuf.p, h->lens_host.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
-  FDX_HIP(h, h->lensmask.ensure((size_t)B * T, false, s));
-  hipLaunchKernelGGL(k_mask_from_lens, dim3((T + 255) / 256, B), dim3(256), 0, s, static_cast<uint8_t*>(h->lensmask.p),
-                     static_cast<const int*>(h->lensbuf.p), B, T);
-  // the conv's input must read 0 from every item's length on: what earlier runs (other lengths) left there is cleared
-  FDX_HIP(h, hipMemsetAsync(h->Y.p, 0, (size_t)B * h->wd.residual_channels * h->ld * sizeof(float), s));
-  h->ragged_lens = static_cast<const int*>(h->lensbuf.p);
-  const int rc = fdx_sampler_run(h, kind, tab, n_rows, x, step_noise, seed, static_cast<const uint8_t*>(h->lensmask.p), st);
-  h->ragged_lens = nullptr;
+  FDX_HIP(h, h->keepbuf.ensure((size_t)B * ld * sizeof(float), true, s));
+  hipLaunchKernelGGL(k_keep_from_mask, dim3((T + 255) / 256, B), dim3(256), 0, s, h->keepbuf.f(), ld, x_mask, B, T);
+  // the conv's input must read 0 wherever no frame exists: what earlier runs (other masks) left there is cleared
+  FDX_HIP(h, hipMemsetAsync(h->Y.p, 0, (size_t)B * h->wd.residual_channels * ld * sizeof(float), s));
+  h->ragged_keep = h->keepbuf.f() + kHalo;
+  const int rc = fdx_sampler_run(h, kind, tab, n_rows, x, step_noise, seed, x_mask, st);
+  h->ragged_keep = nullptr;
   return rc;
 }
 

@@ -108,6 +108,52 @@ class GaussianDiffusion(nn.Module):
                                                C.c_void_p(smax.data_ptr()), smin.numel(), a, b, _lib.ptr(noise), _lib.ptr(out), st), eng.h)
         return out
 
+    RAGGED_GAP = 16      # frames of hole between items: the widest dilated tap reaches 8 (dilation_cycle <= 4), the library asks for >= 16
+    RAGGED_BUCKET = 64   # the single row is padded to a multiple of this (bounds the number of geometries a stream produces)
+
+    def _forward_ragged(self, eng, cond, x, lens, kind, table, step_noise, seed, st):
+        """Exact-ragged batch: items laid end to end in one row with holes between them, `fdx_sampler_run_ragged`, results scattered
+        back to the padded [B, T, M] layout.  The gathers / scatters are plain copies (torch as plumbing); all arithmetic is in the
+        library."""
+        if not hasattr(_lib.lib(), "fdx_sampler_run_ragged") or getattr(self.denoise_fn, "_KIND", "") != "wavenet":
+            raise NotImplementedError("exact-ragged batches are built for the WaveNet denoiser")
+        device = x.device
+        B, M, T = x.shape
+        offs, cur = [], 0
+        for n in lens:
+            offs.append(cur)
+            cur += n + self.RAGGED_GAP
+        Tc = cur - self.RAGGED_GAP
+        Tc = (Tc + self.RAGGED_BUCKET - 1) // self.RAGGED_BUCKET * self.RAGGED_BUCKET
+        cond_c = torch.zeros((1, cond.shape[1], Tc), device=device, dtype=torch.float32)
+        x_c = torch.zeros((1, M, Tc), device=device, dtype=torch.float32)
+        hole = torch.ones((1, Tc), device=device, dtype=torch.uint8)
+        for b, (o, n) in enumerate(zip(offs, lens)):
+            cond_c[0, :, o:o + n] = cond[b, :, :n]
+            x_c[0, :, o:o + n] = x[b, :, :n]
+            hole[0, o:o + n] = 0
+        n_rows = table.shape[0]
+        sn = None
+        if kind == _lib.SAMPLER_NAIVE and (step_noise is not None or self.step_rng == "torch"):
+            # (no reference RNG stream to reproduce here: the reference never runs a ragged batch this way; draws are per batch)
+            sn = torch.zeros((n_rows, 1, M, Tc), device=device, dtype=torch.float32)
+            src = step_noise if step_noise is not None else torch.randn((n_rows, B, M, T), device=device)
+            for b, (o, n) in enumerate(zip(offs, lens)):
+                sn[:, 0, :, o:o + n] = src[:, b, :, :n]
+        mel_c = torch.empty((1, Tc, M), device=device, dtype=torch.float32)
+        smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
+        smax = self.spec_max.detach().reshape(-1).to("cpu", torch.float32).contiguous()
+        with eng.lock:
+            self.denoise_fn.prepare(cond_c, None)
+            _lib.check(_lib.lib().fdx_sampler_run_ragged(eng.h, kind, C.c_void_p(table.ctypes.data), n_rows, _lib.ptr(x_c), _lib.ptr(sn),
+                                                         seed, _lib.ptr(hole), st), eng.h)
+            _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x_c), 1, M, Tc, C.c_void_p(smin.data_ptr()),
+                                                  C.c_void_p(smax.data_ptr()), smin.numel(), _lib.ptr(mel_c), st), eng.h)
+        mel = torch.zeros((B, T, M), device=device, dtype=torch.float32)
+        for b, (o, n) in enumerate(zip(offs, lens)):
+            mel[b, :n] = mel_c[0, o:o + n]
+        return mel
+
     def train_step(self, *a, **k):
         raise NotImplementedError("fish_diffusion_amd implements the inference hot path only; use the reference "
                                   "GaussianDiffusion for training (diffusion.py:172-190)")
@@ -122,10 +168,12 @@ class GaussianDiffusion(nn.Module):
                 x_init: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None, lengths=None):
         """features [B, T, E] -> mel [B, T, M].  `x_init` / `step_noise` (extensions, default None) inject the
         random draws the reference takes from the global RNG (diffusion.py:222,232; noise_predictor.py:101).
-        `lengths` (extension): per-item valid frame counts of a padded batch -> EXACT-RAGGED mode (`fdx_sampler_run_ragged`): every
-        item's mel[:length] is bit for bit what a batch-1 call on its unpadded features returns (the reference's inference loop,
-        tools/diffusion/inference.py:336-376, runs one segment at a time); frames beyond an item's length are undefined.  Mutually
-        exclusive with x_masks / cond_masks (the reference's own padded-batch semantics)."""
+        `lengths` (extension): per-item valid frame counts of a padded batch -> EXACT-RAGGED mode: every item's mel[:length] is bit
+        for bit what a batch-1 call on its unpadded features returns (the reference's inference loop,
+        tools/diffusion/inference.py:336-376, runs one segment at a time); frames beyond an item's length come back as 0.  The
+        batch is laid out as ONE row -- items separated by 16-frame holes, nothing padded to a common length -- and run through
+        `fdx_sampler_run_ragged`, whose holes isolate the items exactly (include/fishdx.h).  Mutually exclusive with x_masks /
+        cond_masks (the reference's own padded-batch semantics)."""
         if sampler_interval is None:
             sampler_interval = self.sampler_interval
         if noise_predictor is None:
@@ -154,6 +202,8 @@ class GaussianDiffusion(nn.Module):
                 noise = torch.randn_like(x) if skip_steps else None
                 x = self._shallow_init(eng, x, original_mel is not None, skip_steps, noise, st)
         B, M, T = x.shape
+        if (B, M, T) != (cond.shape[0], self.mel_bins, cond.shape[2]):
+            raise ValueError(f"x_T {tuple(x.shape)} does not match features {tuple(features.shape)} / mel_channels {self.mel_bins}")
 
         kind, table = schedule.sampler_table(noise_predictor, interval=sampler_interval, skip_steps=skip_steps,
                                              **self._sched)
@@ -169,13 +219,13 @@ class GaussianDiffusion(nn.Module):
                 raise ValueError(f"step_noise must be {(n_rows, B, M, T)}, got {tuple(step_noise.shape)}")
         xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if step_noise is None else 0
-        lens = None
         if lengths is not None:
             if x_masks is not None or cond_masks is not None:
                 raise ValueError("lengths (exact-ragged batches) and x_masks / cond_masks (the reference's padded-batch semantics) are exclusive")
-            lens = np.ascontiguousarray([int(v) for v in (lengths.tolist() if torch.is_tensor(lengths) else lengths)], dtype=np.int32)
-            if lens.shape != (B,) or lens.min() < 1 or lens.max() > T:
-                raise ValueError(f"lengths must be {B} values in [1, {T}], got {lens.tolist()}")
+            lens = [int(v) for v in (lengths.tolist() if torch.is_tensor(lengths) else lengths)]
+            if len(lens) != B or min(lens) < 1 or max(lens) > T:
+                raise ValueError(f"lengths must be {B} values in [1, {T}], got {lens}")
+            return self._forward_ragged(eng, cond, x, lens, kind, table, step_noise, seed, st)
 
         mel = torch.empty((B, T, M), device=device, dtype=torch.float32)
         smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
@@ -199,12 +249,8 @@ class GaussianDiffusion(nn.Module):
                 elif step_noise is not None and chunk != n_rows:
                     sn = step_noise[r0:r1]
                 tab = table[r0:r1]
-                if lens is not None:
-                    _lib.check(_lib.lib().fdx_sampler_run_ragged(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x), _lib.ptr(sn),
-                                                                 seed + r0, C.c_void_p(lens.ctypes.data), st), eng.h)
-                else:
-                    _lib.check(_lib.lib().fdx_sampler_run(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x),
-                                                          _lib.ptr(sn), seed + r0, _lib.ptr(xm), st), eng.h)
+                _lib.check(_lib.lib().fdx_sampler_run(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x),
+                                                      _lib.ptr(sn), seed + r0, _lib.ptr(xm), st), eng.h)
             _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x), B, M, T, C.c_void_p(smin.data_ptr()),
                                                   C.c_void_p(smax.data_ptr()), smin.numel(), _lib.ptr(mel), st), eng.h)
         return mel

@@ -46,12 +46,13 @@ def _eff(b: int) -> float:
     return _BATCH_EFF[-1][1]
 
 
-def make_batches(lengths: Sequence[int], max_batch: int, max_pad_ratio: Optional[float] = None) -> List[List[int]]:
+def make_batches(lengths: Sequence[int], max_batch: int, max_pad_ratio: Optional[float] = None, padding_free: bool = False) -> List[List[int]]:
     """Group utterance indices (given in ANY order) into micro-batches of at most `max_batch`, each padded to its longest
     member.  Utterances are sorted longest-first and cut into consecutive groups; the cut minimises the modelled time
     sum(len(group) * longest(group) / eff(len(group))) by dynamic programming (padding wastes frames, small batches waste the
     chip).  `max_pad_ratio`, when given, additionally forbids padding any member by more than that fraction of the group's
-    longest (the plain greedy rule)."""
+    longest (the plain greedy rule).  `padding_free`: the batch runs in exact-ragged mode, where padding costs no arithmetic (the
+    group's cost is the sum of its members' own lengths): fuller batches always win."""
     order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
     n = len(order)
     if n == 0:
@@ -64,7 +65,7 @@ def make_batches(lengths: Sequence[int], max_batch: int, max_pad_ratio: Optional
         for i in range(max(0, j - max_batch), j):          # group = order[i:j], longest = L[i]
             if max_pad_ratio is not None and L[j - 1] < (1.0 - max_pad_ratio) * L[i]:
                 continue
-            c = best[i] + (j - i) * L[i] / _eff(j - i)
+            c = best[i] + (sum(L[i:j]) if padding_free else (j - i) * L[i]) / _eff(j - i)
             if c < best[j] - 1e-9:
                 best[j], cut[j] = c, i
     batches: List[List[int]] = []
@@ -104,7 +105,7 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
         den = getattr(diffusion, "denoise_fn", None)
         exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") == "fp32"
     out = []
-    for group in make_batches([lengths[i] for i in mine], max_batch):
+    for group in make_batches([lengths[i] for i in mine], max_batch, padding_free=bool(exact)):
         idx = [mine[g] for g in group]
         T = max(lengths[i] for i in idx)
         if bucket and bucket > 1:

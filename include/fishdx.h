@@ -178,15 +178,16 @@ enum { FDX_SAMPLER_NAIVE = 0, FDX_SAMPLER_UNIPC = 1, FDX_SAMPLER_PLMS = 2 };
  * x_mask as in fdx_wavenet_forward.  fdx_wavenet_prepare must have been called for this batch. */
 int fdx_sampler_run(fdx_handle h, int kind, const float* host_table, int n_rows, float* x,
                     const float* step_noise, uint64_t seed, const uint8_t* x_mask, fdx_stream s);
-/* The same sampler run over an EXACT-RAGGED batch: item b has host_lens[b] <= T valid frames (the geometry fdx_wavenet_prepare was
- * given is the padded one).  Every item is computed exactly as if it ran alone at its own length -- bit for bit: the denoiser treats
- * frames from an item's length on as non-existent (the dilated conv reads zeros there, like its own zero padding), and workgroup
- * tiles that lie wholly beyond an item's length are skipped.  This is what a serving loop wants from a padded batch; the
- * reference's own batched semantics (x_masks / cond_masks: the padded tail stays "alive" inside the receptive field,
- * wavenet.py:217-221,233-234) remain available through fdx_sampler_run + x_mask.  x beyond an item's length is left undefined.
- * WaveNet denoiser, fp32 kernels only.  The conditioner passed to fdx_wavenet_prepare may hold anything beyond an item's length. */
+/* The same sampler run in EXACT-MASK mode: frames with x_mask != 0 (dev [B][T] bytes) are treated as NON-EXISTENT -- the dilated convs
+ * read zeros there at every layer, exactly like their own zero padding -- instead of the reference's masked semantics, where a masked
+ * frame is zeroed at the denoiser's input and output but stays alive in between (wavenet.py:217-221,233-234) and so leaks into the
+ * receptive field of its neighbours.  Consequence: any run of >= 16 masked frames isolates what lies on either side of it, bit for
+ * bit.  That is what lets a serving loop lay a ragged batch out as ONE row -- items separated by 16-frame holes, no padding to a
+ * common length -- and get every item exactly as if it had been run alone (what tools/diffusion/inference.py:336-376 computes
+ * one segment at a time); fish_diffusion_amd.GaussianDiffusion(..., lengths=) does that.  x at masked frames is left undefined.
+ * WaveNet denoiser, fp32 kernels only. */
 int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* host_table, int n_rows, float* x, const float* step_noise,
-                           uint64_t seed, const int* host_lens, fdx_stream s);
+                           uint64_t seed, const uint8_t* x_mask, fdx_stream s);
 /* The start of shallow diffusion, diffusion.py:223-232: out = q_sample(norm_spec(src), t, noise).
  *   normalise != 0: v = (src - spec_min) / (spec_max - spec_min) * 2 - 1 (diffusion.py:315-316).  spec_min/max are host arrays of
  *   n_spec floats; the reference's [1,1,n] buffers broadcast against the LAST axis of the [B,M,T] tensor, so n_spec is 1 or T.

@@ -804,7 +804,7 @@ def test_segment_loop_of_the_caller_extractor_frames_to_pasted_waveform(dev):
     f0[1][:] = 0.0                                                   # all-unvoiced segment: stays silent (:108-109)
     spk = torch.tensor([3])
     mel_lens = [(min(e, total) - s) // 512 for s, e in segs]      # audio[start:end] clips at the end of the audio (inference.py:355,104)
-    x_all = torch.randn(4, 128, max(mel_lens), generator=g)
+    x_all = torch.randn(4, 128, 64, generator=g)                      # (64 = the padded length of the batched run)
     ri_all = torch.rand(4, 9, generator=g)
     ri_all[:, 0] = 0
     sn_all = torch.randn(4, max(mel_lens) * 512, 9, generator=g)

@@ -336,7 +336,7 @@ dist.destroy_process_group()
 def test_every_conv_tile_shape_is_bit_identical_to_the_64x64_tile(dev):
     """convgemm16s.hip.h: the workgroup tile of the dilated conv + gate (NR 16-row blocks x NM*16 columns) is a scheduling choice --
     every output element is the same k-ordered fp32 fma chain over the same four K ranges.  Each of the nine non-default shapes,
-    forced through FDX_CONV_SHAPE in its own process, must reproduce the fixed 64 x 64 tile's result BIT FOR BIT on ragged
+    forced through FDX_CONV_SHAPE in its own process, must reproduce the fixed 64 x 64 tile's ("44": the round-1 kernel) result BIT FOR BIT on ragged
     geometries (tile overhang, T < one tile, odd T, batch > 1, masks), and the automatic choice must as well."""
     code = r'''
 import os, sys, hashlib, torch
@@ -363,7 +363,7 @@ for B, T in ((1, 1), (1, 37), (2, 113), (1, 257), (3, 430), (1, 861)):
 print("DIGEST", h.hexdigest())
 ''' % ROOT
     digests = {}
-    for shape in ("0", "auto", "45", "46", "47", "48", "24", "25", "26", "27", "28"):
+    for shape in ("44", "auto", "45", "46", "47", "48", "24", "25", "26", "27", "28"):
         env = dict(os.environ)
         env.pop("FDX_CONV_SHAPE", None)
         if shape != "auto":
