@@ -172,35 +172,49 @@ def test_wavenet_bf16_storage_mode(dev):
             out = net(x.to(dev), t.to(dev), cond.to(dev), x_masks=xm.to(dev), cond_masks=xm.to(dev)).cpu()
             net.storage = "fp32"
             again = net(x.to(dev), t.to(dev), cond.to(dev), x_masks=xm.to(dev), cond_masks=xm.to(dev)).cpu()
-            e_model, e_ref = rel_err(out, model), rel_err(out, ref32)
-            print(f"bf16 storage, C={cfg['residual_channels']} B={B} T={T}: vs bf16 model {e_model:.2e}, vs fp32 reference {e_ref:.2e}")
-            # An operand that sits on a bf16 rounding boundary may round the other way after a different fp32 summation order;
-            # every flip is a 2^-8-relative change of ONE operand element (a few hundred per call at these sizes), so the model
-            # is matched to ~1e-3, not to fp32 noise -- still closer than the fp32 arithmetic is, and nowhere near what a layout
-            # or packing error would give (O(1)).
-            assert e_model < 1e-2 and e_model < e_ref
-            assert e_ref < 5e-2
+            e_model, e_ref, e_floor = rel_err(out, model), rel_err(out, ref32), rel_err(model, ref32)
+            print(f"bf16 storage, C={cfg['residual_channels']} B={B} T={T}: HIP vs bf16 model {e_model:.2e}, HIP vs fp32 reference {e_ref:.2e}, "
+                  f"bf16 model vs fp32 reference {e_floor:.2e}")
+            # The bound is derived, not picked: `e_floor` is what rounding these weights / operands to bf16 costs in exact arithmetic
+            # order (the CPU model).  An operand that sits on a bf16 rounding boundary may round the other way after a different fp32
+            # summation order -- each flip is one 2^-8-relative change of one operand element -- so HIP and the model differ by a
+            # fraction of the rounding cost itself (measured: 0.35x - 0.98x of it), bounded here by 1.25x; and HIP's distance from the fp32 reference stays within
+            # twice the model's.  A layout or packing error gives O(1), nowhere near either bound.
+            assert e_model <= 1.25 * e_floor and e_ref <= 2.0 * e_floor, (e_model, e_ref, e_floor)
             assert torch.equal(again, fp32) and rel_err(fp32, ref32) < 2e-5
 
 
 def test_bf16_storage_mode_under_the_sampler(dev):
     """The opt-in mode through GaussianDiffusion (recorded graphs are keyed on it): UniPC / PLMS with masks and a geometry change;
-    the mel stays bf16-close to the fp32 path's and switching back reproduces fp32 bit for bit."""
+    switching back reproduces fp32 bit for bit, and the mel's distance from the fp32 path's is bounded by what the CPU model of the
+    same rounding policy (oracle/wavenet_ref.bf16_storage_model driving the oracle sampler) loses against the fp32 oracle -- within
+    a factor 2 -- instead of by a hand-picked constant."""
+    from oracle import sampler_ref, wavenet_ref
     sd = wavenet_sd(WN_SMALL, 101)
     diff = _diffusion(WN_SMALL, sd, dev)
+    sdb, rb = wavenet_ref.bf16_storage_model(sd)
+    kwn = dict(residual_layers=WN_SMALL["residual_layers"], dilation_cycle=WN_SMALL["dilation_cycle"])
+    den32 = _oracle_den(sd, WN_SMALL)
+    den16 = lambda x, t, c, xm, cm: wavenet_ref.wavenet_forward(sdb, x, t, c, xm, cm, operand_round=rb, **kwn)   # noqa: E731
     g = torch.Generator().manual_seed(17)
     for B, T, pred in ((2, 45, "unipc"), (1, 130, "plms"), (2, 45, "unipc")):
-        feats, x0 = torch.randn(B, T, 256, generator=g).to(dev), torch.randn(B, 128, T, generator=g).to(dev)
-        m = torch.zeros(B, T, dtype=torch.bool, device=dev)
+        feats, x0 = torch.randn(B, T, 256, generator=g), torch.randn(B, 128, T, generator=g)
+        m = torch.zeros(B, T, dtype=torch.bool)
         m[-1, T - 9:] = True
-        kw = dict(sampler_interval=50, noise_predictor=pred, x_masks=m, cond_masks=m, x_init=x0)
-        a = diff(feats, **kw)
+        with torch.no_grad():
+            o32 = sampler_ref.diffusion_sample(den32, feats, x_init=x0, sampler_interval=50, predictor=pred, x_masks=m, cond_masks=m)
+            o16 = sampler_ref.diffusion_sample(den16, feats, x_init=x0, sampler_interval=50, predictor=pred, x_masks=m, cond_masks=m)
+        e_floor = rel_err(o16, o32)
+        kw = dict(sampler_interval=50, noise_predictor=pred, x_masks=m.to(dev), cond_masks=m.to(dev), x_init=x0.to(dev))
+        a = diff(feats.to(dev), **kw)
         diff.denoise_fn.storage = "bf16"
-        b1, b2 = diff(feats, **kw), diff(feats, **kw)            # second run replays the recorded graph
+        b1, b2 = diff(feats.to(dev), **kw), diff(feats.to(dev), **kw)            # second run replays the recorded graph
         diff.denoise_fn.storage = "fp32"
-        a2 = diff(feats, **kw)
+        a2 = diff(feats.to(dev), **kw)
         assert torch.equal(a, a2) and torch.equal(b1, b2)
-        assert torch.isfinite(b1).all() and 0 < rel_err(b1.cpu(), a.cpu()) < 3e-2, (B, T, pred)
+        e = rel_err(b1.cpu(), a.cpu())
+        print(f"bf16 under {pred} (B={B}, T={T}): HIP bf16 vs HIP fp32 {e:.2e}; CPU bf16 model vs fp32 oracle {e_floor:.2e}")
+        assert torch.isfinite(b1).all() and 0 < e <= 2.0 * e_floor, (B, T, pred, e, e_floor)
 
 
 def test_wavenet_ragged_lengths_vs_oracle(dev):
