@@ -128,6 +128,8 @@ struct fdx_ctx {
   int outp_shape_nr = 0, outp_shape_nm = 0;   // 0: the 32x32x2 kernel
   const void* wn_arena_bf16 = nullptr;   // opt-in bf16 storage mode: residual-block weights as bf16 fragments (wavenet.hip)
   fdx::DevBuf Yb, Zb;                    // ... and the two GEMM operands in C8-blocked bf16
+  fdx::DevBuf wn_bf16_lds;               // the same bf16 weights in the LDS-tiled kernels' order (bf16lds.hip.h), derived at bf16 attach
+  bool wn_bf16_lds_ok = false;
   int bf16_B = 0, bf16_T = 0;            // geometry Yb / Zb were last zeroed for
   bool cond_masked = false; int condraw_ld = 0;
   fdx::DevBuf tdev, E, Hm, S0, S;      // step-embedding pipeline; ldn below

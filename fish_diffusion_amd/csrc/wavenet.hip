@@ -15,6 +15,7 @@
 #include "common.hip.h"
 #include "elementwise.hip.h"
 #include "convgemm16s.hip.h"
+#include "bf16lds.hip.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -47,6 +48,13 @@ static int conv_shape_env() {
   return v;
 }
 static bool shapes_enabled() { return conv_shape_env() != 0; }
+// bf16 storage mode: LDS-tiled kernels (bf16lds.hip.h) when a launch has at least this many 128 x 128 tiles; FDX_BF16_LDS=0 disables,
+// FDX_BF16_LDS=<n> sets the threshold
+static long bf16_lds_min_tiles() {
+  static const long v = [] { const char* e = getenv("FDX_BF16_LDS"); return e ? atol(e) : 256L; }();
+  return v;
+}
+static bool bf16_lds_enabled() { return bf16_lds_min_tiles() > 0; }
 static int outp_shape_env() {   // FDX_OUTP_SHAPE=0: always the 32x32x2 kernel; =<NR><NM>: force a 16x16x4 shape
   static const int v = [] { const char* e = getenv("FDX_OUTP_SHAPE"); return e ? atoi(e) : -1; }();
   return v;
@@ -423,6 +431,25 @@ extern "C" int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev, size_t byt
   h->wn_arena_bf16 = dev;
   h->prepared = false;    // the blocked operand buffers are sized in prepare
   ++h->alloc_gen;         // recorded sampler graphs bake the kernel choice in
+  // the LDS-tiled kernels' A order (bf16lds.hip.h), a permutation of the same 16-byte groups: one-off, default stream, synchronous
+  h->wn_bf16_lds_ok = false;
+  if (dev && h->wd.residual_channels % 64 == 0 && bf16_lds_enabled()) {
+    FDX_HIP(h, hipSetDevice(h->device));
+    WnBf16Layout bl;
+    wn_bf16_layout(h->wd, bl);
+    const int C = h->wd.residual_channels, L = h->wd.residual_layers;
+    FDX_HIP(h, h->wn_bf16_lds.ensure(bl.total16 * 16, false, nullptr));
+    const uint4* src = static_cast<const uint4*>(dev);
+    uint4* dst = static_cast<uint4*>(h->wn_bf16_lds.p);
+    for (int i = 0; i < L; ++i) {
+      const size_t nc = (size_t)(C / 64) * (C / 32) * 3 * 512, no = (size_t)(2 * C / 128) * (C / 32) * 512;
+      hipLaunchKernelGGL(k_bf16lds_repack, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, nullptr, dst + bl.conv[i], src + bl.conv[i], C / 64, C / 32, 3);
+      hipLaunchKernelGGL(k_bf16lds_repack, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, nullptr, dst + bl.outp[i], src + bl.outp[i], 2 * C / 128, C / 32, 1);
+    }
+    FDX_HIP(h, hipGetLastError());
+    FDX_HIP(h, hipStreamSynchronize(nullptr));
+    h->wn_bf16_lds_ok = true;
+  }
   return FDX_OK;
 }
 
@@ -625,6 +652,17 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       __bf16* Yb = reinterpret_cast<__bf16*>(h->Yb.p) + (size_t)kHalo * 8;
       __bf16* Zb = reinterpret_cast<__bf16*>(h->Zb.p) + (size_t)kHalo * 8;
       const long bsB = (long)C * ld;               // bf16 elements per item
+      if (h->wn_bf16_lds_ok && (long)B * ((T + 127) / 128) * (C / 64) >= bf16_lds_min_tiles()) {   // large column counts: LDS-tiled
+        const uint4* WL = static_cast<const uint4*>(h->wn_bf16_lds.p);
+        const uint4* Yg = reinterpret_cast<const uint4*>(Yb);
+        const uint4* Zg = reinterpret_cast<const uint4*>(Zb);
+        BfEpiGate eg{Pl, p_bs, ld, Zb, bsB, ld, C};
+        FDX_HIP(h, launch_bf16lds(WL + bl.conv[i], Yg, bsB / 8, ld, C, dil, B, T, 2 * C, eg, s, ev0, ev1));
+        BfEpiResSkip er{X, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, (i + 1 < L) ? Yb : nullptr, bsB, C, skip_mode, sqrtL,
+                        (float)(1.0 / (double)sqrtL)};
+        FDX_HIP(h, launch_bf16lds(WL + bl.outp[i], Zg, bsB / 8, ld, C, 0, B, T, 2 * C, er, s, eo0, eo1));
+        continue;
+      }
       EpiGateB g{};
       g.out = Z; g.o_bs = bsC; g.ldo = ld; g.P = Pl; g.p_bs = p_bs; g.ldp = ld; g.C = C;
       g.outb = Zb; g.ob_bs = bsB;

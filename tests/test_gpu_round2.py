@@ -537,3 +537,16 @@ def test_bf16_storage_error_table_full_size_net(dev):
         json.dump(out, f, indent=1)
     assert rows[0]["max_rel_of_peak"] < 1e-3                      # 100-step UniPC: inside the mel bar on this net (no margin claimed)
     assert rows[1]["max_rel_of_peak"] < 2e-2 and rows[1]["rms_rel_of_peak"] < 2e-3   # 1000-step DDPM: bf16-class, as SURVEY F4 predicted
+
+
+# ------------------------------------------------------------------------------------------------ bf16 mode: LDS-tiled kernels
+def test_bf16_lds_tiled_kernels_hold_the_same_bounds(dev):
+    """csrc/bf16lds.hip.h (128 x 128 tiles, operands staged through LDS, the conv's three taps reading one staged window) is what the
+    opt-in bf16 mode runs at large column counts (BASELINE configs[4]).  FDX_BF16_LDS=1 forces it for every geometry: the bf16 tests of
+    tests/test_gpu_parity.py -- agreement with the CPU model of the rounding policy, bounded by that model's own rounding cost; the
+    sampler runs; bit-identical fp32 results after switching back -- must hold unchanged (small / full net, ragged T, masks, batch 2)."""
+    env = dict(os.environ, FDX_BF16_LDS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-s", "-k", "bf16"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

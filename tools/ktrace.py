@@ -17,14 +17,16 @@ from fish_diffusion_amd import DENOISERS, _lib  # noqa: E402
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 LAYERS = int(sys.argv[2]) if len(sys.argv) > 2 else 20      # fewer layers: do the weights (11 MB per layer) stay in the Infinity Cache?
+STORAGE = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 T = 861
 net = DENOISERS.build(dict(type="WaveNetDenoiser", mel_channels=128, d_encoder=256, residual_channels=512, residual_layers=LAYERS,
                            dilation_cycle=4, use_linear_bias=True)).to(dev)
+net.storage = STORAGE
 x, cond, t = torch.randn(B, 128, T, device=dev), torch.randn(B, 256, T, device=dev), torch.tensor([500.0], device=dev)
 for _ in range(6):
     net(x, t, cond)
 torch.cuda.synchronize()
-CAP, NL = 256 * B, 64
+CAP, NL = 256 * max(B, 4), 12 if B > 4 else 64
 buf = torch.zeros(NL * CAP * 32, dtype=torch.int64, device=dev)
 lib = _lib.lib()
 lib.fdx_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int]
