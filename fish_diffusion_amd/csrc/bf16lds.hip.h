@@ -20,6 +20,7 @@
 #pragma once
 #include "convgemm.hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace fdx {
 
@@ -36,7 +37,6 @@ struct BfArgs {
 #endif
 };
 
-constexpr int kBfWin = 128 + 16;   // staged columns per block: tile + 8 either side (dilation <= 8)
 
 // ---- epilogues: called once per (row block pair | row block, column block) with the wave's accumulators
 struct BfEpiGate {     // wavenet.py:112-115; Z out as blocked bf16 (the out-projection's operand)
@@ -57,19 +57,31 @@ struct BfEpiResSkip {  // wavenet.py:117-120 + the skip sum of :228; Y = x + ste
   float inv_div, r_inv_div;
 };
 
-template <class Epi, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void bf16lds_kernel(BfArgs a, Epi epi) {
-  constexpr int TAPS = Epi::kTaps;
+typedef __attribute__((address_space(3))) void* bf_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* bf_glb_ptr_t;
+
+// WN = waves along the columns (2: 128 x 128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU; 4: 128 x 256 tile, 8 waves, 3 LDS
+// stages, 1 workgroup per CU).  The conv's weight slab (3 taps) is 2.7x its activation window, so the tile grows along the columns:
+// bytes staged per MFMA drop by 37 % and the third stage lets a block's DMA run two blocks ahead.
+template <int WN> struct BfGeom {
+  static constexpr int kWaves = 2 * WN, kThreads = 64 * kWaves, kCols = 64 * WN, kWin = kCols + 16, kStages = WN == 4 ? 3 : 2;
+  static constexpr int kBG = 4 * kWin, kBPieces = kBG / 64;                  // B window per block, in 16-byte groups / 1-KiB pieces
+  static_assert(kBG % 64 == 0 && kBPieces == 2 * kWaves + 1, "wave 0 stages three B pieces, the others two");
+};
+
+template <class Epi, int WN, int DBG = 0>
+__global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds_kernel(BfArgs a, Epi epi) {
+  using Ge = BfGeom<WN>;
+  constexpr int TAPS = Epi::kTaps, NW = Ge::kWaves, WIN = Ge::kWin, NST = Ge::kStages;
   constexpr int A_G = TAPS * 2 * 2 * 128;           // 16-byte groups of A per block
-  constexpr int B_G = 4 * kBfWin;                   // ... of B
-  constexpr int A_LD = A_G / 256;                   // A loads per thread per block
-  constexpr int B_LD = (B_G + 255) / 256;
-  constexpr int B_GP = B_LD * 256;                  // B region padded to whole passes: every thread loads and stores unconditionally
-  __shared__ uint4 lds[2][A_G + B_GP];
+  constexpr int A_LD = A_G / (64 * NW);             // A pieces per wave per block
+  constexpr int STAGE_G = A_G + Ge::kBG;
+  static_assert(A_G % (64 * NW) == 0, "whole A pieces per wave");
+  __shared__ uint4 lds[NST * STAGE_G];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int g = lane >> 5, i = lane & 31;
 
   // ---- tile -> XCD map: 2 row groups x 4 column groups when the counts divide (each XCD keeps its weight group L2-resident and
@@ -88,10 +100,10 @@ __global__ __launch_bounds__(256, 2) void bf16lds_kernel(BfArgs a, Epi epi) {
     nt = L - mt * a.n_tiles_n;
   }
   const int item = nt / a.tiles_per_item;
-  const int t0 = (nt - item * a.tiles_per_item) * 128;
+  const int t0 = (nt - item * a.tiles_per_item) * Ge::kCols;
 
-  const uint4* Ag = a.Wp + (size_t)((DBG & 16) ? 0 : mt) * a.n_blk * A_G;
-  const uint4* Bg = (DBG & 16) ? a.Xb - 8 : a.Xb + item * a.x_bs + (t0 - 8);
+  const uint4* Ag = a.Wp + (size_t)mt * a.n_blk * A_G;
+  const uint4* Bg = a.Xb + item * a.x_bs + (t0 - 8);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -101,97 +113,110 @@ __global__ __launch_bounds__(256, 2) void bf16lds_kernel(BfArgs a, Epi epi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][nb][r] = 0.f;
 
-  // Staging registers: two sets of named scalars (hipcc routes register ARRAYS filled by loads through scratch memory here, and
-  // conditional loads serialise load -> wait -> ds_write: 7 k cycles per block instead of the ~1 k the MFMAs need).  Every thread
-  // loads and stores unconditionally; a thread past the end of the B window re-loads its last group into the padded LDS tail.
-  // Two sets = a prefetch distance of two blocks: one block's MFMAs (~0.8-1.5 k cycles) do not cover an HBM miss.
-  static_assert((A_LD == 6 || A_LD == 2) && B_LD == 3, "staging code below is written out for these counts");
-#define BF_DECL(S) uint4 ra0##S, ra1##S, ra2##S = uint4{0u, 0u, 0u, 0u}, ra3##S = ra2##S, ra4##S = ra2##S, ra5##S = ra2##S, rb0##S, rb1##S, rb2##S
-  BF_DECL(P);
-  BF_DECL(Q);
+  // ---- staging: global -> LDS directly (global_load_lds_dwordx4: one wave-instruction lands 1 KiB at a wave-uniform LDS base +
+  // lane * 16, which is exactly the linear image both operands have here).  No staging registers and no ds_write pass: through
+  // registers the ds_write_b128s alone were 10.8 k of the K loop's 42.6 k cycles (13 cycles of the CU's VGPR -> LDS path each).
   auto boff = [&](int k) {
-    const int e = min(k * 256 + tid, B_G - 1);
-    const int row = e / kBfWin, col = e - row * kBfWin;
+    const int e = min((k * NW + wave) * 64 + lane, Ge::kBG - 1);
+    const int row = e / WIN, col = e - row * WIN;
     return (size_t)row * a.ld + col;
   };
   const size_t bo0 = boff(0), bo1 = boff(1), bo2 = boff(2);
   const size_t b_blk = (size_t)4 * a.ld;
-  const int last = a.n_blk - 1;
-#define BF_GLOAD(S, blk_)                                                 \
-  do {                                                                    \
-    const int bk_ = min((blk_), last);   /* past the end: re-load the last block (unconditional, unused) */ \
-    const uint4* pa_ = Ag + (size_t)bk_ * A_G + tid;                      \
-    ra0##S = pa_[0]; ra1##S = pa_[256];                                   \
-    if constexpr (A_LD == 6) { ra2##S = pa_[512]; ra3##S = pa_[768]; ra4##S = pa_[1024]; ra5##S = pa_[1280]; } \
-    const uint4* pb_ = Bg + (size_t)bk_ * b_blk;                          \
-    rb0##S = pb_[bo0]; rb1##S = pb_[bo1]; rb2##S = pb_[bo2];              \
-  } while (0)
-#define BF_LSTORE(S, buf_)                                                \
-  do {                                                                    \
-    uint4* l_ = lds[buf_] + tid;                                          \
-    l_[0] = ra0##S; l_[256] = ra1##S;                                     \
-    if constexpr (A_LD == 6) { l_[512] = ra2##S; l_[768] = ra3##S; l_[1024] = ra4##S; l_[1280] = ra5##S; } \
-    l_[A_G] = rb0##S; l_[A_G + 256] = rb1##S; l_[A_G + 512] = rb2##S;     \
-  } while (0)
-  auto compute = [&](int buf) {
-    const uint4* la = lds[buf];
-    const uint4* lb = lds[buf] + A_G;
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+  constexpr int NP = A_LD + 3;                      // DMA pieces per wave per block (the last one on wave 0 only)
+  auto piece = [&](int q, int bk, int st) {
+    uint4* l = lds + st * STAGE_G + wave * 64;
+    const uint4* pb = Bg + (size_t)bk * b_blk;
+    if (q < A_LD) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(Ag + (size_t)bk * A_G + tid + q * NW * 64), (bf_lds_ptr_t)(l + q * NW * 64), 16, 0, 0);
+    else if (q == A_LD) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(pb + bo0), (bf_lds_ptr_t)(l + A_G), 16, 0, 0);
+    else if (q == A_LD + 1) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(pb + bo1), (bf_lds_ptr_t)(l + A_G + NW * 64), 16, 0, 0);
+    else if (wave == 0) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(pb + bo2), (bf_lds_ptr_t)(l + A_G + 2 * NW * 64), 16, 0, 0);
+  };
+  // The DMA is waited for by hand: __syncthreads() would drain it (vmcnt(0)) at every barrier; with three stages the newest block
+  // stays in flight across the barrier (its pieces: A_LD + 2, + 1 on wave 0).
+  auto wait_landed = [&](bool newest_in_flight) {
+    if (NST == 3 && newest_in_flight) {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + 3) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + 2) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // One block's MFMAs, with the DMA of block bk2 (into stage st2) issued a piece or two per MFMA step: an LDS-DMA piece costs its
+  // wave 60-180 issue cycles, which hide behind the previous step's MFMAs (asynchronous: 128 pipe cycles per step) but not when
+  // all of a block's pieces are issued back to back in front of them (measured: +10 k cycles on a 29.5 k K loop).
+  // The fragment reads are software-pipelined by hand too (step j+1's four ds_read_b128 before step j's four MFMAs): left to itself
+  // hipcc re-uses ONE fragment register set, so every step waits out the LDS latency.
+  auto compute = [&](int st, int bk2, int st2) {
+    const uint4* la = lds + st * STAGE_G + wr * 64 + i + g * 128;
+    const uint4* lb = lds + st * STAGE_G + A_G + g * WIN + wc * 64 + i;
+    constexpr int NS = TAPS * 2;
+    constexpr int SPREAD = NST == 3 ? NS : (NS + 1) / 2;      // two stages: the pieces must land before this block's barrier
+    bf16x8 fa[2][2], fb[2][2];
+    auto frag = [&](int j, int set) {
+      const int tap = j >> 1, s2 = j & 1;
       const int shift = TAPS == 3 ? 8 + (tap - 1) * a.dil : 8;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 fa[2], fb[2];
+      for (int x = 0; x < 2; ++x) fa[set][x] = __builtin_bit_cast(bf16x8, la[(tap * 2 + s2) * 256 + x * 32]);
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          const uint4 v = la[((tap * 2 + s) * 2 + g) * 128 + wr * 64 + x * 32 + i];
-          fa[x] = __builtin_bit_cast(bf16x8, v);
-        }
+      for (int nb = 0; nb < 2; ++nb) fb[set][nb] = __builtin_bit_cast(bf16x8, lb[2 * s2 * WIN + shift + nb * 32]);
+    };
+    if (!(DBG & 4)) frag(0, 0);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const uint4 v = lb[(2 * s + g) * kBfWin + shift + wc * 64 + nb * 32 + i];
-          fb[nb] = __builtin_bit_cast(bf16x8, v);
-        }
+    for (int j = 0; j < NS; ++j) {
+      if (!(DBG & 4) && j + 1 < NS) frag(j + 1, (j + 1) & 1);
+      if (!(DBG & 1) && j < SPREAD) {
+#pragma unroll
+        for (int q = j * NP / SPREAD; q < (j + 1) * NP / SPREAD; ++q) piece(q, bk2, st2);
+      }
+      __builtin_amdgcn_sched_barrier(0);            // (pins the order: the scheduler otherwise undoes the pipelining)
+      if (!(DBG & 4)) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[x], fb[nb], acc[x][nb], 0, 0, 0);
+          for (int nb = 0; nb < 2; ++nb)
+            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j & 1][x], fb[j & 1][nb], acc[x][nb], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
+  // ---- K loop over the 32-channel blocks; the stage indices are compile-time constants (unrolled NST-fold) so that the DMA into
+  // one stage and the ds_reads of another are provably disjoint.  Past the last block the DMA re-loads the last block into a stage
+  // nobody reads again: every iteration issues the same number of pieces, so the counted wait holds to the end.
+  const int last = a.n_blk - 1;
   FDX_STAMP(0);
-  BF_GLOAD(P, 0);
-  BF_LSTORE(P, 0);
-  BF_GLOAD(Q, 1);
-  __syncthreads();
+  if (!(DBG & 1)) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) piece(q, 0, 0);
+    if (NST == 3) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) piece(q, min(1, last), 1);
+    }
+  }
+  wait_landed(true);
   FDX_STAMP(1);
-  for (int blk = 0; blk < a.n_blk; blk += 2) {
-    // even block: in LDS buffer 0; set Q holds block blk+1 (in flight since the last half-iteration); block blk+2 -> set P
-    BF_GLOAD(P, blk + 2);
-    __builtin_amdgcn_sched_barrier(0);              // (left alone, hipcc sinks the loads below the MFMAs, right in front of their use)
-    if (!(DBG & 4)) compute(0);
-    __builtin_amdgcn_sched_barrier(0);
-    BF_LSTORE(Q, 1);
-    __syncthreads();
+  auto body = [&](auto S_, int blk) {
+    constexpr int S = decltype(S_)::value;
+    compute(S, min(blk + NST - 1, last), (S + NST - 1) % NST);
+    wait_landed(true);
+  };
+  for (int blk = 0; blk < a.n_blk; blk += NST) {
+    body(std::integral_constant<int, 0>{}, blk);
+    if (blk + 1 < a.n_blk) body(std::integral_constant<int, 1>{}, blk + 1);
 #ifdef FDX_KTRACE
-    if (blk == 2) FDX_STAMP(3);
+    if (blk == 0) FDX_STAMP(3);
 #endif
-    // odd block: in LDS buffer 1; block blk+3 -> set Q
-    BF_GLOAD(Q, blk + 3);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & 4) && blk + 1 < a.n_blk) compute(1);
-    __builtin_amdgcn_sched_barrier(0);
-    BF_LSTORE(P, 0);
-    __syncthreads();
+    if (NST == 3 && blk + 2 < a.n_blk) body(std::integral_constant<int, NST - 1>{}, blk + 2);
 #ifdef FDX_KTRACE
-    if (blk == 2) FDX_STAMP(4);
+    if (blk == 0) FDX_STAMP(4);
 #endif
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-loads must have landed before this workgroup's LDS is released
   FDX_STAMP(2);
-#undef BF_DECL
-#undef BF_GLOAD
-#undef BF_LSTORE
 
   // ---------------------------------------------------------------- epilogue
   if (DBG & 8) return;
@@ -269,30 +294,42 @@ __global__ __launch_bounds__(256, 2) void bf16lds_kernel(BfArgs a, Epi epi) {
   FDX_STAMP(5);
 }
 
-template <class Epi>
-inline hipError_t launch_bf16lds(const uint4* Wp, const uint4* Xb, long x_bs, int ld, int C, int dil, int B, int T, int rows, const Epi& epi,
-                                 hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
-  BfArgs a;
-  a.Wp = Wp; a.Xb = Xb; a.x_bs = x_bs; a.ld = ld; a.n_blk = C / 32; a.dil = dil; a.T = T;
-  a.tiles_per_item = (T + 127) / 128;
+template <class Epi, int WN>
+inline hipError_t launch_bf16lds_wn(BfArgs a, int B, int T, const Epi& epi, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  using Ge = BfGeom<WN>;
+  a.tiles_per_item = (T + Ge::kCols - 1) / Ge::kCols;
   a.n_tiles_n = B * a.tiles_per_item;
-  a.n_mtiles = rows / 128;
   const int grid = a.n_tiles_n * a.n_mtiles;
   if (grid <= 0) return hipSuccess;
 #ifdef FDX_KTRACE
   a.trace = nullptr;
   if (g_trace.buf && g_trace.n < g_trace.max_launches && grid <= g_trace.blocks_cap)
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
-#endif
-#ifdef FDX_KTRACE
   static const int dbg = [] { const char* e = getenv("FDX_BF16_DBG"); return e ? atoi(e) : 0; }();
-#define FDX_BF_DBG(D) if (dbg == D) { hipLaunchKernelGGL((bf16lds_kernel<Epi, D>), dim3(grid), dim3(256), 0, s, a, epi); return hipGetLastError(); }
-  FDX_BF_DBG(1) FDX_BF_DBG(2) FDX_BF_DBG(3) FDX_BF_DBG(4) FDX_BF_DBG(7) FDX_BF_DBG(8) FDX_BF_DBG(11) FDX_BF_DBG(12) FDX_BF_DBG(16) FDX_BF_DBG(20) FDX_BF_DBG(28)
+#define FDX_BF_DBG(D) if (dbg == D) { hipLaunchKernelGGL((bf16lds_kernel<Epi, WN, D>), dim3(grid), dim3(Ge::kThreads), 0, s, a, epi); return hipGetLastError(); }
+  FDX_BF_DBG(1) FDX_BF_DBG(4) FDX_BF_DBG(5)
 #undef FDX_BF_DBG
 #endif
-  if (ev0) hipExtLaunchKernelGGL((bf16lds_kernel<Epi>), dim3(grid), dim3(256), 0, s, ev0, ev1, 0, a, epi);
-  else hipLaunchKernelGGL((bf16lds_kernel<Epi>), dim3(grid), dim3(256), 0, s, a, epi);
+  if (ev0) hipExtLaunchKernelGGL((bf16lds_kernel<Epi, WN>), dim3(grid), dim3(Ge::kThreads), 0, s, ev0, ev1, 0, a, epi);
+  else hipLaunchKernelGGL((bf16lds_kernel<Epi, WN>), dim3(grid), dim3(Ge::kThreads), 0, s, a, epi);
   return hipGetLastError();
+}
+
+// FDX_BF16_WN = 2 | 4 forces a tile width (A/B); default: see bf16lds_pick_wn
+inline int bf16lds_pick_wn(int B, int T, int rows) {
+  static const int forced = [] { const char* e = getenv("FDX_BF16_WN"); return e ? atoi(e) : 0; }();
+  if (forced == 2 || forced == 4) return forced;
+  return (long)B * ((T + 255) / 256) * (rows / 128) >= 256 ? 4 : 2;   // the wide tile runs one workgroup per CU: it needs a full round
+}
+
+template <class Epi>
+inline hipError_t launch_bf16lds(const uint4* Wp, const uint4* Xb, long x_bs, int ld, int C, int dil, int B, int T, int rows, const Epi& epi,
+                                 hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  BfArgs a;
+  a.Wp = Wp; a.Xb = Xb; a.x_bs = x_bs; a.ld = ld; a.n_blk = C / 32; a.dil = dil; a.T = T;
+  a.n_mtiles = rows / 128;
+  a.tiles_per_item = a.n_tiles_n = 0;
+  return bf16lds_pick_wn(B, T, rows) == 4 ? launch_bf16lds_wn<Epi, 4>(a, B, T, epi, s, ev0, ev1) : launch_bf16lds_wn<Epi, 2>(a, B, T, epi, s, ev0, ev1);
 }
 
 // The LDS kernel's A order from the register-direct bf16 order (16-byte groups are moved whole):
