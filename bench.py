@@ -446,7 +446,7 @@ def main():
         C_, M_ = WN_CFG["residual_channels"], B * T
         esz = 2 if bf16 else 4
         alg_bytes = esz * (2 * C_ * 3 * C_ + C_ * M_ + C_ * M_) + 4 * 2 * C_ * M_    # weights + Y in + Z out (+ fp32 conditioner slab)
-        kdesc = (("convgemm_kernel<2,splitK,OPK_BF16,EpiGateB> (v_mfma_f32_32x32x16_bf16)" if bf16 else
+        kdesc = (("bf16lds_kernel<BfEpiGate, 4> (v_mfma_f32_32x32x16_bf16; 128 x 256 tile, operands into LDS by DMA, 3 stages)" if bf16 else
                   "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + f": dilated conv k=3 + gate of the residual block at batch {B}")
         traffic_key, traffic_expect = "convgate", {"config": "ddpm1000" + ("_bf16" if bf16 else ""), "batch": B, "frames": T}
 
@@ -478,15 +478,19 @@ def main():
     # ------------------------------------------------------------------------------------------------ outside the timed region
     other = []
     stages = None
-    if cfg in ("headline", "ddpm1000", "sharded") and do_prof and not bf16 and rank == 0:   # the second residual-block kernel, one extra step
+    if cfg in ("headline", "ddpm1000", "sharded") and do_prof and rank == 0:   # the second residual-block kernel, one extra step
         prof_begin(prof_handle(), _lib.PROF_WN_OUTPROJ, stride)
         step(warmup)
         torch.cuda.synchronize()
         n, avg_ms, fl = prof_end(prof_handle())
         if n:
             tr, src = pmc_traffic(cfg, "outproj", traffic_expect)
-            e = roofline_entry("convgemm_kernel<2,splitK,EpiResSkip> (v_mfma_f32_32x32x2_f32): 1x1 out-projection + residual / skip epilogue", n,
+            e = roofline_entry(("bf16lds_kernel<BfEpiResSkip, 4> (v_mfma_f32_32x32x16_bf16; HBM-bound: the fp32 residual stream and skip sum are "
+                                "read and written every layer)" if bf16 else "convgemm_kernel<2,splitK,EpiResSkip> (v_mfma_f32_32x32x2_f32)")
+                               + ": 1x1 out-projection + residual / skip epilogue", n,
                                avg_ms, fl, peak, f"every {stride}th launch of one extra step outside the timed region", tr, src)
+            if bf16:
+                e["bound"] = "hbm"
             other.append(e)
     if cfg == "headline":
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

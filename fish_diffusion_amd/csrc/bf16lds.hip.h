@@ -3,17 +3,25 @@
 //
 // The register-direct kernels (convgemm_kernel<..., OPK_BF16>) stream 4 KB of operands per 4 MFMAs per wave: with the bf16 MFMA 16x
 // faster than the fp32 one that is 128 B/cycle/CU of L1/L2 traffic, and the kernel sits at ~20 % of the 2.5 PFLOP/s roof.  Here a
-// workgroup owns a 128-row x 128-column tile; its operands are staged through LDS ONCE per 32-channel block and shared by the 4 waves
-// (2 x 2, each 64 x 64 = 2 x 2 MFMA blocks of v_mfma_f32_32x32x16_bf16):
+// workgroup owns a 128-row x 128- or 256-column tile; its operands are brought into LDS ONCE per 32-channel block and shared by
+// the 4 / 8 waves (2 x 2 or 2 x 4, each 64 x 64 = 2 x 2 MFMA blocks of v_mfma_f32_32x32x16_bf16):
 //
 //   A (weights)      packed on the device at attach time as [m-tile][block][tap][k16-step][k-group][128 rows] x 16 B: one block is a
 //                    contiguous 8 KB x taps slab, copied linearly global -> LDS; a lane's fragment (row i, 8 consecutive k) is one
 //                    conflict-free ds_read_b128.
 //   B (activations)  C8-blocked bf16 (16-byte group = 8 consecutive channels of one column = a lane's B fragment): per block the
-//                    4 channel-group rows x (128 + 16) columns window is staged once and the conv's THREE TAPS read it at shifted
+//                    4 channel-group rows x (tile + 16) columns window is staged once and the conv's THREE TAPS read it at shifted
 //                    columns -- the dilated-conv window in LDS that north_star asks for; a third of the activation traffic.
-//   double-buffered LDS (2 x 33 KB => 2 workgroups per CU), one barrier per block; the global loads of block k+1 are in flight
-//   while block k's 24 MFMAs per wave run.
+//   staging          LDS-DMA (global_load_lds_dwordx4: both LDS images are linear in the order the lanes address them), 2 stages
+//                    x 33 KB and 2 workgroups per CU (128 columns) or 3 stages x 41 KB and 1 workgroup per CU (256 columns: 37 %
+//                    fewer staged bytes per MFMA, a block's DMA runs two blocks ahead); one barrier per block; the DMA is counted by
+//                    hand (s_waitcnt vmcnt(N)) and issued a piece at a time between the MFMA steps.
+//
+// Measured steps at batch 16 (conv + gate, us per launch, hipExt events): register-direct 75.9 -> LDS tile through staging registers
+// 63.5 (register ARRAYS filled by loads went through scratch memory until they became named scalars: 185) -> loads-first epilogues
+// 59.2 -> LDS-DMA 55.0 -> 256-column tile, 3 stages, pieces spread over the MFMA steps 51.9 -> asm DMA (clean lgkmcnt counting) 51.0
+// = 34 % of the nominal 2.5 PFLOP/s roof; per workgroup 43 k shader cycles of which the MFMAs need 24.6 k (the chip runs this
+// kernel at ~1.7 GHz).  What is left: the epilogue's fp32 conditioner reads (all CUs reach it together: an HBM burst), barrier skew.
 //
 // Paired rows (dilated conv + gate): rows 0..63 of a wave pair = gate rows of 32 channels (wave row wr) + the matching filter rows, so
 // sigmoid(g) * tanh(f) is formed in registers.  Epilogues write the next GEMM's operand directly in the blocked bf16 layout.
@@ -124,13 +132,21 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
   const size_t bo0 = boff(0), bo1 = boff(1), bo2 = boff(2);
   const size_t b_blk = (size_t)4 * a.ld;
   constexpr int NP = A_LD + 3;                      // DMA pieces per wave per block (the last one on wave 0 only)
+  // (inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in flight hipcc stops counting its LDS reads and waits
+  // lgkmcnt(0) in front of every other MFMA step; the asm statement is invisible to its counters -- the DMA is counted by hand below)
+  const unsigned lds0 = (unsigned)(size_t)(bf_lds_ptr_t)lds + (unsigned)wave * 1024u;
+  auto glds16 = [&](const uint4* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
   auto piece = [&](int q, int bk, int st) {
-    uint4* l = lds + st * STAGE_G + wave * 64;
+    const unsigned l = lds0 + (unsigned)st * (STAGE_G * 16);
     const uint4* pb = Bg + (size_t)bk * b_blk;
-    if (q < A_LD) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(Ag + (size_t)bk * A_G + tid + q * NW * 64), (bf_lds_ptr_t)(l + q * NW * 64), 16, 0, 0);
-    else if (q == A_LD) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(pb + bo0), (bf_lds_ptr_t)(l + A_G), 16, 0, 0);
-    else if (q == A_LD + 1) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(pb + bo1), (bf_lds_ptr_t)(l + A_G + NW * 64), 16, 0, 0);
-    else if (wave == 0) __builtin_amdgcn_global_load_lds((bf_glb_ptr_t)(pb + bo2), (bf_lds_ptr_t)(l + A_G + 2 * NW * 64), 16, 0, 0);
+    if (q < A_LD) glds16(Ag + (size_t)bk * A_G + tid + q * NW * 64, l + q * NW * 1024);
+    else if (q == A_LD) glds16(pb + bo0, l + A_G * 16);
+    else if (q == A_LD + 1) glds16(pb + bo1, l + (A_G + NW * 64) * 16);
+    else if (wave == 0) glds16(pb + bo2, l + (A_G + 2 * NW * 64) * 16);
   };
   // The DMA is waited for by hand: __syncthreads() would drain it (vmcnt(0)) at every barrier; with three stages the newest block
   // stays in flight across the barrier (its pieces: A_LD + 2, + 1 on wave 0).
@@ -315,11 +331,14 @@ inline hipError_t launch_bf16lds_wn(BfArgs a, int B, int T, const Epi& epi, hipS
   return hipGetLastError();
 }
 
-// FDX_BF16_WN = 2 | 4 forces a tile width (A/B); default: see bf16lds_pick_wn
+// FDX_BF16_WN = 2 | 4 forces a tile width (A/B).  The wide tile runs one workgroup per CU in lock-step rounds of 256: it is chosen
+// when its rounds are at least 80 % full (measured, 50 steps: batch 8 = one full round 59 vs 63 ms; batch 12 = 1.5 rounds 94 vs 92;
+// batch 16 = two full rounds 286 vs 300 ms per 100 steps).
 inline int bf16lds_pick_wn(int B, int T, int rows) {
   static const int forced = [] { const char* e = getenv("FDX_BF16_WN"); return e ? atoi(e) : 0; }();
   if (forced == 2 || forced == 4) return forced;
-  return (long)B * ((T + 255) / 256) * (rows / 128) >= 256 ? 4 : 2;   // the wide tile runs one workgroup per CU: it needs a full round
+  const long wide = (long)B * ((T + 255) / 256) * (rows / 128), rounds = (wide + 255) / 256;
+  return wide * 5 >= rounds * 256 * 4 ? 4 : 2;
 }
 
 template <class Epi>

@@ -540,12 +540,14 @@ def test_bf16_storage_error_table_full_size_net(dev):
 
 
 # ------------------------------------------------------------------------------------------------ bf16 mode: LDS-tiled kernels
-def test_bf16_lds_tiled_kernels_hold_the_same_bounds(dev):
-    """csrc/bf16lds.hip.h (128 x 128 tiles, operands staged through LDS, the conv's three taps reading one staged window) is what the
-    opt-in bf16 mode runs at large column counts (BASELINE configs[4]).  FDX_BF16_LDS=1 forces it for every geometry: the bf16 tests of
-    tests/test_gpu_parity.py -- agreement with the CPU model of the rounding policy, bounded by that model's own rounding cost; the
-    sampler runs; bit-identical fp32 results after switching back -- must hold unchanged (small / full net, ragged T, masks, batch 2)."""
-    env = dict(os.environ, FDX_BF16_LDS="1")
+@pytest.mark.parametrize("wn", ["2", "4"])
+def test_bf16_lds_tiled_kernels_hold_the_same_bounds(dev, wn):
+    """csrc/bf16lds.hip.h (128 x 128 and 128 x 256 tiles, operands brought into LDS by DMA, the conv's three taps reading one staged
+    window) is what the opt-in bf16 mode runs at large column counts (BASELINE configs[4]).  FDX_BF16_LDS=1 forces it for every
+    geometry and FDX_BF16_WN the tile width: the bf16 tests of tests/test_gpu_parity.py -- agreement with the CPU model of the rounding
+    policy, bounded by that model's own rounding cost; the sampler runs; bit-identical fp32 results after switching back -- must hold
+    unchanged (small / full net, ragged T, masks, batch 2)."""
+    env = dict(os.environ, FDX_BF16_LDS="1", FDX_BF16_WN=wn)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-s", "-k", "bf16"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout[-3000:])

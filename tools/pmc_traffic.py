@@ -33,7 +33,7 @@ def main():
            "note": "bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024",
            "kernels": {}}
     for k in fetch:
-        if "convgemm" not in k:
+        if "convgemm" not in k and "bf16lds" not in k:
             continue
         n, f = fetch[k]
         w = write.get(k, (0, 0.0))[1]
