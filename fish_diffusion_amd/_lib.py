@@ -51,12 +51,14 @@ class RefineGanDesc(C.Structure):
 
 class FeatureTerm(C.Structure):
     _fields_ = [("kind", C.c_int), ("per_frame", C.c_int), ("preproc", C.c_int), ("src_frames", C.c_int), ("values", C.c_void_p),
-                ("w", C.c_void_p), ("b", C.c_void_p), ("p0", C.c_float), ("p1", C.c_float)]
+                ("w", C.c_void_p), ("b", C.c_void_p), ("p0", C.c_float), ("p1", C.c_float),
+                ("neck", C.c_int), ("neck_w", C.c_void_p), ("neck_b", C.c_void_p)]
 
 
 TERM_VECTOR, TERM_EMBEDDING, TERM_SCALAR_LINEAR = 0, 1, 2
 PRE_NONE, PRE_PITCH_TO_SCALE = 0, 1
 MAX_FEATURE_TERMS = 6
+MAX_NECK = 32
 ACT_NONE, ACT_SILU = 0, 1
 
 
@@ -120,6 +122,8 @@ _SIGS = {
                                            C.c_int, _P, _P]),
     "fdx_features_forward_src": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(FeatureTerm),
                                             C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "fdx_features_forward_svs": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P,
+                                            C.POINTER(FeatureTerm), C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "fdx_repeat_expand": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, _P, _P]),
     "fdx_debug_conv1d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, _P, _P]),

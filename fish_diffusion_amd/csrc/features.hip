@@ -28,6 +28,9 @@ struct FeatArgs {
   int B, T, Din, E, n_terms, act, channel_first;
   int S, x_channel_first;                               // contents frames / layout (see fdx_features_forward_src)
   float x_scale;                                        // (float)S / T, the scale F.interpolate(mode="nearest") uses
+  const long long* gather;                              // phones2mel [B][T] or null
+  const uint8_t* gmask;                                 // [B][T]: 1 => gathered text features * 0 (before the terms)
+  int neck; const float* neck_w; const float* neck_b;   // use_neck text encoder: Linear(Din, neck) then w = [E][neck]
   fdx_feature_term terms[FDX_MAX_FEATURE_TERMS];
   float term_scale[FDX_MAX_FEATURE_TERMS];              // (float)src_frames / T per term
 };
@@ -44,21 +47,40 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  for (int c0 = 0; c0 < a.Din; c0 += kTC) {
+  auto src_frame = [&](int t) {
+    if (a.gather) return (int)a.gather[(long)b * a.T + t];
+    return a.S == a.T ? t : nearest_src(t, a.x_scale, a.S);
+  };
+  auto x_at = [&](int ts, int c) { return a.x_channel_first ? a.x[((long)b * a.Din + c) * a.S + ts] : a.x[((long)b * a.S + ts) * a.Din + c]; };
+  // use_neck: the bottleneck activations of this block's frames first (rounded to fp32 like the reference's first Linear), then
+  // the main loop contracts over them instead of over the contents channels
+  __shared__ float hs[kTT][FDX_MAX_NECK + 1];
+  if (a.neck > 0) {
+    for (int idx = tid; idx < kTT * a.neck; idx += 256) {
+      const int r = idx / a.neck, n = idx - r * a.neck, t = t0 + r;
+      float hv = 0.f;
+      if (t < a.T) {
+        const int ts = src_frame(t);
+        for (int c = 0; c < a.Din; ++c) hv += x_at(ts, c) * a.neck_w[(long)n * a.Din + c];
+        if (a.neck_b) hv += a.neck_b[n];
+      }
+      hs[r][n] = hv;
+    }
+    __syncthreads();
+  }
+  const int Dk = a.neck > 0 ? a.neck : a.Din;           // contraction length of the main loop (= row length of a.w)
+  for (int c0 = 0; c0 < Dk; c0 += kTC) {
     for (int i = tid; i < kTT * kTC; i += 256) {
       const int r = i / kTC, c = i - r * kTC;
       const int t = t0 + r;
       float xv = 0.f;
-      if (t < a.T && c0 + c < a.Din) {
-        const int ts = a.S == a.T ? t : nearest_src(t, a.x_scale, a.S);
-        xv = a.x_channel_first ? a.x[((long)b * a.Din + c0 + c) * a.S + ts] : a.x[((long)b * a.S + ts) * a.Din + c0 + c];
-      }
+      if (t < a.T && c0 + c < Dk) xv = a.neck > 0 ? hs[r][c0 + c] : x_at(src_frame(t), c0 + c);
       xs[r][c] = xv;
     }
     for (int i = tid; i < kTE * kTC; i += 256) {
       const int r = i / kTC, c = i - r * kTC;
       const int e = e0 + r;
-      ws[r][c] = (e < a.E && c0 + c < a.Din) ? a.w[(long)e * a.Din + c0 + c] : 0.f;
+      ws[r][c] = (e < a.E && c0 + c < Dk) ? a.w[(long)e * Dk + c0 + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll 8
@@ -77,6 +99,7 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
     if (t >= a.T) continue;
     float v = acc[i];
     if (a.bias) v += a.bias[e];
+    if (a.gmask && a.gmask[(long)b * a.T + t]) v = 0.f;       // gathered features * (1 - mel_mask), diffsinger.py:88-90
     for (int k = 0; k < a.n_terms; ++k) {
       const fdx_feature_term& m = a.terms[k];
       const int Sk = m.src_frames > 0 ? m.src_frames : a.T;
@@ -95,7 +118,17 @@ __global__ __launch_bounds__(256) void k_features(FeatArgs a) {
           s = s < 0.f ? 0.f : s;
           s = s > 1.f ? 1.f : s;
         }
-        float y = m.w[e] * s;
+        float y;
+        if (m.neck > 0) {                         // Linear(1, neck) then Linear(neck, E)
+          y = 0.f;
+          for (int n = 0; n < m.neck; ++n) {
+            float hn = m.neck_w[n] * s;
+            if (m.neck_b) hn += m.neck_b[n];
+            y += m.w[(long)e * m.neck + n] * hn;
+          }
+        } else {
+          y = m.w[e] * s;
+        }
         if (m.b) y += m.b[e];
         v += y;
       }
@@ -145,6 +178,16 @@ extern "C" int fdx_features_forward_src(fdx_handle h, const float* contents, int
                                         int n_terms, int act, const uint8_t* mask, int channel_first, float* features,
                                         fdx_stream st) {
   GenScope gen_scope(h);
+  return fdx_features_forward_svs(h, contents, B, S, contents_channel_first, T, Din, E, w_text, b_text, 0, nullptr, nullptr, nullptr, nullptr,
+                                  terms, n_terms, act, mask, channel_first, features, st);
+}
+
+extern "C" int fdx_features_forward_svs(fdx_handle h, const float* contents, int B, int S, int contents_channel_first, int T, int Din,
+                                        int E, const float* w_text, const float* b_text, int neck, const float* neck_w,
+                                        const float* neck_b, const long long* phones2mel, const uint8_t* gather_mask,
+                                        const fdx_feature_term* terms, int n_terms, int act, const uint8_t* mask, int channel_first,
+                                        float* features, fdx_stream st) {
+  GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
   if (S <= 0) return fail(h, FDX_E_ARG, "fdx_features_forward: contents has no frames");
   if (act != FDX_ACT_NONE && act != FDX_ACT_SILU) return fail(h, FDX_E_ARG, "fdx_features_forward_ex: unknown activation %d", act);
@@ -152,11 +195,14 @@ extern "C" int fdx_features_forward_src(fdx_handle h, const float* contents, int
     return fail(h, FDX_E_ARG, "fdx_features_forward: bad arguments");
   if (n_terms < 0 || n_terms > FDX_MAX_FEATURE_TERMS || (n_terms && !terms))
     return fail(h, FDX_E_ARG, "fdx_features_forward: at most %d additive terms", FDX_MAX_FEATURE_TERMS);
+  if (neck < 0 || neck > FDX_MAX_NECK || (neck > 0 && !neck_w))
+    return fail(h, FDX_E_ARG, "fdx_features_forward_svs: neck size %d (at most %d, with its weights)", neck, FDX_MAX_NECK);
   FeatArgs a{};
   a.x = contents; a.w = w_text; a.bias = b_text; a.out = features;
   a.B = B; a.T = T; a.Din = Din; a.E = E; a.n_terms = n_terms;
   a.act = act; a.mask = mask; a.channel_first = channel_first;
   a.S = S; a.x_channel_first = contents_channel_first; a.x_scale = (float)S / (float)T;
+  a.gather = phones2mel; a.gmask = gather_mask; a.neck = neck; a.neck_w = neck_w; a.neck_b = neck_b;
   for (int k = 0; k < n_terms; ++k) {
     const fdx_feature_term& m = terms[k];
     if (m.kind < FDX_TERM_VECTOR || m.kind > FDX_TERM_SCALAR_LINEAR || !m.values)
@@ -165,6 +211,8 @@ extern "C" int fdx_features_forward_src(fdx_handle h, const float* contents, int
     if (m.kind == FDX_TERM_SCALAR_LINEAR && m.preproc == FDX_PRE_PITCH_TO_SCALE && m.p1 == m.p0)
       return fail(h, FDX_E_ARG, "fdx_features_forward: term %d: f0_max == f0_min", k);
     if (m.src_frames < 0) return fail(h, FDX_E_ARG, "fdx_features_forward: term %d: negative src_frames", k);
+    if (m.neck < 0 || m.neck > FDX_MAX_NECK || (m.neck > 0 && (m.kind != FDX_TERM_SCALAR_LINEAR || !m.neck_w)))
+      return fail(h, FDX_E_ARG, "fdx_features_forward: term %d: bad neck", k);
     a.terms[k] = m;
     a.term_scale[k] = (float)(m.src_frames > 0 ? m.src_frames : T) / (float)T;
   }

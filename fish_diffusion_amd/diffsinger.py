@@ -8,7 +8,7 @@ Mirrors, for inference:
 
 `forward_features` is ONE fused HIP launch (`fdx_features_forward`): text Linear + speaker embedding / mix + pitch
 Linear(pitch_to_scale(f0)) + pitch-shift / energy projections, added in the reference's order.  Encoders this module
-cannot fuse (FastSpeech2 / BERT text encoders, the phones2mel gather of SVS) raise NotImplementedError: they are not
+cannot fuse (FastSpeech2 / BERT text encoders) raise NotImplementedError: they are not
 on this path.
 """
 from __future__ import annotations
@@ -68,23 +68,35 @@ class NaiveProjectionEncoder(nn.Module):
     def __init__(self, input_size, output_size, use_embedding: bool = False, use_neck: bool = False, neck_size: int = 8,
                  preprocessing=None):
         super().__init__()
-        if use_neck and not use_embedding:
-            raise NotImplementedError("NaiveProjectionEncoder(use_neck=True) is not used by any SVC config and is not fused")
         self.use_embedding, self.input_size, self.output_size = use_embedding, input_size, output_size
+        self.use_neck, self.neck_size = bool(use_neck) and not use_embedding, int(neck_size)
         self.preprocessing = preprocessing
         if use_embedding:
             self.embedding = nn.Embedding(input_size, output_size)
             nn.init.normal_(self.embedding.weight, mean=0, std=output_size ** -0.5)
+        elif use_neck:                                  # naive_projection.py:37-41: keys projection.0.* / projection.1.*
+            if not 0 < self.neck_size <= _lib.MAX_NECK:
+                raise ValueError(f"neck_size {neck_size}: the fused front end takes 1..{_lib.MAX_NECK}")
+            self.projection = nn.Sequential(nn.Linear(input_size, self.neck_size), nn.Linear(self.neck_size, output_size))
         else:
             self.projection = nn.Linear(input_size, output_size)
-            nn.init.xavier_uniform_(self.projection.weight)
-            nn.init.constant_(self.projection.bias, 0.0)
+        for m in self.modules():                        # reset_params, :48-55
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0.0)
         self._handle: Optional[_lib.Handle] = None
 
     def _engine(self, device):
         if self._handle is None or self._handle.device != device:
             self._handle = _lib.Handle(device)
         return self._handle
+
+    def linear_params(self):
+        """(w, b, neck, neck_w, neck_b) as fp32 contiguous tensors: the output Linear, and -- use_neck -- the bottleneck Linear."""
+        f = lambda t: t.detach().to(torch.float32).contiguous()   # noqa: E731
+        if self.use_neck:
+            return f(self.projection[1].weight), f(self.projection[1].bias), self.neck_size, f(self.projection[0].weight), f(self.projection[0].bias)
+        return f(self.projection.weight), f(self.projection.bias), 0, None, None
 
     @torch.no_grad()
     def forward(self, x, *args, **kwargs):
@@ -98,11 +110,12 @@ class NaiveProjectionEncoder(nn.Module):
         x2 = x.to(torch.float32).reshape(1, -1, self.input_size).contiguous()
         out = torch.empty((1, x2.shape[1], self.output_size), device=x.device, dtype=torch.float32)
         eng = self._engine(x.device)
-        w, b = self.projection.weight.detach().float().contiguous(), self.projection.bias.detach().float().contiguous()
+        w, b, neck, nw, nb = self.linear_params()
         with eng.lock:
-            _lib.check(_lib.lib().fdx_features_forward(eng.h, _lib.ptr(x2), 1, x2.shape[1], self.input_size, self.output_size,
-                                                       _lib.ptr(w), _lib.ptr(b), None, 0, _lib.ptr(out),
-                                                       _lib.stream_ptr(x.device)), eng.h)
+            _lib.check(_lib.lib().fdx_features_forward_svs(eng.h, _lib.ptr(x2), 1, x2.shape[1], 0, x2.shape[1], self.input_size,
+                                                           self.output_size, _lib.ptr(w), _lib.ptr(b), neck, _lib.ptr(nw) if neck else None,
+                                                           _lib.ptr(nb) if neck else None, None, None, None, 0, _lib.ACT_NONE, None, 0,
+                                                           _lib.ptr(out), _lib.stream_ptr(x.device)), eng.h)
         return out.reshape(*lead, self.output_size)
 
 
@@ -166,10 +179,12 @@ class DiffSinger(nn.Module):
         else:
             raise ValueError(f"scalar feature of shape {tuple(values.shape)} does not match batch {B} x frames {T}")
         v = v.contiguous()
-        w = enc.projection.weight.detach().to(torch.float32).reshape(-1).contiguous()
-        b = enc.projection.bias.detach().to(torch.float32).contiguous()
-        keep += [v, w, b]
-        return _lib.FeatureTerm(_lib.TERM_SCALAR_LINEAR, per_frame, pre, src_frames, v.data_ptr(), w.data_ptr(), b.data_ptr(), F0_MIN, F0_MAX)
+        w, b, neck, nw, nb = enc.linear_params()
+        w = w.reshape(-1) if not neck else w
+        nw = nw.reshape(-1) if neck else None
+        keep += [v, w, b, nw, nb]
+        return _lib.FeatureTerm(_lib.TERM_SCALAR_LINEAR, per_frame, pre, src_frames, v.data_ptr(), w.data_ptr(), b.data_ptr(), F0_MIN, F0_MAX,
+                                neck, nw.data_ptr() if neck else None, nb.data_ptr() if neck else None)
 
     @torch.no_grad()
     def forward_features(self, speakers, contents, contents_lens, contents_max_len, mel_lens=None, mel_max_len=None,
@@ -179,8 +194,6 @@ class DiffSinger(nn.Module):
         SVCInference.forward -- `repeat_expand(text_features, mel_len).T` (tools/diffusion/inference.py:113-114): with
         `expand_to=T` the contents (and a per-frame pitch track of another length) are read at their own frame rate and
         nearest-expanded to T frames inside the launch; `contents_channel_first` takes the extractor's `[B, Din, S]` layout."""
-        if phones2mel is not None:
-            raise NotImplementedError("phones2mel (SVS duration gather, diffsinger.py:85-90) is outside the SVC hot path")
         if not isinstance(self.text_encoder, NaiveProjectionEncoder) or self.text_encoder.use_embedding:
             raise NotImplementedError("only the NaiveProjectionEncoder (Linear) text encoder is fused")
         _lib.require_gpu(contents, "contents")
@@ -193,6 +206,21 @@ class DiffSinger(nn.Module):
         if T <= 0:
             raise ValueError("expand_to must be positive")
         expand = expand_to is not None
+        p2m = gmask = None
+        if phones2mel is not None:        # SVS duration gather (diffsinger.py:85-90): frame t <- text frame phones2mel[b][t], * (1 - mel_mask)
+            if expand:
+                raise ValueError("phones2mel and expand_to are two different frame maps")
+            if mel_masks is None:
+                raise TypeError("phones2mel needs mel_lens: the reference multiplies the gathered features by 1 - mel_masks")
+            p2m = phones2mel.to(device=contents.device, dtype=torch.int64).contiguous()
+            if p2m.ndim != 2 or p2m.shape[0] != B:
+                raise ValueError(f"phones2mel of shape {tuple(phones2mel.shape)} for a batch of {B}")
+            T = int(p2m.shape[1])
+            if tuple(mel_masks.shape) != (B, T):
+                raise ValueError(f"mel mask {tuple(mel_masks.shape)} does not match phones2mel {tuple(p2m.shape)}")
+            if T and (int(p2m.min()) < 0 or int(p2m.max()) >= S):
+                raise RuntimeError("index out of range in phones2mel")    # torch.gather raises RuntimeError as well
+            gmask = mel_masks.to(device=contents.device, dtype=torch.uint8).contiguous()
         E = self.text_encoder.output_size
         keep, terms = [], []
         # speaker: float embedding [B,E] / [B,T,E] given directly, or ids through speaker_encoder (diffsinger.py:92-108)
@@ -202,7 +230,7 @@ class DiffSinger(nn.Module):
                 raise ValueError(f"speaker embedding {tuple(v.shape)} does not broadcast to [{B}, {T}, {E}]")
             per_frame = int(v.ndim == 3 and v.shape[1] == T and T != 1)
             keep.append(v)
-            terms.append(_lib.FeatureTerm(_lib.TERM_VECTOR, per_frame, 0, 0, v.data_ptr(), None, None, 0.0, 0.0))
+            terms.append(_lib.FeatureTerm(_lib.TERM_VECTOR, per_frame, 0, 0, v.data_ptr(), None, None, 0.0, 0.0, 0, None, None))
         elif speakers is not None and hasattr(self, "speaker_encoder"):
             enc = self.speaker_encoder
             if not enc.use_embedding:
@@ -214,7 +242,7 @@ class DiffSinger(nn.Module):
                 raise IndexError("speaker id out of range")   # nn.Embedding raises IndexError as well
             tab = enc.embedding.weight.detach().to(torch.float32).contiguous()
             keep += [ids, tab]
-            terms.append(_lib.FeatureTerm(_lib.TERM_EMBEDDING, 0, 0, 0, ids.data_ptr(), tab.data_ptr(), None, 0.0, 0.0))
+            terms.append(_lib.FeatureTerm(_lib.TERM_EMBEDDING, 0, 0, 0, ids.data_ptr(), tab.data_ptr(), None, 0.0, 0.0, 0, None, None))
         if hasattr(self, "pitch_encoder"):
             terms.append(self._scalar_term(self.pitch_encoder, pitches, B, T, keep, allow_expand=expand))
         if pitch_shift is not None and hasattr(self, "pitch_shift_encoder"):
@@ -225,15 +253,17 @@ class DiffSinger(nn.Module):
             raise ValueError("too many additive terms")
 
         x = contents.to(torch.float32).contiguous()
-        w = self.text_encoder.projection.weight.detach().to(torch.float32).contiguous()
-        b = self.text_encoder.projection.bias.detach().to(torch.float32).contiguous()
+        w, b, neck, nw, nb = self.text_encoder.linear_params()
         out = torch.empty((B, T, E), device=contents.device, dtype=torch.float32)
         arr = (_lib.FeatureTerm * max(1, len(terms)))(*terms)
         eng = self._engine(contents.device)
         with eng.lock:
-            _lib.check(_lib.lib().fdx_features_forward_src(eng.h, _lib.ptr(x), B, S, int(bool(contents_channel_first)), T, Din, E,
-                                                           _lib.ptr(w), _lib.ptr(b), arr, len(terms), _lib.ACT_NONE, None, 0,
-                                                           _lib.ptr(out), _lib.stream_ptr(contents.device)), eng.h)
+            _lib.check(_lib.lib().fdx_features_forward_svs(eng.h, _lib.ptr(x), B, S, int(bool(contents_channel_first)), T, Din, E,
+                                                           _lib.ptr(w), _lib.ptr(b), neck, _lib.ptr(nw) if neck else None,
+                                                           _lib.ptr(nb) if neck else None, _lib.ptr(p2m) if p2m is not None else None,
+                                                           _lib.ptr(gmask) if gmask is not None else None, arr, len(terms), _lib.ACT_NONE,
+                                                           None, 0, _lib.ptr(out), _lib.stream_ptr(contents.device)), eng.h)
+        del p2m, gmask, nw, nb
         del keep
         return dict(features=out, x_masks=mel_masks, x_lens=mel_lens, cond_masks=mel_masks)
 

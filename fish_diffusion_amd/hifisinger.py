@@ -7,7 +7,7 @@ forward_features = three fused launches of the front-end kernel (`fdx_features_f
     feature_fuser[2] Linear + SiLU, `*= 1 - src_masks`, written channel-first core.py:107-110 (and the transpose of :137)
 forward = forward_features + `RefineGANGenerator(features, pitches)` (core.py:136-139).
 Both encoder variants are built: RefineGAN (hifi_svc_v2) and the NSF-HiFiGAN generator with num_mels = hidden_size
-(hifi_svc v1, core.py:35-37,140-141).  phones2mel (SVS) is not.
+(hifi_svc v1, core.py:35-37,140-141).  The phones2mel gather of SVS (core.py:72-78) is part of the first launch.
 """
 from __future__ import annotations
 
@@ -51,24 +51,31 @@ class HiFiSinger(nn.Module):
             self._handle = _lib.Handle(device)
         return self._handle
 
-    def _launch(self, eng, x, lin_w, lin_b, terms, act, mask, channel_first):
-        B, T, Din = x.shape
-        E = lin_w.shape[0]
+    def _launch(self, eng, x, lin, terms, act, mask, channel_first, gather=None, gather_mask=None):
+        """One front-end launch.  `lin` = (w, b, neck, neck_w, neck_b) as NaiveProjectionEncoder.linear_params() returns them."""
+        B, S, Din = x.shape
+        w, b, neck, nw, nb = lin
+        E = w.shape[0]
+        T = S if gather is None else int(gather.shape[1])
         out = torch.empty((B, E, T) if channel_first else (B, T, E), device=x.device, dtype=torch.float32)
         arr = (_lib.FeatureTerm * max(1, len(terms)))(*terms)
-        w, b = lin_w.detach().to(torch.float32).contiguous(), lin_b.detach().to(torch.float32).contiguous()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
+        gm = None if gather_mask is None else gather_mask.to(torch.uint8).contiguous()
         with eng.lock:
-            _lib.check(_lib.lib().fdx_features_forward_ex(eng.h, _lib.ptr(x), B, T, Din, E, _lib.ptr(w), _lib.ptr(b), arr, len(terms), act,
-                                                          _lib.ptr(m), int(channel_first), _lib.ptr(out), _lib.stream_ptr(x.device)), eng.h)
+            _lib.check(_lib.lib().fdx_features_forward_svs(eng.h, _lib.ptr(x), B, S, 0, T, Din, E, _lib.ptr(w), _lib.ptr(b), neck,
+                                                           _lib.ptr(nw) if neck else None, _lib.ptr(nb) if neck else None,
+                                                           _lib.ptr(gather) if gather is not None else None, _lib.ptr(gm), arr, len(terms), act,
+                                                           _lib.ptr(m), int(channel_first), _lib.ptr(out), _lib.stream_ptr(x.device)), eng.h)
         return out
+
+    @staticmethod
+    def _lin(layer):
+        return layer.weight.detach().to(torch.float32).contiguous(), layer.bias.detach().to(torch.float32).contiguous(), 0, None, None
 
     @torch.no_grad()
     def forward_features(self, speakers, contents, contents_lens, contents_max_len, pitch_shift=None, phones2mel=None, energy=None,
                          channel_first: bool = False):
         """core.py:55-115.  `channel_first=True` returns features as [B, hidden, T] (what the generator consumes)."""
-        if phones2mel is not None:
-            raise NotImplementedError("phones2mel (SVS duration gather, core.py:72-78) is outside the SVC hot path")
         if not isinstance(self.text_encoder, NaiveProjectionEncoder) or self.text_encoder.use_embedding:
             raise NotImplementedError("only the NaiveProjectionEncoder (Linear) text encoder is fused")
         if contents_lens is None:
@@ -76,6 +83,14 @@ class HiFiSinger(nn.Module):
         _lib.require_gpu(contents, "contents")
         src_masks = self.get_mask_from_lengths(contents_lens, contents_max_len)
         B, T, _ = contents.shape
+        p2m = None
+        if phones2mel is not None:        # SVS duration gather (core.py:72-78): frame t <- text frame phones2mel[b][t], * (1 - src_mask)
+            p2m = phones2mel.to(device=contents.device, dtype=torch.int64).contiguous()
+            if p2m.ndim != 2 or p2m.shape[0] != B or tuple(src_masks.shape) != tuple(p2m.shape):
+                raise ValueError(f"phones2mel {tuple(phones2mel.shape)} does not match the mask {tuple(src_masks.shape)}")
+            if p2m.numel() and (int(p2m.min()) < 0 or int(p2m.max()) >= T):
+                raise RuntimeError("index out of range in phones2mel")
+            T = int(p2m.shape[1])
         E = self.text_encoder.output_size
         keep, terms = [], []
         if speakers.ndim in (2, 3) and torch.is_floating_point(speakers):
@@ -100,9 +115,9 @@ class HiFiSinger(nn.Module):
             terms.append(DiffSinger._scalar_term(self.energy_encoder, energy, B, T, keep))
         eng = self._engine(contents.device)
         x = contents.to(torch.float32).contiguous()
-        f = self._launch(eng, x, self.text_encoder.projection.weight, self.text_encoder.projection.bias, terms, _lib.ACT_NONE, None, False)
-        f = self._launch(eng, f, self.feature_fuser[0].weight, self.feature_fuser[0].bias, [], _lib.ACT_SILU, None, False)
-        f = self._launch(eng, f, self.feature_fuser[2].weight, self.feature_fuser[2].bias, [], _lib.ACT_SILU, src_masks, channel_first)
+        f = self._launch(eng, x, self.text_encoder.linear_params(), terms, _lib.ACT_NONE, None, False, p2m, src_masks if p2m is not None else None)
+        f = self._launch(eng, f, self._lin(self.feature_fuser[0]), [], _lib.ACT_SILU, None, False)
+        f = self._launch(eng, f, self._lin(self.feature_fuser[2]), [], _lib.ACT_SILU, src_masks, channel_first)
         del keep
         return dict(features=f, src_masks=src_masks)
 

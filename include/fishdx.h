@@ -327,6 +327,11 @@ typedef struct {
   const float* w;
   const float* b;   /* may be NULL */
   float p0, p1;
+  /* NaiveProjectionEncoder(use_neck=True) (naive_projection.py:37-41) on a scalar term: Linear(1, neck) then Linear(neck, E):
+     h[n] = neck_w[n] * pre(value) + neck_b[n], term = w[E][neck] . h + b[E].  neck = 0: the plain Linear(1, E) above. */
+  int neck;
+  const float* neck_w;
+  const float* neck_b;   /* may be NULL */
 } fdx_feature_term;
 /* contents: dev [B][T][Din]; w_text: dev [E][Din]; b_text: dev [E] or NULL; terms: HOST array; features: dev [B][T][E]. */
 int fdx_features_forward(fdx_handle h, const float* contents, int B, int T, int Din, int E, const float* w_text,
@@ -345,6 +350,19 @@ int fdx_features_forward_ex(fdx_handle h, const float* contents, int B, int T, i
  * (F.interpolate(mode="nearest"), utils/tensor.py:7-43) fused into the projection instead of materialising [T][Din]. */
 int fdx_features_forward_src(fdx_handle h, const float* contents, int B, int S, int contents_channel_first, int T, int Din,
                              int E, const float* w_text, const float* b_text, const fdx_feature_term* terms, int n_terms,
+                             int act, const uint8_t* mask, int channel_first, float* features, fdx_stream s);
+/* The SVS variant of the same launch (archs/diffsinger/diffsinger.py:83-90; archs/hifisinger/core.py:71-79):
+ *   phones2mel  dev int64 [B][T] or NULL: output frame t reads source frame phones2mel[b][t] (in [0, S)) instead of the
+ *               nearest-expansion index -- torch.gather(text_encoder(contents), 1, phones2mel) -- and
+ *   gather_mask dev bytes [B][T] or NULL: 1 => the gathered text features of that frame are multiplied by 0
+ *               (`* (1 - mel_masks[:, :, None].float())`) BEFORE the additive terms;
+ *   neck > 0    the text encoder is NaiveProjectionEncoder(use_neck=True) (naive_projection.py:37-41):
+ *               Linear(Din, neck) [neck_w dev [neck][Din], neck_b dev [neck] or NULL] then Linear(neck, E) [w_text dev [E][neck]].
+ *               neck <= FDX_MAX_NECK. */
+#define FDX_MAX_NECK 32
+int fdx_features_forward_svs(fdx_handle h, const float* contents, int B, int S, int contents_channel_first, int T, int Din,
+                             int E, const float* w_text, const float* b_text, int neck, const float* neck_w, const float* neck_b,
+                             const long long* phones2mel, const uint8_t* gather_mask, const fdx_feature_term* terms, int n_terms,
                              int act, const uint8_t* mask, int channel_first, float* features, fdx_stream s);
 /* dst[r][t] = src[r][min(floor(t * (float)S / T), S - 1)] for r < rows: fish_diffusion.utils.tensor.repeat_expand
  * (mode "nearest") on its own, e.g. for a pitch track given at another frame rate (inference.py:108-109). */

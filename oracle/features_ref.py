@@ -45,12 +45,29 @@ def mask_from_lengths(lengths: torch.Tensor, max_len: Optional[int] = None) -> t
     return ids >= lengths.unsqueeze(1).expand(-1, int(max_len))
 
 
+def _projection(sd: SD, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """NaiveProjectionEncoder.forward without preprocessing (naive_projection.py:34-44,57-60): nn.Linear, or -- use_neck --
+    nn.Sequential(Linear(in, neck), Linear(neck, out)) with state-dict keys projection.0.* / projection.1.*."""
+    if f"{prefix}.projection.0.weight" in sd:
+        h = F.linear(x, sd[f"{prefix}.projection.0.weight"], sd[f"{prefix}.projection.0.bias"])
+        return F.linear(h, sd[f"{prefix}.projection.1.weight"], sd[f"{prefix}.projection.1.bias"])
+    return F.linear(x, sd[f"{prefix}.projection.weight"], sd[f"{prefix}.projection.bias"])
+
+
+def _has(sd: SD, prefix: str) -> bool:
+    return f"{prefix}.projection.weight" in sd or f"{prefix}.projection.0.weight" in sd
+
+
 def forward_features(sd: SD, contents, speakers=None, pitches=None, pitch_shift=None, energy=None, mel_lens=None,
-                     mel_max_len=None) -> dict:
-    """diffsinger.py:57-134 without the phones2mel gather.  Keys of ``sd`` are the DiffSinger state-dict names:
-    text_encoder.projection.{weight,bias}, speaker_encoder.embedding.weight, {pitch,pitch_shift,energy}_encoder.projection.*"""
+                     mel_max_len=None, phones2mel=None) -> dict:
+    """diffsinger.py:57-134.  Keys of ``sd`` are the DiffSinger state-dict names:
+    text_encoder.projection.{weight,bias} (use_neck: projection.{0,1}.*), speaker_encoder.embedding.weight,
+    {pitch,pitch_shift,energy}_encoder.projection.*"""
     mel_masks = mask_from_lengths(mel_lens, mel_max_len) if mel_lens is not None else None
-    features = F.linear(contents, sd["text_encoder.projection.weight"], sd["text_encoder.projection.bias"])
+    features = _projection(sd, "text_encoder", contents)
+    if phones2mel is not None:                                  # :85-90, the SVS duration gather
+        idx = phones2mel.unsqueeze(-1).repeat([1, 1, features.shape[-1]]).long()
+        features = torch.gather(features, 1, idx) * (1 - mel_masks[:, :, None].float())
     emb = None
     if speakers is not None and speakers.ndim in (2, 3) and torch.is_floating_point(speakers):
         emb = speakers
@@ -60,16 +77,31 @@ def forward_features(sd: SD, contents, speakers=None, pitches=None, pitch_shift=
         emb = emb[:, None, :]
     if emb is not None:
         features = features + emb
-    if "pitch_encoder.projection.weight" in sd:
-        features = features + F.linear(pitch_to_scale(pitches), sd["pitch_encoder.projection.weight"],
-                                       sd["pitch_encoder.projection.bias"])
-    if pitch_shift is not None and "pitch_shift_encoder.projection.weight" in sd:
-        e = F.linear(pitch_shift, sd["pitch_shift_encoder.projection.weight"], sd["pitch_shift_encoder.projection.bias"])
+    if _has(sd, "pitch_encoder"):
+        features = features + _projection(sd, "pitch_encoder", pitch_to_scale(pitches))
+    if pitch_shift is not None and _has(sd, "pitch_shift_encoder"):
+        e = _projection(sd, "pitch_shift_encoder", pitch_shift)
         features = features + (e[:, None, :] if e.ndim == 2 else e)
-    if energy is not None and "energy_encoder.projection.weight" in sd:
-        e = F.linear(energy, sd["energy_encoder.projection.weight"], sd["energy_encoder.projection.bias"])
+    if energy is not None and _has(sd, "energy_encoder"):
+        e = _projection(sd, "energy_encoder", energy)
         features = features + (e[:, None, :] if e.ndim == 2 else e)
     return dict(features=features, x_masks=mel_masks, x_lens=mel_lens, cond_masks=mel_masks)
+
+
+def seeded_svs_frontend_state(seed: int, content_dim=64, hidden=96, n_speakers=10, neck=8) -> SD:
+    """A front end whose text, pitch and energy encoders use the bottleneck variant (use_neck=True, neck_size=neck)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out_f, in_f):
+        bound = (6.0 / (out_f + in_f)) ** 0.5
+        return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound, (torch.rand(out_f, generator=g) * 2 - 1) * 0.05
+
+    sd = {}
+    for name, din in (("text_encoder", content_dim), ("pitch_encoder", 1), ("energy_encoder", 1)):
+        sd[f"{name}.projection.0.weight"], sd[f"{name}.projection.0.bias"] = lin(neck, din)
+        sd[f"{name}.projection.1.weight"], sd[f"{name}.projection.1.bias"] = lin(hidden, neck)
+    sd["speaker_encoder.embedding.weight"] = torch.randn(n_speakers, hidden, generator=g) * hidden ** -0.5
+    return sd
 
 
 def seeded_frontend_state(seed: int, content_dim=256, hidden=256, n_speakers=10, pitch_shift=False, energy=False) -> SD:
@@ -93,13 +125,17 @@ def seeded_frontend_state(seed: int, content_dim=256, hidden=256, n_speakers=10,
 
 
 # ------------------------------------------------------------------------------------------------ HiFiSinger (hifi_svc_v2)
-def hifisinger_features(sd: SD, contents, speakers, contents_lens, contents_max_len, pitch_shift=None, energy=None) -> dict:
-    """archs/hifisinger/core.py:55-115 without the phones2mel gather: text Linear + speaker embedding (+ pitch-shift / energy
+def hifisinger_features(sd: SD, contents, speakers, contents_lens, contents_max_len, pitch_shift=None, energy=None,
+                        phones2mel=None) -> dict:
+    """archs/hifisinger/core.py:55-115: text Linear + speaker embedding (+ pitch-shift / energy
     projections), then feature_fuser = Linear, SiLU, Linear, SiLU (:24-29) and `features *= 1 - src_masks` (:109-110).
     Keys: text_encoder.projection.*, speaker_encoder.embedding.weight, {pitch_shift,energy}_encoder.projection.*,
     feature_fuser.{0,2}.{weight,bias}."""
     src_masks = mask_from_lengths(contents_lens, contents_max_len) if contents_lens is not None else None
     features = F.linear(contents, sd["text_encoder.projection.weight"], sd["text_encoder.projection.bias"])
+    if phones2mel is not None:                                  # core.py:72-78
+        idx = phones2mel.unsqueeze(-1).repeat([1, 1, features.shape[-1]]).long()
+        features = torch.gather(features, 1, idx) * (1 - src_masks[:, :, None].float())
     if speakers.ndim in (2, 3) and torch.is_floating_point(speakers):
         emb = speakers
     else:

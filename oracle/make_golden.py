@@ -200,6 +200,83 @@ def golden_frontend_expand(R):
     save("frontend_expand", **arrays)
 
 
+def golden_frontend_svs(R):
+    """The SVS branch of the front end: `torch.gather(text_encoder(contents), 1, phones2mel) * (1 - mel_masks)`
+    (archs/diffsinger/diffsinger.py:83-90; archs/hifisinger/core.py:71-79) and NaiveProjectionEncoder(use_neck=True)
+    (modules/encoders/naive_projection.py:37-41) -- the reference's own method source on real encoder instances."""
+    print("front end: phones2mel gather + use_neck encoders")
+    get_mask, fwd_features = R["diffsinger_methods"]()
+    Enc = R["NaiveProjectionEncoder"]
+    Din, E, neck = 64, 96, 8
+
+    class RefFrontEnd(torch.nn.Module):
+        forward_features = fwd_features
+
+        def __init__(self, sd, use_neck):
+            super().__init__()
+            self.get_mask_from_lengths = get_mask.__func__ if hasattr(get_mask, "__func__") else get_mask
+            kw = dict(use_neck=True, neck_size=neck) if use_neck else {}
+            self.text_encoder = Enc(Din, E, **kw)
+            self.speaker_encoder = Enc(10, E, use_embedding=True)
+            self.pitch_encoder = Enc(1, E, preprocessing=R["pitch_to_scale"], **kw)
+            self.energy_encoder = Enc(1, E, **kw)
+            self.load_state_dict(sd, strict=True)
+
+    g = torch.Generator().manual_seed(123)
+    B, S, T = 3, 23, 70                       # S phonemes, T mel frames
+    contents = torch.randn(B, S, Din, generator=g)
+    f0 = torch.rand(B, T, generator=g) * 1300.0
+    energy = torch.rand(B, T, 1, generator=g)
+    ids = torch.tensor([3, 0, 9])
+    mel_lens = torch.tensor([70, 51, 64])
+    src_lens = torch.tensor([23, 17, 20])
+    phones2mel = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):                        # monotone durations like opencpop_transcription.py:50-57 (zeros in the padding)
+        cuts = torch.sort(torch.randint(1, int(mel_lens[b]), (int(src_lens[b]) - 1,), generator=g)).values
+        edges = [0] + cuts.tolist() + [int(mel_lens[b])]
+        for i in range(int(src_lens[b])):
+            phones2mel[b, edges[i]:edges[i + 1]] = i
+    sd_neck = features_ref.seeded_svs_frontend_state(31, Din, E, 10, neck)
+    sd_plain = features_ref.seeded_frontend_state(32, Din, E, 10, energy=True)
+    arrays = dict(contents=contents, f0=f0, energy=energy, ids=ids, mel_lens=mel_lens, src_lens=src_lens, phones2mel=phones2mel,
+                  neck=np.int64(neck), sha1_neck=np.array(state_sha1(sd_neck)), sha1_plain=np.array(state_sha1(sd_plain)))
+    for tag, sd, use_neck, p2m in (("neck_gather", sd_neck, True, phones2mel), ("plain_gather", sd_plain, False, phones2mel),
+                                   ("neck_frames", sd_neck, True, None)):
+        c = contents if p2m is not None else torch.randn(B, T, Din, generator=g)
+        if p2m is None:
+            arrays["contents_frames"] = c
+        ref = RefFrontEnd(sd, use_neck).forward_features(ids, c, src_lens if p2m is not None else mel_lens, S if p2m is not None else T,
+                                                         mel_lens=mel_lens, mel_max_len=T, pitches=f0.clone(), phones2mel=p2m, energy=energy)
+        mine = features_ref.forward_features(sd, c, ids, f0, None, energy, mel_lens, T, phones2mel=p2m)
+        assert torch.equal(mine["features"], ref["features"]), tag
+        arrays[f"features_{tag}"] = ref["features"]
+    save("frontend_svs", **arrays)
+
+    # HiFiSinger's copy of the gather (core.py:71-79): the mask is src_masks, taken over the mel frames
+    get_mask_h, fwd_feat_h, _ = R["hifisinger_methods"]()
+    hsd = features_ref.seeded_hifisinger_state(8, content_dim=Din, hidden=E)
+
+    class RefHifi(torch.nn.Module):
+        forward_features = fwd_feat_h
+
+        def __init__(self):
+            super().__init__()
+            self.get_mask_from_lengths = get_mask_h.__func__ if hasattr(get_mask_h, "__func__") else get_mask_h
+            self.text_encoder = Enc(Din, E)
+            self.speaker_encoder = Enc(10, E, use_embedding=True)
+            self.pitch_shift_encoder = Enc(1, E)
+            self.energy_encoder = Enc(1, E)
+            self.feature_fuser = torch.nn.Sequential(torch.nn.Linear(E, E), torch.nn.SiLU(), torch.nn.Linear(E, E), torch.nn.SiLU())
+            self.load_state_dict(hsd, strict=True)
+
+    shift = torch.randn(B, 1, generator=g)
+    ref = RefHifi().forward_features(ids, contents, mel_lens, T, pitch_shift=shift, phones2mel=phones2mel, energy=energy)["features"]
+    mine = features_ref.hifisinger_features(hsd, contents, ids, mel_lens, T, shift, energy, phones2mel=phones2mel)["features"]
+    assert torch.equal(mine, ref), "oracle hifisinger gather != reference"
+    save("frontend_svs_hifisinger", contents=contents, ids=ids, mel_lens=mel_lens, phones2mel=phones2mel, shift=shift, energy=energy,
+         features=ref, sha1=np.array(state_sha1(hsd)))
+
+
 TD_SMALL = dict(mel_channels=128, dim=128, mlp_factor=2, condition_dim=256, num_layers=2)
 TD_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=12)   # convnext.py:264-271 defaults
 
@@ -746,6 +823,7 @@ def main():
     golden_round2(R)
     golden_convnext_cross(R)
     golden_refinegan_sine(R)
+    golden_frontend_svs(R)
 
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
@@ -753,7 +831,8 @@ def main():
 
 
 if __name__ == "__main__":
-    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2, "convnext_cross": golden_convnext_cross, "refinegan_sine": golden_refinegan_sine}
+    SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2, "convnext_cross": golden_convnext_cross, "refinegan_sine": golden_refinegan_sine,
+                "frontend_svs": golden_frontend_svs}
     if len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(os.cpu_count())

@@ -685,8 +685,65 @@ def test_forward_features_matches_reference_golden(dev):
         assert torch.equal(out["x_masks"].cpu(), g["masks"].bool()) and out["cond_masks"] is out["x_masks"]
     with pytest.raises(IndexError):
         ma.forward_features(torch.tensor([10, 0, 0], device=dev), c, lens, T, pitches=f0)
-    with pytest.raises(NotImplementedError):
-        ma.forward_features(ids, c, lens, T, pitches=f0, phones2mel=torch.zeros(3, T, dtype=torch.long, device=dev))
+
+
+def test_forward_features_svs_gather_and_neck_match_reference_golden(dev):
+    """SVS branch of the front end inside the same fused launch: `torch.gather(text_encoder(contents), 1, phones2mel) * (1 - mel_masks)`
+    (diffsinger.py:83-90), NaiveProjectionEncoder(use_neck=True) for the text / pitch / energy encoders (naive_projection.py:37-41),
+    and HiFiSinger's copy of the gather (core.py:71-79) -- vs the reference's own method source on real encoder instances."""
+    from fish_diffusion_amd import DiffSinger, HiFiSinger, pitch_to_scale
+    from oracle import features_ref
+    g = load("frontend_svs")
+    Din, neck, E = g["contents"].shape[2], int(g["neck"]), g["features_neck_gather"].shape[2]
+    sd_neck, sd_plain = features_ref.seeded_svs_frontend_state(31, Din, E, 10, neck), features_ref.seeded_frontend_state(32, Din, E, 10, energy=True)
+
+    def build(sd, use_neck):
+        kw = dict(use_neck=True, neck_size=neck) if use_neck else {}
+        cfg = dict(text_encoder=dict(type="NaiveProjectionEncoder", input_size=Din, output_size=E, **kw),
+                   speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=E, use_embedding=True),
+                   pitch_encoder=dict(type="NaiveProjectionEncoder", input_size=1, output_size=E, preprocessing=pitch_to_scale, **kw),
+                   energy_encoder=dict(type="NaiveProjectionEncoder", input_size=1, output_size=E, **kw),
+                   diffusion=dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5], spec_max=[0]))
+        m = DiffSinger(cfg)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.startswith("diffusion.") for k in missing)
+        return m.to(dev).eval()
+
+    mn, mp = build(sd_neck, True), build(sd_plain, False)
+    ids, lens, slens = (torch.as_tensor(g[k]).to(dev) for k in ("ids", "mel_lens", "src_lens"))
+    p2m = torch.as_tensor(g["phones2mel"]).to(dev)
+    S, T = g["contents"].shape[1], p2m.shape[1]
+    c, f0, energy = g["contents"].to(dev), g["f0"].to(dev), g["energy"].to(dev)
+    for tag, m in (("neck_gather", mn), ("plain_gather", mp)):
+        out = m.forward_features(ids, c, slens, S, mel_lens=lens, mel_max_len=T, pitches=f0, phones2mel=p2m, energy=energy)
+        e = rel_err(out["features"].cpu(), g[f"features_{tag}"])
+        print(f"front end, {tag}: rel err {e:.2e}")
+        assert out["features"].shape == g[f"features_{tag}"].shape and e < 1e-5, tag
+    out = mn.forward_features(ids, g["contents_frames"].to(dev), lens, T, mel_lens=lens, mel_max_len=T, pitches=f0, energy=energy)
+    assert rel_err(out["features"].cpu(), g["features_neck_frames"]) < 1e-5
+    # a use_neck encoder on its own (the reference calls encoders individually in a few tools)
+    ref = features_ref._projection(sd_neck, "text_encoder", g["contents"])
+    assert rel_err(mn.text_encoder(c).cpu(), ref) < 1e-5
+    # error behaviour: torch.gather raises RuntimeError on an index outside the text frames; the mask is not optional (:88-90)
+    bad = p2m.clone()
+    bad[0, 3] = S
+    with pytest.raises(RuntimeError):
+        mn.forward_features(ids, c, slens, S, mel_lens=lens, mel_max_len=T, pitches=f0, phones2mel=bad, energy=energy)
+    with pytest.raises(TypeError):
+        mn.forward_features(ids, c, slens, S, pitches=f0, phones2mel=p2m, energy=energy)
+    # HiFiSinger: same gather, masked by src_masks over the mel frames, then the fuser
+    h = load("frontend_svs_hifisinger")
+    hsd = features_ref.seeded_hifisinger_state(8, content_dim=Din, hidden=E)
+    lin1 = dict(type="NaiveProjectionEncoder", input_size=1, output_size=E)
+    from oracle import refinegan_ref
+    hm = HiFiSinger(dict(hidden_size=E, text_encoder=dict(type="NaiveProjectionEncoder", input_size=Din, output_size=E),
+                         speaker_encoder=dict(type="NaiveProjectionEncoder", input_size=10, output_size=E, use_embedding=True),
+                         pitch_shift_encoder=lin1, energy_encoder=lin1, encoder=dict(type="RefineGAN", **dict(refinegan_ref.CONFIG, num_mels=E))))
+    missing, unexpected = hm.load_state_dict(hsd, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") for k in missing)
+    hm = hm.to(dev).eval()
+    out = hm.forward_features(ids, c, lens, T, pitch_shift=h["shift"].to(dev), phones2mel=p2m, energy=energy)
+    assert out["features"].shape == h["features"].shape and rel_err(out["features"].cpu(), h["features"]) < 1e-5
 
 
 def test_repeat_expand_and_fused_expansion_match_reference_golden(dev):

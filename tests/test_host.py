@@ -318,6 +318,16 @@ def test_diffsinger_frontend_state_dict_contract(lib):
         m.forward()
     with pytest.raises(RuntimeError):   # CPU tensors: no fallback
         m.forward_features(torch.tensor([1]), torch.zeros(1, 4, 256), torch.tensor([4]), 4, pitches=torch.zeros(1, 4))
+    # use_neck: nn.Sequential(Linear(in, neck), Linear(neck, out)) -> keys projection.0.* / projection.1.* (naive_projection.py:37-41)
+    from fish_diffusion_amd.diffsinger import NaiveProjectionEncoder
+    enc = NaiveProjectionEncoder(64, 96, use_neck=True, neck_size=8)
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == {
+        "projection.0.weight": (8, 64), "projection.0.bias": (8,), "projection.1.weight": (96, 8), "projection.1.bias": (96,)}
+    w, b, neck, nw, nb = enc.linear_params()
+    assert neck == 8 and tuple(w.shape) == (96, 8) and tuple(nw.shape) == (8, 64) and float(nb.abs().max()) == 0.0
+    assert NaiveProjectionEncoder(10, 96, use_embedding=True, use_neck=True).use_neck is False    # the embedding wins, as in the reference
+    with pytest.raises(ValueError):
+        NaiveProjectionEncoder(64, 96, use_neck=True, neck_size=64)
 
 
 # ------------------------------------------------------------------ ConvNext denoiser: packing + arena layout, via the numpy kernel emulation

@@ -115,6 +115,28 @@ def test_frontend_oracle_matches_reference():
         assert torch.equal(out["x_masks"], g["masks"].bool())
 
 
+def test_frontend_svs_oracle_matches_reference():
+    """The SVS branch: phones2mel gather * (1 - mel_mask) (diffsinger.py:83-90; hifisinger core.py:71-79) and the use_neck encoders
+    (naive_projection.py:37-41) vs the outputs of the reference's own method source on real encoder instances."""
+    from oracle import features_ref
+    g = load("frontend_svs")
+    Din, neck = g["contents"].shape[2], int(g["neck"])
+    E = g["features_neck_gather"].shape[2]
+    sd_neck, sd_plain = features_ref.seeded_svs_frontend_state(31, Din, E, 10, neck), features_ref.seeded_frontend_state(32, Din, E, 10, energy=True)
+    assert sha1_state(sd_neck) == str(g["sha1_neck"]) and sha1_state(sd_plain) == str(g["sha1_plain"])
+    ids, lens, p2m = torch.as_tensor(g["ids"]), torch.as_tensor(g["mel_lens"]), torch.as_tensor(g["phones2mel"])
+    T = p2m.shape[1]
+    for tag, sd, c, idx in (("neck_gather", sd_neck, g["contents"], p2m), ("plain_gather", sd_plain, g["contents"], p2m),
+                            ("neck_frames", sd_neck, g["contents_frames"], None)):
+        out = features_ref.forward_features(sd, c, ids, g["f0"], None, g["energy"], lens, T, phones2mel=idx)["features"]
+        assert out.shape == g[f"features_{tag}"].shape and rel_err(out, g[f"features_{tag}"]) < 1e-6, tag
+    h = load("frontend_svs_hifisinger")
+    hsd = features_ref.seeded_hifisinger_state(8, content_dim=Din, hidden=E)
+    assert sha1_state(hsd) == str(h["sha1"])
+    out = features_ref.hifisinger_features(hsd, h["contents"], ids, lens, T, h["shift"], h["energy"], phones2mel=p2m)["features"]
+    assert rel_err(out, h["features"]) < 1e-6
+
+
 @pytest.mark.parametrize("tag", ["small", "hifisinger"])
 def test_refinegan_oracle_matches_reference(tag):
     from oracle import refinegan_ref
