@@ -59,43 +59,60 @@ __global__ void k_td_addpos(float* __restrict__ X, long bs, int ld, const float*
 }
 
 
-// LayerNorm over channels, in place: 8 frames x 32 channel groups per workgroup (T/8 workgroups: latency-bound, wants many),
-// values in registers, two-pass statistics
-constexpr int kLnFr = 8, kLnCg = 32, kLnCpt = 16;
+// LayerNorm over channels, in place: FR frames x (256 / FR) channel groups per workgroup, values in registers, two-pass statistics.
+// The kernel is latency-bound (1.8 MB in, 1.8 MB out at batch 1): what matters is how wide the row segments are that a wave touches
+// per load (FR * 4 bytes) against how many workgroups there are (T / FR); FR = 8 measured 11.3 us per launch at T = 861, D = 512.
+template <int FR>
 __global__ __launch_bounds__(256) void k_td_layernorm(float* __restrict__ X, long bs, int ld, const float* __restrict__ w,
                                                       const float* __restrict__ bia, int D, int T, float eps) {
-  __shared__ float red[kLnCg][kLnFr];
-  const int tc = threadIdx.x & (kLnFr - 1), cg = threadIdx.x / kLnFr;
-  const int b = blockIdx.y, t = blockIdx.x * kLnFr + tc;
-  const int cpt = D / kLnCg;
+  constexpr int CG = 256 / FR, CPT = 512 / CG;       // channel groups; channels per thread at the largest D (512)
+  __shared__ float red[4][FR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tc = threadIdx.x & (FR - 1), cg = threadIdx.x / FR;
+  const int b = blockIdx.y, t = blockIdx.x * FR + tc;
+  const int cpt = D / CG;
   const bool live = t < T;
   float* xb = X + b * bs + (live ? t : T - 1);
-  float u[kLnCpt];
+  // (unconditional loads from a clamped row: behind `if (ci < cpt)` hipcc waits for each load before it issues the next --
+  // the kernel's time was proportional to the channels per thread: 11.3 us at 16)
+  float u[CPT];
   float s1 = 0.f;
 #pragma unroll
-  for (int ci = 0; ci < kLnCpt; ++ci) {
-    u[ci] = 0.f;
-    if (ci < cpt) { u[ci] = xb[(long)(cg * cpt + ci) * ld]; s1 += u[ci]; }
-  }
-  auto total = [&](float v) {
-    __syncthreads();
-    red[cg][tc] = v;
-    __syncthreads();
-    float s = 0.f;
+  for (int ci = 0; ci < CPT; ++ci) u[ci] = xb[(long)(cg * cpt + min(ci, cpt - 1)) * ld];
 #pragma unroll
-    for (int g = 0; g < kLnCg; ++g) s += red[g][tc];
-    return s;
+  for (int ci = 0; ci < CPT; ++ci) s1 += ci < cpt ? u[ci] : 0.f;
+  auto total = [&](float v) {                         // over the channel groups: lanes of equal frame, then the four waves
+#pragma unroll
+    for (int off = FR; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane < FR) red[wave][lane] = v;
+    __syncthreads();
+    return (red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]);
   };
   const float mean = total(s1) / (float)D;
   float s2 = 0.f;
 #pragma unroll
-  for (int ci = 0; ci < kLnCpt; ++ci)
-    if (ci < cpt) { const float dl = u[ci] - mean; s2 += dl * dl; }
+  for (int ci = 0; ci < CPT; ++ci) { const float dl = u[ci] - mean; s2 += ci < cpt ? dl * dl : 0.f; }
   const float rstd = 1.f / sqrtf(total(s2) / (float)D + eps);
   if (!live) return;
+  float wv[CPT], bv[CPT];
 #pragma unroll
-  for (int ci = 0; ci < kLnCpt; ++ci)
-    if (ci < cpt) { const int c = cg * cpt + ci; xb[(long)c * ld] = (u[ci] - mean) * rstd * w[c] + bia[c]; }
+  for (int ci = 0; ci < CPT; ++ci) { const int c = cg * cpt + min(ci, cpt - 1); wv[ci] = w[c]; bv[ci] = bia[c]; }
+#pragma unroll
+  for (int ci = 0; ci < CPT; ++ci)
+    if (ci < cpt) xb[(long)(cg * cpt + ci) * ld] = (u[ci] - mean) * rstd * wv[ci] + bv[ci];
+}
+inline int ln_frames() {   // FDX_LN_FR = 4 | 8 | 16 | 32 (A/B)
+  static const int v = [] { const char* e = getenv("FDX_LN_FR"); const int k = e ? atoi(e) : 0; return (k == 4 || k == 8 || k == 16 || k == 32) ? k : 8; }();
+  return v;
+}
+inline void launch_layernorm(float* X, long bs, int ld, const float* w, const float* bia, int B, int D, int T, hipStream_t s) {
+  const int fr = (D % 64) ? 8 : ln_frames();          // FR = 4 -> 64 channel groups: D must divide by them
+  const dim3 grid((T + fr - 1) / fr, B);
+  if (fr == 4) hipLaunchKernelGGL(k_td_layernorm<4>, grid, dim3(256), 0, s, X, bs, ld, w, bia, D, T, 1e-5f);
+  else if (fr == 32) hipLaunchKernelGGL(k_td_layernorm<32>, grid, dim3(256), 0, s, X, bs, ld, w, bia, D, T, 1e-5f);
+  else if (fr == 16) hipLaunchKernelGGL(k_td_layernorm<16>, grid, dim3(256), 0, s, X, bs, ld, w, bia, D, T, 1e-5f);
+  else hipLaunchKernelGGL(k_td_layernorm<8>, grid, dim3(256), 0, s, X, bs, ld, w, bia, D, T, 1e-5f);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -312,7 +329,6 @@ inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, i
                                const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s) {
   const long bsD = (long)D * ld, bsH = (long)H * ld;
   const int DH = D / kHeads;
-  const dim3 ln_grid((T + kLnFr - 1) / kLnFr, B);
   auto residual = [&](const PackedW& p, const float* in, long in_bs) {   // X += W in + b
     EpiScaleRes e{};
     e.X = X; e.bs = bsD; e.ld = ld; e.bias = A + p.b_off; e.gamma = nullptr; e.M = D; e.mask = nullptr; e.mask_ld = T;
@@ -329,18 +345,18 @@ inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, i
   at.kmask = tgt_kpm;
   if ((e = launch_attn(DH, at, B, s)) != hipSuccess) return e;
   if ((e = residual(y.sa_out, sc.O, bsD)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_td_layernorm, ln_grid, dim3(256), 0, s, X, bsD, ld, A + y.n1w, A + y.n1b, D, T, 1e-5f);
+  launch_layernorm(X, bsD, ld, A + y.n1w, A + y.n1b, B, D, T, s);
   // ---- cross-attention block
   if ((e = gemm(A, y.ca_q, B, T, X, bsD, ld, bias_epi(sc.QKV, 3 * bsD, ld, A + y.ca_q.b_off, D, ACT_NONE), s)) != hipSuccess) return e;
   at.K = KV; at.k_bs = kv_bs; at.V = KV + (size_t)D * ld; at.v_bs = kv_bs;
   at.kmask = mem_kpm;
   if ((e = launch_attn(DH, at, B, s)) != hipSuccess) return e;
   if ((e = residual(y.ca_out, sc.O, bsD)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_td_layernorm, ln_grid, dim3(256), 0, s, X, bsD, ld, A + y.n2w, A + y.n2b, D, T, 1e-5f);
+  launch_layernorm(X, bsD, ld, A + y.n2w, A + y.n2b, B, D, T, s);
   // ---- feed-forward block
   if ((e = gemm(A, y.lin1, B, T, X, bsD, ld, bias_epi(sc.G, bsH, ld, A + y.lin1.b_off, H, ACT_GELU), s)) != hipSuccess) return e;
   if ((e = residual(y.lin2, sc.G, bsH)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_td_layernorm, ln_grid, dim3(256), 0, s, X, bsD, ld, A + y.n3w, A + y.n3b, D, T, 1e-5f);
+  launch_layernorm(X, bsD, ld, A + y.n3w, A + y.n3b, B, D, T, s);
   return hipGetLastError();
 }
 
