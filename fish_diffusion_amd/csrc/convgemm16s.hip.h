@@ -96,20 +96,20 @@ template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum o
   const float* keep; long keep_bs;
   struct Pre { VecN<NM> old; VecN<NM> keep; float bias, sb; };
   __device__ __forceinline__ bool is_res(int row) const { return __builtin_amdgcn_readfirstlane(row) < C; }
+  // Branch-free: every load is unconditional, from a pointer selected by the (wave-uniform) conditions.  With the loads inside
+  // `if (res) .. else if (skip) ..` hipcc put an `s_waitcnt vmcnt(0)` in front of each epilogue site's loads (the two branches
+  // write the same registers), i.e. four full memory round trips in a row -- with the K loop's first operand stages in flight
+  // behind them -- before the first MFMA: most of the 4.2 k cycles "set-up + prefetch" of this kernel at batch 1.
   __device__ __forceinline__ Pre load(int b, int row, int t) const {
     Pre p;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) p.old.v[m] = 0.f;
-    p.bias = bias[row]; p.sb = 0.f;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) p.keep.v[m] = 1.f;
-    if (is_res(row)) {
-      p.old = ldN<NM>(X + b * bs + (long)row * ld + t);
-      if (Y) p.sb = sb[(long)row * sb_ld + b * sb_bs];
-      if (Y && keep) p.keep = ldN<NM>(keep + b * keep_bs + t);
-    } else if (skip_mode == 1 || skip_mode == 2) {
-      p.old = ldN<NM>(SK + b * bs + (long)(row - C) * ld + t);
-    }
+    const bool res = is_res(row), use_y = res && Y, use_keep = use_y && keep;
+    const float* src = res ? X + b * bs + (long)row * ld + t : SK + b * bs + (long)(row - C) * ld + t;   // (SK unread by store() when the sum starts here)
+    const float* sbp = use_y ? sb + (long)row * sb_ld + b * sb_bs : bias + row;
+    const float* kp = use_keep ? keep + b * keep_bs + t : bias;      // (any 8 readable floats; one line for all lanes)
+    p.old = ldN<NM>(src);
+    p.bias = bias[row];
+    p.sb = *sbp;
+    p.keep = ldN<NM>(kp);                       // (raw: store() applies `use_keep` -- touching a loaded value here would wait for it)
     return p;
   }
   __device__ __forceinline__ void store(int b, int row, int t, int nvalid, VecN<NM> v, const Pre& p) const {
@@ -121,7 +121,7 @@ template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum o
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         xn.v[m] = div_const(p.old.v[m] + v.v[m], 1.41421356237309504880f, 0.70710678118654752440f);
-        yn.v[m] = p.keep.v[m] != 0.f ? xn.v[m] + p.sb : 0.f;
+        yn.v[m] = (!keep || p.keep.v[m] != 0.f) ? xn.v[m] + p.sb : 0.f;
       }
       stNp<NM, false>(X + o, xn, nvalid);
       if (Y) stNp<NM, true>(Y + o, yn, nvalid);

@@ -61,7 +61,8 @@ __global__ void k_td_addpos(float* __restrict__ X, long bs, int ld, const float*
 
 // LayerNorm over channels, in place: FR frames x (256 / FR) channel groups per workgroup, values in registers, two-pass statistics.
 // The kernel is latency-bound (1.8 MB in, 1.8 MB out at batch 1): what matters is how wide the row segments are that a wave touches
-// per load (FR * 4 bytes) against how many workgroups there are (T / FR); FR = 8 measured 11.3 us per launch at T = 861, D = 512.
+// per load (FR * 4 bytes) against how many workgroups there are (T / FR); 11.3 us per launch at T = 861, D = 512 before the loads
+// became unconditional, 5.5 us after (FR = 16).
 template <int FR>
 __global__ __launch_bounds__(256) void k_td_layernorm(float* __restrict__ X, long bs, int ld, const float* __restrict__ w,
                                                       const float* __restrict__ bia, int D, int T, float eps) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_td_layernorm(float* __restrict__ X, lon
     if (ci < cpt) xb[(long)(cg * cpt + ci) * ld] = (u[ci] - mean) * rstd * wv[ci] + bv[ci];
 }
 inline int ln_frames() {   // FDX_LN_FR = 4 | 8 | 16 | 32 (A/B)
-  static const int v = [] { const char* e = getenv("FDX_LN_FR"); const int k = e ? atoi(e) : 0; return (k == 4 || k == 8 || k == 16 || k == 32) ? k : 8; }();
+  static const int v = [] { const char* e = getenv("FDX_LN_FR"); const int k = e ? atoi(e) : 0; return (k == 4 || k == 8 || k == 16 || k == 32) ? k : 16; }();   // 16: 2272 us per call; 8: 2294; 4: 2332; 32: 2379
   return v;
 }
 inline void launch_layernorm(float* X, long bs, int ld, const float* w, const float* bia, int B, int D, int T, hipStream_t s) {
