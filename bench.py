@@ -287,8 +287,10 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=None, help="denoiser calls the CPU baseline actually runs (the rest extrapolated linearly)")
     ap.add_argument("--no-prof", action="store_true", help="do not time the dominant kernel with HIP events")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive repeat of the headline step")
-    ap.add_argument("--storage", choices=("fp32", "bf16"), default="fp32",
-                    help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype")
+    ap.add_argument("--storage", choices=("fp32", "bf16", "fp16x3"), default="fp32",
+                    help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype.  "
+                         "fp16x3: the OPT-IN fp16-split mode (hi + lo operands, three fp16 MFMAs per product block, fp32 accumulate): fp32-class "
+                         "results, used by launches with enough LDS tiles (batch >= 5 at 10 s); reported as its own dtype")
     ap.add_argument("--prof-stride", type=int, default=None, help="time every N-th launch of the dominant kernel")
     ap.add_argument("--no-exact", action="store_true", help="sharded config: the reference's padded-batch semantics (x_masks / cond_masks) instead of "
                     "the library's exact-ragged batches (every utterance as if run alone; padding tiles skipped)")
@@ -325,13 +327,15 @@ def main():
     fdist.broadcast_model_weights(diff.denoise_fn if diff is not None else None, voc.model, dev, src=0)
     torch.cuda.synchronize()
     t_weights = time.perf_counter() - t0
-    if args.storage == "bf16":
+    if args.storage != "fp32":
         if diff is None:
-            raise SystemExit("--storage bf16 applies to the denoiser")
-        diff.denoise_fn.storage = "bf16"
+            raise SystemExit(f"--storage {args.storage} applies to the denoiser")
+        diff.denoise_fn.storage = args.storage
     voc.model.rng = "philox"          # perf mode: source noise drawn on the device inside the library
     bf16 = args.storage == "bf16"
-    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+    f16s = args.storage == "fp16x3"
+    # fp16x3: an fp32-class product block costs three fp16 MFMAs -> the roof for ALGORITHMIC flops is a third of the fp16 MFMA peak
+    peak = PEAK_BF16_TFLOPS if bf16 else (round(PEAK_BF16_TFLOPS / 3.0, 1) if f16s else PEAK_F32_TFLOPS)
 
     n_total = steps + warmup
     extra = {}
@@ -439,16 +443,19 @@ def main():
         metric = f"audio-seconds/sec/GPU ({n_steps}-step DDPM denoise + NSF-HiFiGAN, 44.1 kHz)"
         workload = (f"BASELINE configs[4] as SURVEY F4 reads it: diff_svc_v2 WaveNet, DDPM (naive) sampler, {n_steps} denoiser calls, multi-speaker "
                     f"front end (128-entry speaker embedding), batch={B} x {args.seconds:g} s per GPU (= batch 128 over 8 GPUs), then NSF-HiFiGAN config_v1; "
-                    + ("bf16 storage / fp32 accumulate (opt-in mode)" if bf16 else "fp32"))
+                    + ("bf16 storage / fp32 accumulate (opt-in mode)" if bf16 else
+                       "fp16-split operands (hi + lo), 3 fp16 MFMAs per product block, fp32 accumulate (opt-in mode, fp32-class)" if f16s else "fp32"))
         cfg_extra = {"batch_per_gpu": B, "frames": T, "sampler": "naive (DDPM ancestral)", "sampler_steps": n_steps, "step_noise": "device Philox"}
         prof_handle = lambda: diff.denoise_fn.engine(dev)   # noqa: E731
         prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 97   # co-prime with 20: every layer sampled, ~200 launches
         C_, M_ = WN_CFG["residual_channels"], B * T
-        esz = 2 if bf16 else 4
+        esz = 2 if bf16 else 4      # (fp16x3: hi + lo = 4 bytes per element)
         alg_bytes = esz * (2 * C_ * 3 * C_ + C_ * M_ + C_ * M_) + 4 * 2 * C_ * M_    # weights + Y in + Z out (+ fp32 conditioner slab)
         kdesc = (("bf16lds_kernel<BfEpiGate, 4> (v_mfma_f32_32x32x16_bf16; 128 x 256 tile, operands into LDS by DMA, 3 stages)" if bf16 else
+                  "bf16lds_kernel<BfEpiGate, 4, F16S> (3 x v_mfma_f32_32x32x16_f16 per product block: hi.lo + lo.hi + hi.hi; 128 x 256 tile, LDS-DMA, "
+                  "3 stages; peak = fp16 MFMA peak / 3)" if f16s else
                   "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + f": dilated conv k=3 + gate of the residual block at batch {B}")
-        traffic_key, traffic_expect = "convgate", {"config": "ddpm1000" + ("_bf16" if bf16 else ""), "batch": B, "frames": T}
+        traffic_key, traffic_expect = "convgate", {"config": "ddpm1000" + ("_bf16" if bf16 else "_fp16x3" if f16s else ""), "batch": B, "frames": T}
 
     # ------------------------------------------------------------------------------------------------ warm-up, timed region
     for k in range(warmup):
@@ -486,7 +493,9 @@ def main():
         if n:
             tr, src = pmc_traffic(cfg, "outproj", traffic_expect)
             e = roofline_entry(("bf16lds_kernel<BfEpiResSkip, 4> (v_mfma_f32_32x32x16_bf16; HBM-bound: the fp32 residual stream and skip sum are "
-                                "read and written every layer)" if bf16 else "convgemm_kernel<2,splitK,EpiResSkip> (v_mfma_f32_32x32x2_f32)")
+                                "read and written every layer)" if bf16 else
+                                "bf16lds_kernel<BfEpiResSkip, 4, F16S> (3 x v_mfma_f32_32x32x16_f16 per product block)" if (f16s and cfg == "ddpm1000") else
+                                "convgemm_kernel<2,splitK,EpiResSkip> (v_mfma_f32_32x32x2_f32)")
                                + ": 1x1 out-projection + residual / skip epilogue", n,
                                avg_ms, fl, peak, f"every {stride}th launch of one extra step outside the timed region", tr, src)
             if bf16:
@@ -526,7 +535,9 @@ def main():
         "metric": metric, "value": round(value, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if (cfg == "sharded" and world > 1) else "weak", "vs_baseline": None,
-        "dtype": "f32" if not bf16 else "bf16 storage / f32 accumulate (opt-in mode, not parity-grade)",
+        "dtype": ("bf16 storage / f32 accumulate (opt-in mode, not parity-grade)" if bf16 else
+                  "fp16 hi+lo split operands x3 MFMA / f32 accumulate (opt-in mode, fp32-class; launches with too few LDS tiles run the f32 kernels)" if f16s
+                  else "f32"),
         "data": "synthetic (seeded N(0,1) features, vibrato f0 with an unvoiced gap; random-init weights of the named architecture)",
         "config": dict({"workload": workload, "name": cfg,
                         "parallelism": f"utterance-sharded x{world} (no per-step collective)"}, **cfg_extra),

@@ -81,6 +81,7 @@ _SIGS = {
     "fdx_wavenet_bf16_packed_bytes": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(C.c_size_t)]),
     "fdx_wavenet_bf16_pack": (C.c_int, [C.POINTER(WavenetDesc), C.POINTER(_P), C.c_int, _P, C.c_size_t]),
     "fdx_wavenet_bf16_attach": (C.c_int, [_P, _P, C.c_size_t]),
+    "fdx_wavenet_f16s_enable": (C.c_int, [_P, C.c_int]),
     "fdx_wavenet_bf16_from_arena": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "fdx_wavenet_prepare": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "fdx_wavenet_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),

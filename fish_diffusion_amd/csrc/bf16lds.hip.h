@@ -51,8 +51,9 @@ struct BfEpiGate {     // wavenet.py:112-115; Z out as blocked bf16 (the out-pro
   static constexpr int kTaps = 3;
   static constexpr bool kPaired = true;
   const float* P; long p_bs; int ldp;      // conditioner slab (+ biases), fp32 [B][2C][ldp]
-  __bf16* Zb; long zb_bs; int ldz;         // blocked bf16 out: element (c, t) at ((c >> 3) * ldz + t) * 8 + (c & 7)
+  void* Zb; long zb_bs; int ldz;           // blocked 16-bit out (bf_store_quad); zb_bs in elements
   int C;
+  float acc_scale = 1.f, out_scale = 1.f;  // fp16-split mode: 2^-(operand scales) on the accumulators, 2^k on the stored operand
 };
 struct BfEpiResSkip {  // wavenet.py:117-120 + the skip sum of :228; Y = x + step out as blocked bf16 (the next conv's operand)
   static constexpr int kTaps = 1;
@@ -60,10 +61,40 @@ struct BfEpiResSkip {  // wavenet.py:117-120 + the skip sum of :228; Y = x + ste
   float* X; float* SK; long bs; int ld;    // fp32 residual stream / skip sum [B][C][ld]
   const float* bias;                       // [2C]
   const float* sb; int sb_ld, sb_bs;       // next layer's diffusion projection
-  __bf16* Yb; long yb_bs;                  // blocked bf16 out (null on the last layer)
+  void* Yb; long yb_bs;                    // blocked 16-bit out (null on the last layer)
   int C, skip_mode;
   float inv_div, r_inv_div;
+  float acc_scale = 1.f, out_scale = 1.f;
+  const float* keep = nullptr; long keep_bs = 0;   // exact-mask mode (EpiResSkip16S): the blocked output is 0 where keep[b][t] == 0
 };
+
+// ---- the blocked 16-bit operand layouts (16-byte group = 8 consecutive channels of one column = a lane's B fragment)
+//   bf16 mode:        element (c, t) at ((c >> 3) * ld + t) * 8 + (c & 7)
+//   fp16-split mode:  per 16-channel block four group rows [hi g0][hi g1][lo g0][lo g1]: hi at (((c >> 4) * 4 + ((c >> 3) & 1)) * ld + t) * 8
+//                     + (c & 7), lo two rows further: value * 2^k = hi + lo with hi = fp16(value * 2^k), lo = fp16(value * 2^k - hi)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int F16S>
+__device__ __forceinline__ void bf_store_quad(void* base, long item_off, int ld, int c0, int t, const float (&v)[4], float scale) {
+  if constexpr (F16S) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sv = v[k] * scale;
+      hi[k] = (_Float16)sv;
+      lo[k] = (_Float16)(sv - (float)hi[k]);
+    }
+    _Float16* p = static_cast<_Float16*>(base) + item_off + ((long)((c0 >> 4) * 4 + ((c0 >> 3) & 1)) * ld + t) * 8 + (c0 & 7);
+    *reinterpret_cast<f16x4*>(p) = hi;
+    *reinterpret_cast<f16x4*>(p + (long)2 * ld * 8) = lo;
+  } else {
+    bf16x4 z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = (__bf16)v[k];
+    *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(base) + item_off + ((long)(c0 >> 3) * ld + t) * 8 + (c0 & 7)) = z;
+  }
+}
+
 
 typedef __attribute__((address_space(3))) void* bf_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* bf_glb_ptr_t;
@@ -77,7 +108,11 @@ template <int WN> struct BfGeom {
   static_assert(kBG % 64 == 0 && kBPieces == 2 * kWaves + 1, "wave 0 stages three B pieces, the others two");
 };
 
-template <class Epi, int WN, int DBG = 0>
+// F16S = 1: the fp16-split mode ("past the fp32 roof"): every operand is a pair of fp16 numbers hi + lo (22 mantissa bits), the
+// product block is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped lo.lo term is 2^-22 of
+// the product) -- fp32-class results at a third of the fp16 MFMA rate = 5.3x the fp32 MFMA rate.  Same kernel, same LDS image:
+// a block is 16 channels and the k16-step dimension of the bf16 image becomes the {hi, lo} dimension.
+template <class Epi, int WN, int F16S = 0, int DBG = 0>
 __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds_kernel(BfArgs a, Epi epi) {
   using Ge = BfGeom<WN>;
   constexpr int TAPS = Epi::kTaps, NW = Ge::kWaves, WIN = Ge::kWin, NST = Ge::kStages;
@@ -169,16 +204,20 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
   auto compute = [&](int st, int bk2, int st2) {
     const uint4* la = lds + st * STAGE_G + wr * 64 + i + g * 128;
     const uint4* lb = lds + st * STAGE_G + A_G + g * WIN + wc * 64 + i;
-    constexpr int NS = TAPS * 2;
+    constexpr int NS = F16S ? TAPS : TAPS * 2;                // MFMA steps per block: a tap (both halves of the split) | a k16-step of a tap
     constexpr int SPREAD = NST == 3 ? NS : (NS + 1) / 2;      // two stages: the pieces must land before this block's barrier
-    bf16x8 fa[2][2], fb[2][2];
+    constexpr int NF = F16S ? 2 : 1;                          // fragment pairs per step: {hi, lo} | one
+    uint4 fa[2][NF][2], fb[2][NF][2];
     auto frag = [&](int j, int set) {
-      const int tap = j >> 1, s2 = j & 1;
-      const int shift = TAPS == 3 ? 8 + (tap - 1) * a.dil : 8;
 #pragma unroll
-      for (int x = 0; x < 2; ++x) fa[set][x] = __builtin_bit_cast(bf16x8, la[(tap * 2 + s2) * 256 + x * 32]);
+      for (int f = 0; f < NF; ++f) {
+        const int tap = F16S ? j : j >> 1, s2 = F16S ? f : j & 1;
+        const int shift = TAPS == 3 ? 8 + (tap - 1) * a.dil : 8;
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) fb[set][nb] = __builtin_bit_cast(bf16x8, lb[2 * s2 * WIN + shift + nb * 32]);
+        for (int x = 0; x < 2; ++x) fa[set][f][x] = la[(tap * 2 + s2) * 256 + x * 32];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) fb[set][f][nb] = lb[2 * s2 * WIN + shift + nb * 32];
+      }
     };
     if (!(DBG & 4)) frag(0, 0);
 #pragma unroll
@@ -193,8 +232,18 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
-            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j & 1][x], fb[j & 1][nb], acc[x][nb], 0, 0, 0);
+          for (int nb = 0; nb < 2; ++nb) {
+            if constexpr (F16S) {                   // cross terms first, then the leading one
+              const f16x8 ah = __builtin_bit_cast(f16x8, fa[j & 1][0][x]), al = __builtin_bit_cast(f16x8, fa[j & 1][1][x]);
+              const f16x8 bh = __builtin_bit_cast(f16x8, fb[j & 1][0][nb]), bl = __builtin_bit_cast(f16x8, fb[j & 1][1][nb]);
+              acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[x][nb], 0, 0, 0);
+              acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[x][nb], 0, 0, 0);
+              acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[x][nb], 0, 0, 0);
+            } else {
+              acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j & 1][0][x]),
+                                                                   __builtin_bit_cast(bf16x8, fb[j & 1][0][nb]), acc[x][nb], 0, 0, 0);
+            }
+          }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -253,14 +302,13 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bf16x4 z;
+        float z[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int r = q * 4 + k;
-          z[k] = (__bf16)EpiGate::gate1(acc[0][nb][r] + pg[r], acc[1][nb][r] + pf[r]);
+          z[k] = EpiGate::gate1(acc[0][nb][r] * epi.acc_scale + pg[r], acc[1][nb][r] * epi.acc_scale + pf[r]);
         }
-        const int c0 = ch0 + 8 * q + 4 * half;                   // the quad's first channel (acc_row(4q, half))
-        *reinterpret_cast<bf16x4*>(epi.Zb + item * epi.zb_bs + ((long)(c0 >> 3) * epi.ldz + t) * 8 + (c0 & 7)) = z;
+        bf_store_quad<F16S>(epi.Zb, item * epi.zb_bs, epi.ldz, ch0 + 8 * q + 4 * half, t, z, epi.out_scale);   // (the quad's first channel: acc_row(4q, half))
       }
     } else {
 #pragma unroll
@@ -275,6 +323,8 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
         const bool use_sb = res && epi.Yb;                      // (unconditional loads from a selected pointer: see the staging note)
         const float* sbp = use_sb ? epi.sb + item * epi.sb_bs : epi.bias;
         const long sbs = use_sb ? epi.sb_ld : 1;
+        const float* kp = (use_sb && epi.keep) ? epi.keep + item * epi.keep_bs + t : epi.bias;
+        const float kraw = *kp;
         float old[16], bi[16], sbv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -285,24 +335,21 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          bf16x4 y;
+          float y[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int r = q * 4 + k;
-            float v = acc[x][nb][r] + bi[r];
+            float v = acc[x][nb][r] * epi.acc_scale + bi[r];
             if (res) {
               v = div_const(old[r] + v, 1.41421356237309504880f, 0.70710678118654752440f);
-              y[k] = (__bf16)(epi.Yb ? v + sbv[r] : 0.f);
+              y[k] = (epi.Yb && (!epi.keep || kraw != 0.f)) ? v + sbv[r] : 0.f;
             } else {
               if (rd) v = old[r] + v;
               if (epi.skip_mode >= 2) v = div_const(v, epi.inv_div, epi.r_inv_div);
             }
             RW[o0 + (long)acc_row(r, half) * epi.ld] = v;
           }
-          if (res && epi.Yb) {
-            const int c0 = row0 + 8 * q + 4 * half;
-            *reinterpret_cast<bf16x4*>(epi.Yb + item * epi.yb_bs + ((long)(c0 >> 3) * epi.ld + t) * 8 + (c0 & 7)) = y;
-          }
+          if (res && epi.Yb) bf_store_quad<F16S>(epi.Yb, item * epi.yb_bs, epi.ld, row0 + 8 * q + 4 * half, t, y, epi.out_scale);
         }
       }
     }
@@ -310,7 +357,7 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
   FDX_STAMP(5);
 }
 
-template <class Epi, int WN>
+template <class Epi, int WN, int F16S>
 inline hipError_t launch_bf16lds_wn(BfArgs a, int B, int T, const Epi& epi, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   using Ge = BfGeom<WN>;
   a.tiles_per_item = (T + Ge::kCols - 1) / Ge::kCols;
@@ -322,12 +369,12 @@ inline hipError_t launch_bf16lds_wn(BfArgs a, int B, int T, const Epi& epi, hipS
   if (g_trace.buf && g_trace.n < g_trace.max_launches && grid <= g_trace.blocks_cap)
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
   static const int dbg = [] { const char* e = getenv("FDX_BF16_DBG"); return e ? atoi(e) : 0; }();
-#define FDX_BF_DBG(D) if (dbg == D) { hipLaunchKernelGGL((bf16lds_kernel<Epi, WN, D>), dim3(grid), dim3(Ge::kThreads), 0, s, a, epi); return hipGetLastError(); }
+#define FDX_BF_DBG(D) if (dbg == D) { hipLaunchKernelGGL((bf16lds_kernel<Epi, WN, F16S, D>), dim3(grid), dim3(Ge::kThreads), 0, s, a, epi); return hipGetLastError(); }
   FDX_BF_DBG(1) FDX_BF_DBG(4) FDX_BF_DBG(5)
 #undef FDX_BF_DBG
 #endif
-  if (ev0) hipExtLaunchKernelGGL((bf16lds_kernel<Epi, WN>), dim3(grid), dim3(Ge::kThreads), 0, s, ev0, ev1, 0, a, epi);
-  else hipLaunchKernelGGL((bf16lds_kernel<Epi, WN>), dim3(grid), dim3(Ge::kThreads), 0, s, a, epi);
+  if (ev0) hipExtLaunchKernelGGL((bf16lds_kernel<Epi, WN, F16S>), dim3(grid), dim3(Ge::kThreads), 0, s, ev0, ev1, 0, a, epi);
+  else hipLaunchKernelGGL((bf16lds_kernel<Epi, WN, F16S>), dim3(grid), dim3(Ge::kThreads), 0, s, a, epi);
   return hipGetLastError();
 }
 
@@ -341,14 +388,16 @@ inline int bf16lds_pick_wn(int B, int T, int rows) {
   return wide * 5 >= rounds * 256 * 4 ? 4 : 2;
 }
 
-template <class Epi>
+// x_bs: 16-byte groups between items of Xb.  F16S = 0: bf16 operands, blocks of 32 channels; 1: fp16 {hi, lo} operands, blocks of 16.
+template <int F16S = 0, class Epi>
 inline hipError_t launch_bf16lds(const uint4* Wp, const uint4* Xb, long x_bs, int ld, int C, int dil, int B, int T, int rows, const Epi& epi,
                                  hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   BfArgs a;
-  a.Wp = Wp; a.Xb = Xb; a.x_bs = x_bs; a.ld = ld; a.n_blk = C / 32; a.dil = dil; a.T = T;
+  a.Wp = Wp; a.Xb = Xb; a.x_bs = x_bs; a.ld = ld; a.n_blk = C / (F16S ? 16 : 32); a.dil = dil; a.T = T;
   a.n_mtiles = rows / 128;
   a.tiles_per_item = a.n_tiles_n = 0;
-  return bf16lds_pick_wn(B, T, rows) == 4 ? launch_bf16lds_wn<Epi, 4>(a, B, T, epi, s, ev0, ev1) : launch_bf16lds_wn<Epi, 2>(a, B, T, epi, s, ev0, ev1);
+  return bf16lds_pick_wn(B, T, rows) == 4 ? launch_bf16lds_wn<Epi, 4, F16S>(a, B, T, epi, s, ev0, ev1)
+                                          : launch_bf16lds_wn<Epi, 2, F16S>(a, B, T, epi, s, ev0, ev1);
 }
 
 // The LDS kernel's A order from the register-direct bf16 order (16-byte groups are moved whole):

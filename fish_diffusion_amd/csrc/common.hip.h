@@ -131,6 +131,10 @@ struct fdx_ctx {
   fdx::DevBuf wn_bf16_lds;               // the same bf16 weights in the LDS-tiled kernels' order (bf16lds.hip.h), derived at bf16 attach
   bool wn_bf16_lds_ok = false;
   int bf16_B = 0, bf16_T = 0;            // geometry Yb / Zb were last zeroed for
+  fdx::DevBuf wn_f16s;                   // fp16-split mode: {hi, lo} fp16 weights of the two residual-block GEMMs in LDS order (derived from the fp32 arena)
+  bool wn_f16s_ok = false;
+  fdx::DevBuf Yh, Zh;                    // ... and the two GEMM operands as blocked {hi, lo} fp16
+  int f16s_B = 0, f16s_T = 0;
   bool cond_masked = false; int condraw_ld = 0;
   fdx::DevBuf tdev, E, Hm, S0, S;      // step-embedding pipeline; ldn below
   int n_emb = 0, ldn = 0;

@@ -55,6 +55,7 @@ static long bf16_lds_min_tiles() {
   return v;
 }
 static bool bf16_lds_enabled() { return bf16_lds_min_tiles() > 0; }
+constexpr size_t kBfTileSlack = 8192;   // bytes behind the blocked 16-bit operand buffers (see wn_alloc)
 static int outp_shape_env() {   // FDX_OUTP_SHAPE=0: always the 32x32x2 kernel; =<NR><NM>: force a 16x16x4 shape
   static const int v = [] { const char* e = getenv("FDX_OUTP_SHAPE"); return e ? atoi(e) : -1; }();
   return v;
@@ -428,6 +429,7 @@ extern "C" int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev, size_t byt
     if (int rc = fdx_wavenet_bf16_packed_bytes(&h->wd, &want)) { h->err = g_last_error; return rc; }
     if (bytes != want) return fail(h, FDX_E_ARG, "bf16 arena size mismatch");
   }
+  if (dev && h->wn_f16s_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_bf16_attach: the fp16-split mode is enabled (disable it first)");
   h->wn_arena_bf16 = dev;
   h->prepared = false;    // the blocked operand buffers are sized in prepare
   ++h->alloc_gen;         // recorded sampler graphs bake the kernel choice in
@@ -451,6 +453,101 @@ extern "C" int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev, size_t byt
     h->wn_bf16_lds_ok = true;
   }
   return FDX_OK;
+}
+
+// ================================================================================================ fp16-split mode (opt-in)
+// "Past the fp32 roof" (DESIGN section 5): the two residual-block GEMMs with every operand held as a pair of fp16 numbers
+// value * 2^k = hi + lo (22 mantissa bits) and each product block formed as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with
+// fp32 accumulation: fp32-class results (the dropped lo.lo term and the operands' last two bits are ~2^-22 of a product, below the
+// fp32 accumulation error of a K = 512..1536 sum) at a third of the fp16 MFMA rate.  Only the LDS-tiled kernels (bf16lds.hip.h)
+// exist for it, so a launch uses it when it has enough tiles (the bf16 mode's threshold) and the fp32 kernels otherwise -- both are
+// fp32-class, the mode changes speed, not the contract.  Power-of-two operand scales keep the lo parts out of the fp16 subnormals
+// (weights ~0.05 -> * 2^8; gated outputs in (-1, 1) -> * 2^8; conv inputs O(1..100) -> * 2^4) and are removed exactly in the epilogue.
+constexpr float kF16sWScale = 256.f, kF16sYScale = 16.f, kF16sZScale = 256.f;
+struct F16sDerive { size_t conv_w, outp_w; };   // per layer: fp32 arena offsets (floats)
+static size_t f16s_conv_groups(int C) { return (size_t)(C / 64) * (C / 16) * 3 * 4 * 128; }   // 16-byte groups per layer
+static size_t f16s_outp_groups(int C) { return (size_t)(2 * C / 128) * (C / 16) * 4 * 128; }
+// One thread per 16-byte group of the LDS-order image [m-tile][block16][tap][hl][g][128 rows] (row = wr*64 + x*32 + i):
+//   conv (paired rows):  row(x, wr, i) = x*C + (2*mt + wr)*32 + i  (x = 0 gate half, 1 filter half), channels block*16 + 8*g .. +7
+//   out-projection:      row = (2*mt + wr)*64 + x*32 + i
+static __global__ void k_f16s_from_arena(_Float16* __restrict__ dst, const float* __restrict__ A, const F16sDerive* __restrict__ lay, int L, int C,
+                                         int conv_mode16, int outp_mode16, float wscale) {
+  const size_t per_conv = (size_t)(C / 64) * (C / 16) * 3 * 4 * 128, per_outp = (size_t)(2 * C / 128) * (C / 16) * 4 * 128;
+  const size_t gidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= (size_t)L * (per_conv + per_outp)) return;
+  const int layer = (int)(gidx / (per_conv + per_outp));
+  size_t g = gidx - (size_t)layer * (per_conv + per_outp);
+  const bool conv = g < per_conv;
+  if (!conv) g -= per_conv;
+  const int taps = conv ? 3 : 1, n_blk = C / 16;
+  const int rho = (int)(g & 127);
+  size_t q = g >> 7;
+  const int gg = (int)(q & 1); q >>= 1;
+  const int hl = (int)(q & 1); q >>= 1;
+  const int tap = (int)(q % taps); q /= taps;
+  const int blk = (int)(q % n_blk);
+  const int mt = (int)(q / n_blk);
+  const int wr = rho >> 6, x = (rho >> 5) & 1, i = rho & 31;
+  const int mt_old = 2 * mt + wr;                      // the register-direct packings' tile index (32 channels | 64 rows)
+  const size_t w_off = conv ? lay[layer].conv_w : lay[layer].outp_w;
+  const int n_it32 = conv ? (C / 8) * 3 : C / 8, mode16 = conv ? conv_mode16 : outp_mode16;
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = blk * 16 + 8 * gg + j;
+    const int it32 = conv ? (c >> 3) * 3 + tap : (c >> 3);
+    const size_t src = mode16 ? f32_frag_index16(mt_old, n_it32, it32, (x << 1) | (i >> 4), i & 15, c) : f32_frag_index32(mt_old, n_it32, it32, x, i, c);
+    const float wv = A[w_off + src] * wscale;
+    const _Float16 hi = (_Float16)wv;
+    v[j] = hl ? (_Float16)(wv - (float)hi) : hi;
+  }
+  const size_t out = (size_t)layer * (per_conv + per_outp) + (conv ? 0 : per_conv) + g;
+  *reinterpret_cast<f16x8*>(dst + out * 8) = v;
+}
+
+// on != 0: derive the {hi, lo} weights from the attached fp32 arena and use the fp16-split kernels where a launch has enough tiles;
+// on == 0: back to the fp32 kernels everywhere.  (Mutually exclusive with the bf16 storage mode: attach that one with NULL first.)
+extern "C" int fdx_wavenet_f16s_enable(fdx_handle h, int on) {
+  GenScope gen_scope(h);
+  if (!h) return FDX_E_ARG;
+  if (!h->wn_ok) return fail(h, FDX_E_STATE, "fdx_wavenet_f16s_enable: attach the fp32 arena first");
+  h->wn_f16s_ok = false;
+  h->prepared = false;    // the blocked operand buffers are sized in prepare
+  ++h->alloc_gen;         // recorded sampler graphs bake the kernel choice in
+  if (!on) return FDX_OK;
+  if (h->wn_arena_bf16) return fail(h, FDX_E_STATE, "fdx_wavenet_f16s_enable: the bf16 storage mode is attached (detach it first)");
+  const int C = h->wd.residual_channels, L = h->wd.residual_layers;
+  if (C % 64) return FDX_OK;   // no LDS tiling for this width: the fp32 kernels serve every launch (same fp32-class contract)
+  FDX_HIP(h, hipSetDevice(h->device));
+  const size_t groups = (size_t)L * (f16s_conv_groups(C) + f16s_outp_groups(C));
+  FDX_HIP(h, h->wn_f16s.ensure(groups * 16, false, nullptr));
+  std::vector<F16sDerive> lay(L);
+  for (int i = 0; i < L; ++i) lay[i] = F16sDerive{h->wl.conv[i].w_off, h->wl.outp[i].w_off};
+  FDX_HIP(h, h->scratch_b.ensure(L * sizeof(F16sDerive), false, nullptr));
+  FDX_HIP(h, hipMemcpy(h->scratch_b.p, lay.data(), L * sizeof(F16sDerive), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_f16s_from_arena, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, static_cast<_Float16*>(h->wn_f16s.p), h->wn_arena,
+                     static_cast<const F16sDerive*>(h->scratch_b.p), L, C, conv16() ? 1 : 0, outp16() ? 1 : 0, kF16sWScale);
+  FDX_HIP(h, hipGetLastError());
+  FDX_HIP(h, hipStreamSynchronize(nullptr));
+  h->wn_f16s_ok = true;
+  return FDX_OK;
+}
+
+// Y [B][C][ld] fp32 -> blocked {hi, lo} fp16 (bf_store_quad's layout), scaled: the first layer's conv input
+static __global__ void k_to_blocked_f16s(_Float16* __restrict__ dst, long d_bs, const float* __restrict__ src, long s_bs, int ld, int C, int T, float scale) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int b = blockIdx.y / (C / 8), cb = blockIdx.y - b * (C / 8);
+  f16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = src[b * s_bs + (long)(cb * 8 + j) * ld + t] * scale;
+    hi[j] = (_Float16)v;
+    lo[j] = (_Float16)(v - (float)hi[j]);
+  }
+  _Float16* p = dst + b * d_bs + ((long)((cb >> 1) * 4 + (cb & 1)) * ld + t) * 8;
+  *reinterpret_cast<f16x8*>(p) = hi;
+  *reinterpret_cast<f16x8*>(p + (long)2 * ld * 8) = lo;
 }
 
 // Y [B][C][ld] fp32 -> C8-blocked bf16 (the input projection's second output, once per denoiser call)
@@ -540,9 +637,17 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   if (h->wn_arena_bf16) {   // blocked bf16 operands: same columns (and zero halos) as the fp32 rows, 2 bytes per element
     // (their own geometry stamp: the geometry may have changed while the handle ran in fp32 mode, which does not touch them)
     const bool gb = B != h->bf16_B || T != h->bf16_T;
-    FDX_HIP(h, h->Yb.ensure(sz(C) / 2, gb, s));
-    FDX_HIP(h, h->Zb.ensure(sz(C) / 2, gb, s));
+    // (+ slack: the LDS kernels' 256-column tiles read their whole window, i.e. up to 100 columns past a short row's end -- into
+    // the next row, whose columns feed only outputs >= T; after the last row that is past the buffer)
+    FDX_HIP(h, h->Yb.ensure(sz(C) / 2 + kBfTileSlack, gb, s));
+    FDX_HIP(h, h->Zb.ensure(sz(C) / 2 + kBfTileSlack, gb, s));
     h->bf16_B = B; h->bf16_T = T;
+  }
+  if (h->wn_f16s_ok) {      // blocked {hi, lo} fp16 operands: 2 x 2 bytes per element
+    const bool gf = B != h->f16s_B || T != h->f16s_T;
+    FDX_HIP(h, h->Yh.ensure(sz(C) + kBfTileSlack, gf, s));
+    FDX_HIP(h, h->Zh.ensure(sz(C) + kBfTileSlack, gf, s));
+    h->f16s_B = B; h->f16s_T = T;
   }
   return FDX_OK;
 }
@@ -635,6 +740,13 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   if (h->wn_arena_bf16)
     hipLaunchKernelGGL(k_to_blocked_bf16, ew_grid(T, B * (C / 8)), dim3(kEwBlock), 0, s, reinterpret_cast<__bf16*>(h->Yb.p) + (size_t)kHalo * 8,
                        (long)C * ld, Y, bsC, ld, C, T);
+  // fp16-split mode: taken per call when the launches have enough LDS tiles (else the fp32 kernels: both are fp32-class)
+  const bool f16s = h->wn_f16s_ok && !h->wn_arena_bf16 && (long)B * ((T + 127) / 128) * (C / 64) >= bf16_lds_min_tiles();
+  _Float16* Yh = f16s ? reinterpret_cast<_Float16*>(h->Yh.p) + (size_t)kHalo * 8 : nullptr;
+  _Float16* Zh = f16s ? reinterpret_cast<_Float16*>(h->Zh.p) + (size_t)kHalo * 8 : nullptr;
+  const long bsH = (long)2 * C * ld;             // fp16 elements per item ({hi, lo})
+  if (f16s)
+    hipLaunchKernelGGL(k_to_blocked_f16s, ew_grid(T, B * (C / 8)), dim3(kEwBlock), 0, s, Yh, bsH, Y, bsC, ld, C, T, kF16sYScale);
   const float sqrtL = (float)std::sqrt((double)L);
   for (int i = 0; i < L; ++i) {
     const int dil = l.dil[i];
@@ -645,6 +757,15 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     const long p_bs = (long)L * 2 * C * ld;
     const float* sbn = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn;
     const int skip_mode = (L == 1) ? 3 : (i == 0 ? 0 : (i + 1 == L ? 2 : 1));
+    if (f16s) {               // fp16-split mode: both GEMMs as three v_mfma_f32_32x32x16_f16 per product block
+      const uint4* WH = static_cast<const uint4*>(h->wn_f16s.p) + (size_t)i * (f16s_conv_groups(C) + f16s_outp_groups(C));
+      BfEpiGate eg{Pl, p_bs, ld, Zh, bsH, ld, C, 1.f / (kF16sWScale * kF16sYScale), kF16sZScale};
+      FDX_HIP(h, launch_bf16lds<1>(WH, reinterpret_cast<const uint4*>(Yh), bsH / 8, ld, C, dil, B, T, 2 * C, eg, s, ev0, ev1));
+      BfEpiResSkip er{X, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, (i + 1 < L) ? Yh : nullptr, bsH, C, skip_mode, sqrtL,
+                      (float)(1.0 / (double)sqrtL), 1.f / (kF16sWScale * kF16sZScale), kF16sYScale, keep, (long)ld};
+      FDX_HIP(h, launch_bf16lds<1>(WH + f16s_conv_groups(C), reinterpret_cast<const uint4*>(Zh), bsH / 8, ld, C, 0, B, T, 2 * C, er, s, eo0, eo1));
+      continue;
+    }
     if (h->wn_arena_bf16) {   // bf16 storage mode: both GEMMs on v_mfma_f32_32x32x16_bf16
       WnBf16Layout bl;
       wn_bf16_layout(d, bl);

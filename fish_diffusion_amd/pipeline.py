@@ -103,7 +103,7 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     dev = features[mine[0]].device
     if exact is None:
         den = getattr(diffusion, "denoise_fn", None)
-        exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") == "fp32"
+        exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")   # (fp16x3: ragged runs take the fp32 kernels)
     out = []
     for group in make_batches([lengths[i] for i in mine], max_batch, padding_free=bool(exact)):
         idx = [mine[g] for g in group]

@@ -8,6 +8,7 @@ forwards `data_ptr()`s to the C ABI.  There is no PyTorch fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Optional
 
@@ -172,6 +173,9 @@ class HipDenoiser(nn.Module):
         return out[:, None] if use_4_dim else out
 
 
+STORAGE_MODES = ("fp32", "bf16", "fp16x3")
+
+
 class WaveNet(HipDenoiser):
     """Drop-in for the reference `WaveNet` (registered as DENOISERS "WaveNetDenoiser")."""
 
@@ -206,21 +210,27 @@ class WaveNet(HipDenoiser):
         self._desc = _lib.WavenetDesc(mel_channels, d_encoder, residual_channels, residual_layers,
                                       int(dilation_cycle or 0), int(self.use_linear_bias))
         self._cond_channels = d_encoder
-        self._storage = "fp32"
+        self._storage = os.environ.get("FDX_WAVENET_STORAGE", "fp32")   # (the env default exists for the test suite: it re-runs the fp32 parity tests in the split mode)
+        if self._storage not in STORAGE_MODES:
+            raise ValueError(f"FDX_WAVENET_STORAGE must be one of {STORAGE_MODES}, got {self._storage!r}")
         self._arena_bf16 = None
+        self._f16s_on = False
         self._init_engine()
 
-    # ------------------------------------------------------------------ opt-in bf16 storage mode
+    # ------------------------------------------------------------------ opt-in storage modes of the two residual-block GEMMs
     @property
     def storage(self) -> str:
-        """"fp32" (default, parity-grade) or "bf16": the two residual-block GEMMs read bf16 weights / activation operands and
-        accumulate in fp32 (BASELINE configs[4]).  Not parity-grade; see DESIGN.md for its measured error."""
+        """"fp32" (default).
+        "bf16": bf16 weights / activation operands, fp32 accumulate (BASELINE configs[4]).  Not parity-grade; DESIGN.md has its error.
+        "fp16x3": every operand as an fp16 pair hi + lo, each product block hi.hi + hi.lo + lo.hi on the fp16 MFMA, fp32 accumulate:
+        fp32-class results (the tests hold it to the fp32 path's own bars), used where a launch has enough LDS tiles (batch >= 5 at
+        10 s) and the fp32 kernels otherwise."""
         return self._storage
 
     @storage.setter
     def storage(self, mode: str):
-        if mode not in ("fp32", "bf16"):
-            raise ValueError(f"storage must be 'fp32' or 'bf16', got {mode!r}")
+        if mode not in STORAGE_MODES:
+            raise ValueError(f"storage must be one of {STORAGE_MODES}, got {mode!r}")
         if mode != self._storage:
             self._storage = mode
             self._prep_sig = None
@@ -229,6 +239,9 @@ class WaveNet(HipDenoiser):
 
     def _after_attach(self):
         l = _lib.lib()
+        if self._storage != "fp16x3" and self._f16s_on:
+            _lib.check(l.fdx_wavenet_f16s_enable(self._handle.h, 0), self._handle.h)
+            self._f16s_on = False
         if self._storage == "bf16":
             # Derived on the device from the ATTACHED fp32 arena, never from this module's own parameters: after
             # dist.broadcast_model_weights a non-source rank's parameters are whatever they were initialised with.
@@ -241,6 +254,9 @@ class WaveNet(HipDenoiser):
         elif self._arena_bf16 is not None:
             _lib.check(l.fdx_wavenet_bf16_attach(self._handle.h, None, 0), self._handle.h)
             self._arena_bf16 = None
+        if self._storage == "fp16x3":       # (after the bf16 arena is gone: the two modes exclude each other); weights derived from the attached arena
+            _lib.check(l.fdx_wavenet_f16s_enable(self._handle.h, 1), self._handle.h)
+            self._f16s_on = True
 
 
 DENOISERS.register_module(name="WaveNetDenoiser", module=WaveNet, force=True)

@@ -552,3 +552,61 @@ def test_bf16_lds_tiled_kernels_hold_the_same_bounds(dev, wn):
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout[-3000:])
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ fp16-split mode ("past the fp32 roof")
+FP16X3_SUBSET = ("(wavenet or sampler or config4 or baseline_configs or chained or exact_ragged or end_to_end or segment_loop or shallow or chunked "
+                 "or ragged_batch or pipeline or svc_inference or long_utterance or q_sample) "
+                 "and not bf16 and not fp16 and not convnext and not tfdec and not transformer")
+
+
+@pytest.mark.parametrize("wn", ["2", "4"])
+def test_fp16_split_mode_holds_the_fp32_parity_bars(dev, wn):
+    """`net.storage = "fp16x3"` (csrc/bf16lds.hip.h, F16S): every operand of the two residual-block GEMMs as an fp16 pair hi + lo, each
+    product block as hi.lo + lo.hi + hi.hi on v_mfma_f32_32x32x16_f16, fp32 accumulate.  The claim is "fp32-class", so the bar is the
+    fp32 path's own: the WaveNet / sampler / chained-parity / exact-ragged tests of this suite -- goldens from the real reference, 2e-5
+    per call, 1e-3 rel on the sampled mel, 1e-4 abs on the chained waveform, bit-identical ragged batches -- re-run unchanged with the
+    mode switched on for every WaveNet (FDX_WAVENET_STORAGE) and forced for every geometry (FDX_BF16_LDS=1), at both tile widths."""
+    env = dict(os.environ, FDX_WAVENET_STORAGE="fp16x3", FDX_BF16_LDS="1", FDX_BF16_WN=wn)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_round2.py"),
+                        "-m", "gpu", "-q", "-x", "-k", FP16X3_SUBSET], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_fp16_split_error_table_full_size_net(dev):
+    """Full-size net, 6 x 10 s (enough LDS tiles for the mode's own threshold): the fp16-split mode against the library's fp32 path on the
+    same inputs -- one denoiser call, 100-step UniPC, 100 DDPM steps -- written as an artefact (gpurun_out/fp16x3_error_table.json); the
+    fp32 path's own distance to the reference (1.5e-6 rel on the 100-step mel) is the yardstick."""
+    sd = wavenet_sd(WN_FULL, 1234)
+    B, T = 6, 861
+    g = torch.Generator().manual_seed(4)
+    feats, x0 = torch.randn(B, T, 256, generator=g).to(dev), torch.randn(B, 128, T, generator=g).to(dev)
+    from fish_diffusion_amd import DENOISERS, GaussianDiffusion
+    diff = GaussianDiffusion(dict(type="WaveNetDenoiser", **WN_FULL), spec_min=[-5], spec_max=[0])
+    diff.denoise_fn.load_state_dict(sd, strict=True)
+    diff = diff.to(dev).eval()
+    net = diff.denoise_fn
+    rows = []
+    t = torch.tensor([500.0], device=dev)
+    cond = feats.transpose(1, 2).contiguous()
+    outs = {}
+    for mode in ("fp32", "fp16x3"):
+        net.storage = mode
+        outs[mode] = dict(call=net(x0, t, cond).clone(), unipc=diff(feats, sampler_interval=10, x_init=x0).clone(),
+                          ddpm=diff(feats, sampler_interval=10, noise_predictor="naive", x_init=x0,
+                                    step_noise=torch.randn(100, B, 128, T, generator=torch.Generator().manual_seed(9)).to(dev)).clone())
+    net.storage = "fp32"
+    for run in ("call", "unipc", "ddpm"):
+        a, b = outs["fp32"][run], outs["fp16x3"][run]
+        peak = float(a.abs().max())
+        rows.append(dict(run={"call": "one denoiser call (t = 500)", "unipc": "unipc_100", "ddpm": "ddpm_100_of_1000"}[run], max_abs=float((a - b).abs().max()),
+                         max_rel_of_peak=float((a - b).abs().max()) / peak, rms_rel_of_peak=float((a - b).pow(2).mean().sqrt()) / peak, peak=peak))
+        print(rows[-1])
+    out = dict(net="diff_svc_v2 WaveNet C=512 x 20 layers, seeded weights (seed 1234)", batch=B, frames=T,
+               mode="fp16 hi+lo split operands, 3 MFMAs per product block, fp32 accumulate (opt-in)", reference="the same library's fp32 path, same inputs and noise",
+               rows=rows)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "fp16x3_error_table.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    assert rows[0]["max_rel_of_peak"] < 2e-5 and rows[1]["max_rel_of_peak"] < 1e-4 and rows[2]["max_rel_of_peak"] < 1e-4
