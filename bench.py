@@ -415,8 +415,9 @@ def main():
         prof_handle = lambda: diff.denoise_fn.engine(dev)   # noqa: E731
         prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 7
         alg_bytes = None
-        kdesc = "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32): dilated conv k=3 + gate of the residual block (masked micro-batches)"
-        traffic_key, traffic_expect = "convgate", {"config": "sharded", "batch": B, "frames": max(lens[i] for i in mine)}
+        kdesc = (("bf16lds_kernel<BfEpiGate, WN, F16S> (3 x v_mfma_f32_32x32x16_f16 per product block; peak = fp16 MFMA peak / 3)" if f16s else
+                  "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + ": dilated conv k=3 + gate of the residual block (masked micro-batches)")
+        traffic_key, traffic_expect = "convgate", {"config": "sharded" + ("_fp16x3" if f16s else ""), "batch": B, "frames": max(lens[i] for i in mine)}
     else:  # ddpm1000
         from fish_diffusion_amd import DiffSinger, pitch_to_scale
         B = args.batch or 16

@@ -28,7 +28,8 @@ def main():
     cfg = sys.argv[3] if len(sys.argv) > 3 else "headline"
     workloads = {"headline": {"config": "headline", "batch": 1, "frames": 861}, "vocoder": {"config": "vocoder", "batch": 32, "frames": 1722},
                  "sharded": {"config": "sharded", "batch": 8, "frames": 861}, "ddpm1000": {"config": "ddpm1000", "batch": 16, "frames": 861},
-                 "ddpm1000_bf16": {"config": "ddpm1000_bf16", "batch": 16, "frames": 861}}
+                 "ddpm1000_bf16": {"config": "ddpm1000_bf16", "batch": 16, "frames": 861},
+                 "ddpm1000_fp16x3": {"config": "ddpm1000_fp16x3", "batch": 16, "frames": 861}}
     out = {"source": {"fetch_db": sys.argv[1], "write_db": sys.argv[2]}, "workload": workloads[cfg],
            "note": "bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024",
            "kernels": {}}

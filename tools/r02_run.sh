@@ -11,10 +11,10 @@ for what in "$@"; do
            python bench.py --config ddpm1000 --storage bf16 > $O/bench_ddpm1000_bf16.json 2> $O/bench_ddpm1000_bf16.err; echo "bf16 rc $?" ;;
     headline) python bench.py > $O/bench_headline.json 2> $O/bench_headline.err; echo "headline rc $?"; tail -n 3 $O/bench_headline.err ;;
     rccl) FDX_FORCE_PROCESS_GROUP=1 NCCL_DEBUG=INFO python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/rccl_world1.json 2> $O/rccl_world1.err; echo "rccl rc $?" ;;
-    prof-*) c=${what#prof-}; extra=""; [ "$c" = "ddpm1000_bf16" ] && { c=ddpm1000; extra="--storage bf16"; }
+    prof-*) c=${what#prof-}; extra=""; [ "$c" = "ddpm1000_bf16" ] && { c=ddpm1000; extra="--storage bf16"; }; [ "$c" = "ddpm1000_fp16x3" ] && { c=ddpm1000; extra="--storage fp16x3"; }
             ( cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_${what#prof-} -o p -- python $GRAFT_REPO_ROOT/bench.py --config $c $extra --no-cpu-baseline --no-pcie > $GRAFT_REPO_ROOT/$O/bench_${what#prof-}_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/prof_${what#prof-}.log )
             db=$(ls $O/prof_${what#prof-}/*/*.db $O/prof_${what#prof-}/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db > $O/${what#prof-}_kernel_stats.txt; head -n 12 $O/${what#prof-}_kernel_stats.txt; rm -rf $O/prof_${what#prof-} ;;
-    pmc-*) c=${what#pmc-}; cfg=$c; extra=""; [ "$c" = "ddpm1000_bf16" ] && { cfg=ddpm1000; extra="--storage bf16"; }
+    pmc-*) c=${what#pmc-}; cfg=$c; extra=""; [ "$c" = "ddpm1000_bf16" ] && { cfg=ddpm1000; extra="--storage bf16"; }; [ "$c" = "ddpm1000_fp16x3" ] && { cfg=ddpm1000; extra="--storage fp16x3"; }
            steps="--steps 1 --warmup 1"; [ "$cfg" = "ddpm1000" ] && steps="--steps 1 --warmup 1 --interval 10"   # 100 of the 1000 steps: same launches
            for ctr in FETCH_SIZE WRITE_SIZE; do
              ( cd /tmp && rocprofv3 --pmc $ctr -d $GRAFT_REPO_ROOT/$O/pmc_${c}_$ctr -o p -- python $GRAFT_REPO_ROOT/bench.py --config $cfg $extra $steps --no-cpu-baseline --no-pcie --no-prof > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_${c}_$ctr.log )
