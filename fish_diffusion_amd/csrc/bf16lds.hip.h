@@ -104,8 +104,7 @@ typedef const __attribute__((address_space(1))) void* bf_glb_ptr_t;
 // bytes staged per MFMA drop by 37 % and the third stage lets a block's DMA run two blocks ahead.
 template <int WN> struct BfGeom {
   static constexpr int kWaves = 2 * WN, kThreads = 64 * kWaves, kCols = 64 * WN, kWin = kCols + 16, kStages = WN == 4 ? 3 : 2;
-  static constexpr int kBG = 4 * kWin, kBPieces = kBG / 64;                  // B window per block, in 16-byte groups / 1-KiB pieces
-  static_assert(kBG % 64 == 0 && kBPieces == 2 * kWaves + 1, "wave 0 stages three B pieces, the others two");
+  static_assert((4 * kWin) % 64 == 0, "whole 1-KiB pieces per 4-row window");
 };
 
 // F16S = 1: the fp16-split mode ("past the fp32 roof"): every operand is a pair of fp16 numbers hi + lo (22 mantissa bits), the
@@ -116,10 +115,15 @@ template <class Epi, int WN, int F16S = 0, int DBG = 0>
 __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds_kernel(BfArgs a, Epi epi) {
   using Ge = BfGeom<WN>;
   constexpr int TAPS = Epi::kTaps, NW = Ge::kWaves, WIN = Ge::kWin, NST = Ge::kStages;
-  constexpr int A_G = TAPS * 2 * 2 * 128;           // 16-byte groups of A per block
-  constexpr int A_LD = A_G / (64 * NW);             // A pieces per wave per block
-  constexpr int STAGE_G = A_G + Ge::kBG;
-  static_assert(A_G % (64 * NW) == 0, "whole A pieces per wave");
+  // SUB: 16-channel sub-blocks per stage.  The split mode's out-projection (one tap) takes two: 12 MFMAs per wave between barriers
+  // did not cover a stage's DMA and barrier (K loop 41.7 k cycles against 24.6 k of MFMAs).
+  constexpr int SUB = (F16S && TAPS == 1) ? 2 : 1;
+  constexpr int A_G = SUB * TAPS * 2 * 2 * 128;     // 16-byte groups of A per stage
+  constexpr int B_G = SUB * 4 * WIN;                // ... of B: 4 group rows per (sub-)block
+  constexpr int A_LD = A_G / (64 * NW);             // A pieces (1 KiB) per wave per stage
+  constexpr int B_P = B_G / 64, QB = B_P / NW, RB = B_P % NW;   // B pieces: QB per wave, one more on waves < RB
+  constexpr int STAGE_G = A_G + B_G;
+  static_assert(A_G % (64 * NW) == 0 && B_G % 64 == 0, "whole pieces");
   __shared__ uint4 lds[NST * STAGE_G];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -159,14 +163,15 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
   // ---- staging: global -> LDS directly (global_load_lds_dwordx4: one wave-instruction lands 1 KiB at a wave-uniform LDS base +
   // lane * 16, which is exactly the linear image both operands have here).  No staging registers and no ds_write pass: through
   // registers the ds_write_b128s alone were 10.8 k of the K loop's 42.6 k cycles (13 cycles of the CU's VGPR -> LDS path each).
-  auto boff = [&](int k) {
-    const int e = min((k * NW + wave) * 64 + lane, Ge::kBG - 1);
+  size_t bo[QB + 1];
+#pragma unroll
+  for (int k = 0; k <= QB; ++k) {
+    const int e = min((k * NW + wave) * 64 + lane, B_G - 1);
     const int row = e / WIN, col = e - row * WIN;
-    return (size_t)row * a.ld + col;
-  };
-  const size_t bo0 = boff(0), bo1 = boff(1), bo2 = boff(2);
-  const size_t b_blk = (size_t)4 * a.ld;
-  constexpr int NP = A_LD + 3;                      // DMA pieces per wave per block (the last one on wave 0 only)
+    bo[k] = (size_t)row * a.ld + col;
+  }
+  const size_t b_blk = (size_t)SUB * 4 * a.ld;
+  constexpr int NP = A_LD + QB + 1;                 // DMA pieces per wave per stage (the last one on waves < RB only)
   // (inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in flight hipcc stops counting its LDS reads and waits
   // lgkmcnt(0) in front of every other MFMA step; the asm statement is invisible to its counters -- the DMA is counted by hand below)
   const unsigned lds0 = (unsigned)(size_t)(bf_lds_ptr_t)lds + (unsigned)wave * 1024u;
@@ -179,16 +184,15 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
     const unsigned l = lds0 + (unsigned)st * (STAGE_G * 16);
     const uint4* pb = Bg + (size_t)bk * b_blk;
     if (q < A_LD) glds16(Ag + (size_t)bk * A_G + tid + q * NW * 64, l + q * NW * 1024);
-    else if (q == A_LD) glds16(pb + bo0, l + A_G * 16);
-    else if (q == A_LD + 1) glds16(pb + bo1, l + (A_G + NW * 64) * 16);
-    else if (wave == 0) glds16(pb + bo2, l + (A_G + 2 * NW * 64) * 16);
+    else if (q < A_LD + QB) glds16(pb + bo[q - A_LD], l + (A_G + (q - A_LD) * NW * 64) * 16);
+    else if (wave < RB) glds16(pb + bo[QB], l + (A_G + QB * NW * 64) * 16);
   };
   // The DMA is waited for by hand: __syncthreads() would drain it (vmcnt(0)) at every barrier; with three stages the newest block
-  // stays in flight across the barrier (its pieces: A_LD + 2, + 1 on wave 0).
+  // stays in flight across the barrier (its pieces: A_LD + QB, + 1 on waves < RB).
   auto wait_landed = [&](bool newest_in_flight) {
     if (NST == 3 && newest_in_flight) {
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + 3) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + 2) : "memory");
+      if (wave < RB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + QB + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + QB) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -204,19 +208,20 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
   auto compute = [&](int st, int bk2, int st2) {
     const uint4* la = lds + st * STAGE_G + wr * 64 + i + g * 128;
     const uint4* lb = lds + st * STAGE_G + A_G + g * WIN + wc * 64 + i;
-    constexpr int NS = F16S ? TAPS : TAPS * 2;                // MFMA steps per block: a tap (both halves of the split) | a k16-step of a tap
+    constexpr int NS = F16S ? TAPS * SUB : TAPS * 2;          // MFMA steps per stage: a tap of a sub-block (both halves of the split) | a k16-step of a tap
     constexpr int SPREAD = NST == 3 ? NS : (NS + 1) / 2;      // two stages: the pieces must land before this block's barrier
     constexpr int NF = F16S ? 2 : 1;                          // fragment pairs per step: {hi, lo} | one
     uint4 fa[2][NF][2], fb[2][NF][2];
     auto frag = [&](int j, int set) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        const int tap = F16S ? j : j >> 1, s2 = F16S ? f : j & 1;
+        const int u = (F16S && SUB == 2) ? j : 0;             // sub-block (one tap then)
+        const int tap = F16S ? (SUB == 2 ? 0 : j) : j >> 1, s2 = F16S ? f : j & 1;
         const int shift = TAPS == 3 ? 8 + (tap - 1) * a.dil : 8;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) fa[set][f][x] = la[(tap * 2 + s2) * 256 + x * 32];
+        for (int x = 0; x < 2; ++x) fa[set][f][x] = la[((u * TAPS + tap) * 2 + s2) * 256 + x * 32];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) fb[set][f][nb] = lb[2 * s2 * WIN + shift + nb * 32];
+        for (int nb = 0; nb < 2; ++nb) fb[set][f][nb] = lb[(u * 4 + 2 * s2) * WIN + shift + nb * 32];
       }
     };
     if (!(DBG & 4)) frag(0, 0);
@@ -393,7 +398,8 @@ template <int F16S = 0, class Epi>
 inline hipError_t launch_bf16lds(const uint4* Wp, const uint4* Xb, long x_bs, int ld, int C, int dil, int B, int T, int rows, const Epi& epi,
                                  hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   BfArgs a;
-  a.Wp = Wp; a.Xb = Xb; a.x_bs = x_bs; a.ld = ld; a.n_blk = C / (F16S ? 16 : 32); a.dil = dil; a.T = T;
+  a.Wp = Wp; a.Xb = Xb; a.x_bs = x_bs; a.ld = ld; a.dil = dil; a.T = T;
+  a.n_blk = C / ((F16S && Epi::kTaps == 3) ? 16 : 32);     // channels per LDS stage (the split mode's one-tap GEMM stages two 16-channel sub-blocks)
   a.n_mtiles = rows / 128;
   a.tiles_per_item = a.n_tiles_n = 0;
   return bf16lds_pick_wn(B, T, rows) == 4 ? launch_bf16lds_wn<Epi, 4, F16S>(a, B, T, epi, s, ev0, ev1)
