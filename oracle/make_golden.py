@@ -49,6 +49,35 @@ def save(name, **arrays):
     print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+
+# which make_golden section writes which fixture (prefix match), for tests/golden/MANIFEST.json
+FIXTURE_SECTIONS = (("convnext_cross", "convnext_cross"), ("convnext", "convnext"), ("frontend_expand", "frontend_expand"), ("frontend_svs", "frontend_svs"),
+                    ("tfdec", "tfdec"), ("refinegan_sine", "refinegan_sine"), ("nsf_v1_256_full", "round2"), ("chain_", "round2"))
+
+
+def write_manifest():
+    """tests/golden/MANIFEST.json: every fixture with its generating section, byte size, SHA-256 and array shapes -- checked by
+    tests/test_oracle_golden.py::test_golden_manifest_lists_every_fixture, so a fixture cannot change or appear unrecorded."""
+    import hashlib
+    entries = {}
+    for name in sorted(os.listdir(GOLD)):
+        if not name.endswith(".npz"):
+            continue
+        path = os.path.join(GOLD, name)
+        with open(path, "rb") as f:
+            blob = f.read()
+        with np.load(path, allow_pickle=False) as z:
+            arrays = {k: [str(z[k].dtype), list(z[k].shape)] for k in z.files}
+        section = next((sec for pre, sec in FIXTURE_SECTIONS if name.startswith(pre)), "main")
+        entries[name] = {"section": f"python -m oracle.make_golden{'' if section == 'main' else ' ' + section}", "bytes": len(blob),
+                         "sha256": hashlib.sha256(blob).hexdigest(), "arrays": arrays}
+    manifest = {"generator": "oracle/make_golden.py (runs the REAL reference from /root/reference on seeded inputs; asserts oracle == reference)",
+                "torch": torch.__version__, "numpy": np.__version__, "fixtures": entries}
+    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    print(f"  wrote MANIFEST.json ({len(entries)} fixtures)")
+
+
 def synth_f0(T: int, frame_rate: float = 44100 / 512) -> torch.Tensor:
     """220*2^(0.3 sin(2 pi 0.7 t)) Hz with frames 100-130 unvoiced (scaled for short T)."""
     t = torch.arange(T, dtype=torch.float32) / frame_rate
@@ -524,7 +553,6 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     R = _ref_import.load()
     torch.set_num_threads(os.cpu_count())
-    manifest = {"torch": torch.__version__, "numpy": np.__version__}
 
     # ---------------------------------------------------------------- WaveNet forward
     print("wavenet")
@@ -825,17 +853,19 @@ def main():
     golden_refinegan_sine(R)
     golden_frontend_svs(R)
 
-    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
-        json.dump(manifest, f, indent=1)
+    write_manifest()
     print("done")
 
 
 if __name__ == "__main__":
     SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2, "convnext_cross": golden_convnext_cross, "refinegan_sine": golden_refinegan_sine,
                 "frontend_svs": golden_frontend_svs}
-    if len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only
+    if len(sys.argv) == 2 and sys.argv[1] == "manifest":   # re-index the fixtures on disk (no reference needed)
+        write_manifest()
+    elif len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(os.cpu_count())
         SECTIONS[sys.argv[1]](_ref_import.load())
+        write_manifest()
     else:
         main()

@@ -1,6 +1,7 @@
 """CPU: the oracle restatement reproduces the golden vectors generated from the REAL reference
 (oracle/make_golden.py).  Tolerances are a few ulps: a different host CPU may pick different MKL-DNN kernels."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -313,3 +314,22 @@ def test_refinegan_sine_template_oracle_matches_reference(tag):
     with torch.no_grad():
         wav = refinegan_ref.generator_forward(sd, cfg, g["mel"], g["f0"], _sine_noises(g, cfg, B, T), taps)
     assert torch.equal(taps["template"], g["template"]) and abs_err(wav, g["wav"]) < 1e-6
+
+
+def test_golden_manifest_lists_every_fixture():
+    """tests/golden/MANIFEST.json (oracle/make_golden.py::write_manifest) names every committed fixture with its generating command,
+    size and SHA-256: a fixture cannot change, appear or disappear without the manifest saying so."""
+    import hashlib
+    from tests.helpers import ROOT
+    gold = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gold, "MANIFEST.json")) as f:
+        m = json.load(f)
+    on_disk = sorted(n for n in os.listdir(gold) if n.endswith(".npz"))
+    assert sorted(m["fixtures"]) == on_disk
+    for name, e in m["fixtures"].items():
+        with open(os.path.join(gold, name), "rb") as f:
+            blob = f.read()
+        assert len(blob) == e["bytes"] and hashlib.sha256(blob).hexdigest() == e["sha256"], name
+        assert e["section"].startswith("python -m oracle.make_golden")
+    for need in ("nsf_v1_256_full.npz", "chain_c1.npz", "chain_c2.npz", "frontend_svs.npz", "convnext_cross_small.npz"):
+        assert need in m["fixtures"], need
