@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--storage", choices=("fp32", "bf16", "fp16x3"), default="fp32",
                     help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype.  "
                          "fp16x3: the OPT-IN fp16-split mode (hi + lo operands, three fp16 MFMAs per product block, fp32 accumulate): fp32-class "
-                         "results, used by launches with enough LDS tiles (batch >= 5 at 10 s); reported as its own dtype")
+                         "results, used by launches with enough LDS tiles (batch >= 2 at 10 s); reported as its own dtype")
     ap.add_argument("--prof-stride", type=int, default=None, help="time every N-th launch of the dominant kernel")
     ap.add_argument("--no-exact", action="store_true", help="sharded config: the reference's padded-batch semantics (x_masks / cond_masks) instead of "
                     "the library's exact-ragged batches (every utterance as if run alone; padding tiles skipped)")

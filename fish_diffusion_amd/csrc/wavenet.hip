@@ -55,6 +55,13 @@ static long bf16_lds_min_tiles() {
   return v;
 }
 static bool bf16_lds_enabled() { return bf16_lds_min_tiles() > 0; }
+// fp16-split mode: its alternative is the fp32 kernels (3x the MFMA time), not the register-direct bf16 ones, so it pays from 112 tiles
+// (batch 2 at 10 s: 67 vs 71 ms per 50 steps; batch 3: 70 vs 117; batch 4: 71 vs 146; batch 1 = 56 tiles: 61 vs 41 -- fp32 stays).
+// FDX_BF16_LDS overrides this threshold too (the tests force the mode for every geometry with FDX_BF16_LDS=1).
+static long f16s_min_tiles() {
+  static const long v = [] { const char* e = getenv("FDX_BF16_LDS"); return e ? atol(e) : 112L; }();
+  return v;
+}
 constexpr size_t kBfTileSlack = 8192;   // bytes behind the blocked 16-bit operand buffers (see wn_alloc)
 static int outp_shape_env() {   // FDX_OUTP_SHAPE=0: always the 32x32x2 kernel; =<NR><NM>: force a 16x16x4 shape
   static const int v = [] { const char* e = getenv("FDX_OUTP_SHAPE"); return e ? atoi(e) : -1; }();
@@ -741,7 +748,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     hipLaunchKernelGGL(k_to_blocked_bf16, ew_grid(T, B * (C / 8)), dim3(kEwBlock), 0, s, reinterpret_cast<__bf16*>(h->Yb.p) + (size_t)kHalo * 8,
                        (long)C * ld, Y, bsC, ld, C, T);
   // fp16-split mode: taken per call when the launches have enough LDS tiles (else the fp32 kernels: both are fp32-class)
-  const bool f16s = h->wn_f16s_ok && !h->wn_arena_bf16 && (long)B * ((T + 127) / 128) * (C / 64) >= bf16_lds_min_tiles();
+  const bool f16s = h->wn_f16s_ok && !h->wn_arena_bf16 && f16s_min_tiles() > 0 && (long)B * ((T + 127) / 128) * (C / 64) >= f16s_min_tiles();
   _Float16* Yh = f16s ? reinterpret_cast<_Float16*>(h->Yh.p) + (size_t)kHalo * 8 : nullptr;
   _Float16* Zh = f16s ? reinterpret_cast<_Float16*>(h->Zh.p) + (size_t)kHalo * 8 : nullptr;
   const long bsH = (long)2 * C * ld;             // fp16 elements per item ({hi, lo})

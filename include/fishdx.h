@@ -95,7 +95,7 @@ int fdx_wavenet_bf16_from_arena(fdx_handle h, void* dev_out, size_t bytes, fdx_s
 /* Opt-in fp16-split mode ("past the fp32 roof"): the same two GEMMs with every operand held as hi + lo fp16 (22 mantissa bits)
  * and each product block formed as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16, fp32 accumulate: fp32-class results (held
  * to the fp32 path's own parity bars by the tests) at up to 5.3x the fp32 MFMA rate.  Taken per call when the launches have
- * enough LDS tiles (batch >= 5 at 10 s), the fp32 kernels otherwise.  The weights are derived on the device from the attached
+ * enough LDS tiles (batch >= 2 at 10 s), the fp32 kernels otherwise.  The weights are derived on the device from the attached
  * fp32 arena; on = 0 switches back.  Mutually exclusive with the bf16 storage mode.  Never what the default bench line measures. */
 int fdx_wavenet_f16s_enable(fdx_handle h, int on);
 
