@@ -1,5 +1,6 @@
-// bf16lds.hip.h -- the two residual-block GEMMs of the opt-in bf16 storage mode, LDS-tiled, for large column counts (BASELINE
-// configs[4]: 16 utterances per GPU => N = 13 776 columns).
+// bf16lds.hip.h -- the two residual-block GEMMs of the two opt-in 16-bit-MFMA modes, LDS-tiled, for large column counts (BASELINE
+// configs[4]: 16 utterances per GPU => N = 13 776 columns):  the bf16 storage mode (F16S = 0; not parity-grade) and the fp16-split
+// mode (F16S = 1; fp32-class: operands hi + lo in fp16, three MFMAs per product block -- see the kernel's comment).
 //
 // The register-direct kernels (convgemm_kernel<..., OPK_BF16>) stream 4 KB of operands per 4 MFMAs per wave: with the bf16 MFMA 16x
 // faster than the fp32 one that is 128 B/cycle/CU of L1/L2 traffic, and the kernel sits at ~20 % of the 2.5 PFLOP/s roof.  Here a
@@ -24,7 +25,8 @@
 // kernel at ~1.7 GHz).  What is left: the epilogue's fp32 conditioner reads (all CUs reach it together: an HBM burst), barrier skew.
 //
 // Paired rows (dilated conv + gate): rows 0..63 of a wave pair = gate rows of 32 channels (wave row wr) + the matching filter rows, so
-// sigmoid(g) * tanh(f) is formed in registers.  Epilogues write the next GEMM's operand directly in the blocked bf16 layout.
+// sigmoid(g) * tanh(f) is formed in registers.  Epilogues write the next GEMM's operand directly in the blocked 16-bit layout
+// (bf_store_quad).  Split mode at batch 16: conv + gate 123.0 us (fp32 kernels: 333.6), out-projection 75.4 (144.9).
 #pragma once
 #include "convgemm.hip.h"
 #include <cstdlib>
