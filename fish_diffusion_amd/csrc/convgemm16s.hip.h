@@ -25,6 +25,33 @@ namespace fdx {
 template <int N> struct VecN { float v[N]; };
 struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
 
+// The same N adjacent floats kept as the VECTORS the loads produce (one dwordx4 + one tail load): the K loop's operand ring holds
+// these, so that its loop-carried values are register tuples, not 7-8 scalars hipcc then has to re-assemble (at N >= 7 it copied all
+// three pre-loaded stages into other registers in front of the loop, behind a full s_waitcnt).
+typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f3a __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f2a __attribute__((ext_vector_type(2), aligned(4)));
+template <int N> struct RawTail { typedef float type; };
+template <> struct RawTail<6> { typedef f2u type; };   // (as a 2-vector hipcc routed this instance's ring through scratch memory)
+template <> struct RawTail<7> { typedef f3a type; };
+template <> struct RawTail<8> { typedef f4a type; };
+template <int N> struct RawN {
+  f4a lo; typename RawTail<N>::type hi;
+  template <int M> __device__ __forceinline__ float get() const {
+    if constexpr (M < 4) return lo[M];
+    else if constexpr (N == 5) return hi;
+    else if constexpr (N == 6) return M == 4 ? hi.x : hi.y;
+    else return hi[M - 4];
+  }
+};
+template <int N> __device__ __forceinline__ RawN<N> ldRaw(const float* p) {
+  RawN<N> r;
+  r.lo = *reinterpret_cast<const f4a*>(p);
+  if constexpr (N == 4) r.hi = 0.f;
+  else r.hi = *reinterpret_cast<const typename RawTail<N>::type*>(p + 4);
+  return r;
+}
+
 // N adjacent floats at any dword alignment (sources are the library's own padded rows: >= kTailPad floats of slack right of T)
 template <int N> __device__ __forceinline__ VecN<N> ldN(const float* p) {
   static_assert(N >= 4 && N <= 8, "4..8 columns per lane");
@@ -189,7 +216,8 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
     for (int m = 0; m < NM; ++m) acc[x][m] = f4{0.f, 0.f, 0.f, 0.f};
 
   if (it_begin < it_end) {
-    struct Stage { float a[2][NR]; VecN<NM> b[2]; };                  // two K = 4 sub-steps = 8 channels
+    typedef float avec __attribute__((ext_vector_type(NR)));          // a lane's A values of one sub-step, as loaded (see RawN)
+    struct Stage { avec a[2]; RawN<NM> b[2]; };                       // two K = 4 sub-steps = 8 channels
     const int n = it_end - it_begin;
     const int cb0 = it_begin / a.taps, tap0 = it_begin - cb0 * a.taps;
     constexpr unsigned ASTEP = 2u * 64u * NR * 4u;                      // bytes of A per K iteration
@@ -210,16 +238,10 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const char* pa = Abase + (a_off + a_lane + h * (64u * NR * 4u));
-        if constexpr (NR == 4) {
-          const float4 v = *reinterpret_cast<const float4*>(pa);
-          s.a[h][0] = v.x; s.a[h][1] = v.y; s.a[h][2] = v.z; s.a[h][3] = v.w;
-        } else {
-          const float2 v = *reinterpret_cast<const float2*>(pa);
-          s.a[h][0] = v.x; s.a[h][1] = v.y;
-        }
+        s.a[h] = *reinterpret_cast<const avec*>(pa);
       }
-      s.b[0] = ldN<NM>(reinterpret_cast<const float*>(Xbase + (x_off + x_lane0)));
-      s.b[1] = ldN<NM>(reinterpret_cast<const float*>(Xbase + (x_off + x_lane1)));
+      s.b[0] = ldRaw<NM>(reinterpret_cast<const float*>(Xbase + (x_off + x_lane0)));
+      s.b[1] = ldRaw<NM>(reinterpret_cast<const float*>(Xbase + (x_off + x_lane1)));
       const bool wrap = tap + 1 == a.taps;
       a_off = min(a_off + ASTEP, a_last);
       x_off = min(x_off + (wrap ? d_wrap : d_tap), x_last);
@@ -227,11 +249,18 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
     };
     auto compute = [&](Stage& s) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
+        float bv[NM];
+        bv[0] = s.b[h].template get<0>(); bv[1] = s.b[h].template get<1>(); bv[2] = s.b[h].template get<2>(); bv[3] = s.b[h].template get<3>();
+        if constexpr (NM > 4) bv[4] = s.b[h].template get<4>();
+        if constexpr (NM > 5) bv[5] = s.b[h].template get<5>();
+        if constexpr (NM > 6) bv[6] = s.b[h].template get<6>();
+        if constexpr (NM > 7) bv[7] = s.b[h].template get<7>();
 #pragma unroll
         for (int m = 0; m < NM; ++m)
 #pragma unroll
-          for (int x = 0; x < NR; ++x) acc[x][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.a[h][x], s.b[h].v[m], acc[x][m], 0, 0, 0);
+          for (int x = 0; x < NR; ++x) acc[x][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.a[h][x], bv[m], acc[x][m], 0, 0, 0);
+      }
     };
     constexpr int NLOADS = 2 + (NM == 4 ? 2 : 4);                       // vector loads per slot
     constexpr int NMFMA = 2 * NM * NR;
