@@ -178,13 +178,18 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
   const float* sb; int sb_ld, sb_bs;  // out2 = v + sb[row*sb_ld + b*sb_bs]
   int tight;                          // 1: `out` is a caller tensor with no padding (row pitch may equal T); out2 is always padded
   int out2_zero_masked;               // 1: masked columns of out2 get 0 instead of sb (exact-ragged mode: nothing exists beyond an item's length)
-  struct Pre { float bias, sb; bool m0, m1; };
-  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
-    Pre p{0.f, 0.f, false, false};
-    if (row >= M) return p;
-    if (bias) p.bias = bias[row];
-    if (out2) p.sb = sb[(long)row * sb_ld + b * sb_bs];
-    if (mask) { p.m0 = mask[(long)b * mask_ld + t] != 0; p.m1 = two && mask[(long)b * mask_ld + t + 1] != 0; }
+  // Pre-loads are branch-free and touch no loaded value: every load is unconditional, from a pointer selected by the wave-uniform
+  // conditions (an absent operand reads the output row instead: readable, ignored by store()), rows past M are clamped.
+  // With `bool` members, an early return and `mask[..] != 0` in here hipcc drained all loads (vmcnt(0)) in front of
+  // the K loop -- the operand stages queued behind the epilogue's loads included.
+  // (The mask bytes are read in store(), behind `if (mask)`: pre-loaded, their zero-extension is a use in front of the K loop.)
+  struct Pre { float bias, sb; };
+  __device__ __forceinline__ Pre load(int b, int row, int /*t*/, bool /*two*/) const {
+    Pre p;
+    const int r = min(row, M - 1);
+    const float* dummy = out + b * o_bs;
+    p.bias = *(bias ? bias + r : dummy);
+    p.sb = *(out2 ? sb + (long)r * sb_ld + b * sb_bs : dummy);
     return p;
   }
   __device__ __forceinline__ float act1(float v, float bv, bool masked) const {
@@ -196,13 +201,15 @@ struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional o
   }
   __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
     if (row >= M) return;
-    v.x = act1(v.x, p.bias, p.m0);
-    v.y = act1(v.y, p.bias, p.m1);
+    bool m0 = false, m1 = false;
+    if (mask) { m0 = mask[(long)b * mask_ld + t] != 0; m1 = two && mask[(long)b * mask_ld + t + 1] != 0; }
+    v.x = act1(v.x, p.bias, m0);
+    v.y = act1(v.y, p.bias, m1);
     if (tight) st2(out + b * o_bs + (long)row * ldo + t, v, two);
     else st2p(out + b * o_bs + (long)row * ldo + t, v, two);
     if (out2) {
       f2 y{v.x + p.sb, v.y + p.sb};
-      if (out2_zero_masked) { if (p.m0) y.x = 0.f; if (p.m1) y.y = 0.f; }
+      if (out2_zero_masked) { if (m0) y.x = 0.f; if (m1) y.y = 0.f; }
       st2p(out2 + b * o2_bs + (long)row * ldo2 + t, y, two);
     }
   }
@@ -361,20 +368,22 @@ struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) +
   float* X; long bs; int ld;                 // residual in, result out (in place), padded rows
   const float* bias; const float* gamma; int M;
   const uint8_t* mask; int mask_ld;
-  struct Pre { f2 old; float bias, gamma; bool m0, m1; };
+  struct Pre { f2 old; float bias, gamma; };   // (branch-free, mask read in store(): see EpiBias::load)
   __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
-    Pre p{f2{0.f, 0.f}, 0.f, 0.f, false, false};
-    if (row >= M) return p;
-    p.old = ld2(X + b * bs + (long)row * ld + t, two);
-    p.bias = bias[row]; p.gamma = gamma ? gamma[row] : 1.f;   // gamma == null: plain residual add x + (v + bias)
-    if (mask) { p.m0 = mask[(long)b * mask_ld + t] != 0; p.m1 = two && mask[(long)b * mask_ld + t + 1] != 0; }
+    Pre p;
+    const int r = min(row, M - 1);
+    p.old = ld2(X + b * bs + (long)r * ld + t, two);
+    p.bias = bias[r];
+    p.gamma = *(gamma ? gamma + r : bias + r);                  // gamma == null: plain residual add x + (v + bias), see store()
     return p;
   }
   __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
     if (row >= M) return;
-    v = p.old + p.gamma * (v + p.bias);
-    if (p.m0) v.x = 0.f;
-    if (p.m1) v.y = 0.f;
+    v = p.old + (gamma ? p.gamma : 1.f) * (v + p.bias);
+    if (mask) {
+      if (mask[(long)b * mask_ld + t] != 0) v.x = 0.f;
+      if (two && mask[(long)b * mask_ld + t + 1] != 0) v.y = 0.f;
+    }
     st2p_keep(X + b * bs + (long)row * ld + t, v, two);
   }
 };
