@@ -133,6 +133,8 @@ struct fdx_ctx {
   int bf16_B = 0, bf16_T = 0;            // geometry Yb / Zb were last zeroed for
   fdx::DevBuf wn_f16s;                   // fp16-split mode: {hi, lo} fp16 weights of the two residual-block GEMMs in LDS order (derived from the fp32 arena)
   bool wn_f16s_ok = false;
+  fdx::DevBuf wn_f16s64;                 // ... and in the small-tile kernel's order (f16s64.hip.h), when FDX_F16S_SMALL is set
+  bool wn_f16s64_ok = false;
   fdx::DevBuf Yh, Zh;                    // ... and the two GEMM operands as blocked {hi, lo} fp16
   int f16s_B = 0, f16s_T = 0;
   bool cond_masked = false; int condraw_ld = 0;

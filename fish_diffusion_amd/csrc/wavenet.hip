@@ -16,6 +16,7 @@
 #include "elementwise.hip.h"
 #include "convgemm16s.hip.h"
 #include "bf16lds.hip.h"
+#include "f16s64.hip.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -512,6 +513,52 @@ static __global__ void k_f16s_from_arena(_Float16* __restrict__ dst, const float
   *reinterpret_cast<f16x8*>(dst + out * 8) = v;
 }
 
+// The same weights in the small-tile kernel's order (f16s64.hip.h): [m-tile64][block32][tap][hl][k-group 4][64 rows], row = wr*32 + x*16 + i:
+//   conv (paired rows):  channel mt*32 + wr*16 + i, row x*C + channel (x = 0 gate half, 1 filter half);  out-projection: row mt*64 + r.
+static size_t f16s64_conv_groups(int C) { return (size_t)(2 * C / 64) * (C / 32) * 3 * 2 * 4 * 64; }
+static size_t f16s64_outp_groups(int C) { return (size_t)(2 * C / 64) * (C / 32) * 2 * 4 * 64; }
+static __global__ void k_f16s64_from_arena(_Float16* __restrict__ dst, const float* __restrict__ A, const F16sDerive* __restrict__ lay, int L, int C,
+                                           int conv_mode16, int outp_mode16, float wscale) {
+  const size_t per_conv = (size_t)(2 * C / 64) * (C / 32) * 3 * 2 * 4 * 64, per_outp = (size_t)(2 * C / 64) * (C / 32) * 2 * 4 * 64;
+  const size_t gidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= (size_t)L * (per_conv + per_outp)) return;
+  const int layer = (int)(gidx / (per_conv + per_outp));
+  size_t g = gidx - (size_t)layer * (per_conv + per_outp);
+  const bool conv = g < per_conv;
+  if (!conv) g -= per_conv;
+  const int taps = conv ? 3 : 1, n_blk = C / 32;
+  const int r = (int)(g & 63);
+  size_t q = g >> 6;
+  const int kg = (int)(q & 3); q >>= 2;
+  const int hl = (int)(q & 1); q >>= 1;
+  const int tap = (int)(q % taps); q /= taps;
+  const int blk = (int)(q % n_blk);
+  const int mt = (int)(q / n_blk);
+  const int wr = r >> 5, x = (r >> 4) & 1, i = r & 15;
+  // the register-direct packings address a row as (tile, 32-row half rb, row r32 within it): conv tiles are 32 channels x {gate, filter}
+  const int rb = conv ? x : wr, r32 = conv ? wr * 16 + i : x * 16 + i;
+  const size_t w_off = conv ? lay[layer].conv_w : lay[layer].outp_w;
+  const int n_it32 = conv ? (C / 8) * 3 : C / 8, mode16 = conv ? conv_mode16 : outp_mode16;
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = blk * 32 + 8 * kg + j;
+    const int it32 = conv ? (c >> 3) * 3 + tap : (c >> 3);
+    const size_t src = mode16 ? f32_frag_index16(mt, n_it32, it32, (rb << 1) | (r32 >> 4), r32 & 15, c) : f32_frag_index32(mt, n_it32, it32, rb, r32, c);
+    const float wv = A[w_off + src] * wscale;
+    const _Float16 hi = (_Float16)wv;
+    v[j] = hl ? (_Float16)(wv - (float)hi) : hi;
+  }
+  const size_t out = (size_t)layer * (per_conv + per_outp) + (conv ? 0 : per_conv) + g;
+  *reinterpret_cast<f16x8*>(dst + out * 8) = v;
+}
+// FDX_F16S_SMALL=1: also derive the small-tile image and use f16s64_kernel for launches below the 128 x 128 tile threshold that have at
+// least this many 64 x 64 tiles.  Default off: the kernel has not run on hardware yet.
+static long f16s_small_min_tiles() {
+  static const long v = [] { const char* e = getenv("FDX_F16S_SMALL"); const long k = e ? atol(e) : 0; return k == 1 ? 160L : k; }();
+  return v;
+}
+
 // on != 0: derive the {hi, lo} weights from the attached fp32 arena and use the fp16-split kernels where a launch has enough tiles;
 // on == 0: back to the fp32 kernels everywhere.  (Mutually exclusive with the bf16 storage mode: attach that one with NULL first.)
 extern "C" int fdx_wavenet_f16s_enable(fdx_handle h, int on) {
@@ -535,6 +582,15 @@ extern "C" int fdx_wavenet_f16s_enable(fdx_handle h, int on) {
   hipLaunchKernelGGL(k_f16s_from_arena, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, static_cast<_Float16*>(h->wn_f16s.p), h->wn_arena,
                      static_cast<const F16sDerive*>(h->scratch_b.p), L, C, conv16() ? 1 : 0, outp16() ? 1 : 0, kF16sWScale);
   FDX_HIP(h, hipGetLastError());
+  h->wn_f16s64_ok = false;
+  if (f16s_small_min_tiles() > 0) {
+    const size_t g64 = (size_t)L * (f16s64_conv_groups(C) + f16s64_outp_groups(C));
+    FDX_HIP(h, h->wn_f16s64.ensure(g64 * 16, false, nullptr));
+    hipLaunchKernelGGL(k_f16s64_from_arena, dim3((unsigned)((g64 + 255) / 256)), dim3(256), 0, nullptr, static_cast<_Float16*>(h->wn_f16s64.p), h->wn_arena,
+                       static_cast<const F16sDerive*>(h->scratch_b.p), L, C, conv16() ? 1 : 0, outp16() ? 1 : 0, kF16sWScale);
+    FDX_HIP(h, hipGetLastError());
+    h->wn_f16s64_ok = true;
+  }
   FDX_HIP(h, hipStreamSynchronize(nullptr));
   h->wn_f16s_ok = true;
   return FDX_OK;
@@ -748,7 +804,9 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     hipLaunchKernelGGL(k_to_blocked_bf16, ew_grid(T, B * (C / 8)), dim3(kEwBlock), 0, s, reinterpret_cast<__bf16*>(h->Yb.p) + (size_t)kHalo * 8,
                        (long)C * ld, Y, bsC, ld, C, T);
   // fp16-split mode: taken per call when the launches have enough LDS tiles (else the fp32 kernels: both are fp32-class)
-  const bool f16s = h->wn_f16s_ok && !h->wn_arena_bf16 && f16s_min_tiles() > 0 && (long)B * ((T + 127) / 128) * (C / 64) >= f16s_min_tiles();
+  const bool f16s_big = h->wn_f16s_ok && !h->wn_arena_bf16 && f16s_min_tiles() > 0 && (long)B * ((T + 127) / 128) * (C / 64) >= f16s_min_tiles();
+  const bool f16s_small = !f16s_big && h->wn_f16s_ok && h->wn_f16s64_ok && !h->wn_arena_bf16 && (long)B * ((T + 63) / 64) * (C / 32) >= f16s_small_min_tiles();
+  const bool f16s = f16s_big || f16s_small;
   _Float16* Yh = f16s ? reinterpret_cast<_Float16*>(h->Yh.p) + (size_t)kHalo * 8 : nullptr;
   _Float16* Zh = f16s ? reinterpret_cast<_Float16*>(h->Zh.p) + (size_t)kHalo * 8 : nullptr;
   const long bsH = (long)2 * C * ld;             // fp16 elements per item ({hi, lo})
@@ -765,8 +823,16 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     const float* sbn = S + (size_t)(i + 1 < L ? i + 1 : 0) * C * ldn;
     const int skip_mode = (L == 1) ? 3 : (i == 0 ? 0 : (i + 1 == L ? 2 : 1));
     if (f16s) {               // fp16-split mode: both GEMMs as three v_mfma_f32_32x32x16_f16 per product block
-      const uint4* WH = static_cast<const uint4*>(h->wn_f16s.p) + (size_t)i * (f16s_conv_groups(C) + f16s_outp_groups(C));
       BfEpiGate eg{Pl, p_bs, ld, Zh, bsH, ld, C, 1.f / (kF16sWScale * kF16sYScale), kF16sZScale};
+      if (f16s_small) {       // 64 x 64 tiles on v_mfma_f32_16x16x32_f16 (f16s64.hip.h)
+        const uint4* WS = static_cast<const uint4*>(h->wn_f16s64.p) + (size_t)i * (f16s64_conv_groups(C) + f16s64_outp_groups(C));
+        FDX_HIP(h, launch_f16s64(WS, reinterpret_cast<const uint4*>(Yh), bsH / 8, ld, C, dil, B, T, 2 * C, eg, s, ev0, ev1));
+        BfEpiResSkip ers{X, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, (i + 1 < L) ? Yh : nullptr, bsH, C, skip_mode, sqrtL,
+                         (float)(1.0 / (double)sqrtL), 1.f / (kF16sWScale * kF16sZScale), kF16sYScale, keep, (long)ld};
+        FDX_HIP(h, launch_f16s64(WS + f16s64_conv_groups(C), reinterpret_cast<const uint4*>(Zh), bsH / 8, ld, C, 0, B, T, 2 * C, ers, s, eo0, eo1));
+        continue;
+      }
+      const uint4* WH = static_cast<const uint4*>(h->wn_f16s.p) + (size_t)i * (f16s_conv_groups(C) + f16s_outp_groups(C));
       FDX_HIP(h, launch_bf16lds<1>(WH, reinterpret_cast<const uint4*>(Yh), bsH / 8, ld, C, dil, B, T, 2 * C, eg, s, ev0, ev1));
       BfEpiResSkip er{X, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, (i + 1 < L) ? Yh : nullptr, bsH, C, skip_mode, sqrtL,
                       (float)(1.0 / (double)sqrtL), 1.f / (kF16sWScale * kF16sZScale), kF16sYScale, keep, (long)ld};

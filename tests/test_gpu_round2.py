@@ -610,3 +610,14 @@ def test_fp16_split_error_table_full_size_net(dev):
     with open(os.path.join(ROOT, "gpurun_out", "fp16x3_error_table.json"), "w") as f:
         json.dump(out, f, indent=1)
     assert rows[0]["max_rel_of_peak"] < 2e-5 and rows[1]["max_rel_of_peak"] < 1e-4 and rows[2]["max_rel_of_peak"] < 1e-4
+
+
+def test_fp16_split_small_tile_kernel_holds_the_fp32_parity_bars(dev):
+    """csrc/f16s64.hip.h: the fp16-split mode on 64 x 64 tiles (v_mfma_f32_16x16x32_f16) for small column counts -- batch 1 at 10 s has
+    224 of them.  Same bar as the large-tile kernels: the fp32 suite's WaveNet / sampler / chained / exact-ragged tests unchanged, with the
+    small-tile kernel forced for every geometry (FDX_F16S_SMALL=2: from two tiles; FDX_BF16_LDS huge: never the 128-wide tiles)."""
+    env = dict(os.environ, FDX_WAVENET_STORAGE="fp16x3", FDX_F16S_SMALL="2", FDX_BF16_LDS="1000000000")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_round2.py"),
+                        "-m", "gpu", "-q", "-x", "-k", FP16X3_SUBSET], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
