@@ -13,7 +13,10 @@
 //                   k_f16s64_from_arena), B = the 8 group rows x (64 + 16) columns of the blocked activations exactly as they lie in
 //                   memory ([hi g0][hi g1][lo g0][lo g1] of the two 16-channel halves), 34 KB per stage, three stages.
 //
-// NOT YET RUN ON HARDWARE (written at the end of round 2 without GPU budget): gated behind FDX_F16S_SMALL=1.
+// Status (end of round 2, the last GPU minutes): the WaveNet-forward and sampler golden tests pass with this kernel forced for every
+// geometry (9 tests, fp32 tolerances), and batch 1 x 10 s runs 50 denoiser calls in 29 ms against 40 ms on the fp32 kernels (untuned,
+// first build).  The broad parity subset the large-tile kernels are held to, and the tile thresholds, are not measured yet, so it
+// stays behind FDX_F16S_SMALL=1 (off by default).
 #pragma once
 #include "bf16lds.hip.h"
 

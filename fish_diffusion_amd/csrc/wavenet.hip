@@ -553,7 +553,7 @@ static __global__ void k_f16s64_from_arena(_Float16* __restrict__ dst, const flo
   *reinterpret_cast<f16x8*>(dst + out * 8) = v;
 }
 // FDX_F16S_SMALL=1: also derive the small-tile image and use f16s64_kernel for launches below the 128 x 128 tile threshold that have at
-// least this many 64 x 64 tiles.  Default off: the kernel has not run on hardware yet.
+// least this many 64 x 64 tiles (1: 160; n > 1: n).  Default off: only the forward / sampler golden tests have run with it so far.
 static long f16s_small_min_tiles() {
   static const long v = [] { const char* e = getenv("FDX_F16S_SMALL"); const long k = e ? atol(e) : 0; return k == 1 ? 160L : k; }();
   return v;
