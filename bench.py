@@ -204,14 +204,17 @@ def prof_pause(handle):
 
 
 def prof_end(handle):
-    """(launches, avg_ms, flops_per_launch) of the launches recorded since prof_begin."""
+    """(launches, avg_ms, flops_per_launch, label) of the launches recorded since prof_begin.  `label` is the library's own
+    description of the kernel instantiation those launches ran (fdx_prof_label) -- never a literal in this file."""
     from fish_diffusion_amd import _lib
     n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.lib().fdx_prof_label(handle.h, buf, len(buf)), handle.h)
     _lib.check(_lib.lib().fdx_prof_read(handle.h, C.byref(n), C.byref(ms), C.byref(fl)), handle.h)
     _lib.check(_lib.lib().fdx_prof_enable(handle.h, 0), handle.h)
     if not n.value:
-        return 0, 0.0, 0.0
-    return n.value, ms.value / n.value, fl.value
+        return 0, 0.0, 0.0, ""
+    return n.value, ms.value / n.value, fl.value, buf.value.decode()
 
 
 def roofline_entry(kernel_desc, n, avg_ms, flops, peak, sampling, traffic=None, traffic_src=None, alg_bytes=None):
@@ -232,37 +235,48 @@ def cpu_denoiser(diff):
                                                                dilation_cycle=WN_CFG["dilation_cycle"])
 
 
-def cpu_chain(diff, voc, nsf, T, n_steps, sample_steps, predictor=None):
+CPU_REPEATS = 3   # 1 warm-up + 3 timed runs, median
+
+
+def cpu_chain(diff, voc, nsf, T, n_steps, sample_steps, predictor=None, repeats=CPU_REPEATS):
     """The oracle chain on this box's host cores for ONE utterance of T frames: `sample_steps` of the `n_steps` denoiser calls at
-    full length (the rest extrapolated linearly: every step is the same call) + the full vocoder pass."""
+    full length (the rest extrapolated linearly: every step is the same call) + the full vocoder pass.  Protocol of BASELINE.md
+    section 3: one warm-up pass (a short sampler run + one vocoder pass: thread pool, MKL-DNN primitive caches, page faults), then
+    `repeats` timed passes; returns the MEDIAN pass (by total) and every pass's (denoise, vocoder) seconds."""
     from oracle import nsf_hifigan_ref, sampler_ref
     cores = usable_cores()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
-    t_den = 0.0
     hop = nsf["hop_size"]
+    runs = []
     with torch.no_grad():
-        if diff is not None:
-            den = cpu_denoiser(diff)
-            feats, x0 = torch.randn(1, T, 256, generator=g), torch.randn(1, 128, T, generator=g)
-            den(x0, torch.tensor([500.0]), feats.transpose(1, 2), None, None)   # warm-up (thread pool, MKL-DNN primitives)
-            kw = {}
-            if predictor == "naive":
-                kw = dict(predictor="naive", step_noise=torch.randn(sample_steps, 1, 128, T, generator=g))
-            t0 = time.perf_counter()
-            mel = sampler_ref.diffusion_sample(den, feats, x_init=x0, sampler_interval=1000 // sample_steps, **kw)
-            t_den = (time.perf_counter() - t0) / sample_steps * n_steps
-            melv = 2.30259 * mel.transpose(1, 2)
-        else:
-            melv = torch.randn(1, 128, T, generator=g) * 0.5 - 2.0
+        den = cpu_denoiser(diff) if diff is not None else None
+        feats, x0 = torch.randn(1, T, 256, generator=g), torch.randn(1, 128, T, generator=g)
         gsd = {k: v.detach().cpu() for k, v in voc.model.state_dict().items()}
         f0 = synth_f0(T, nsf["sampling_rate"] / hop)[None]
         ri = torch.rand(1, 9, generator=g)
         sn = torch.randn(1, T * hop, 9, generator=g)
-        t0 = time.perf_counter()
-        nsf_hifigan_ref.generator_forward(gsd, nsf, melv, f0, ri, sn)
-        t_voc = time.perf_counter() - t0
-    return t_den, t_voc, cores
+        for r in range(repeats + 1):
+            warm = r == 0
+            ss = min(sample_steps, 5) if warm else sample_steps
+            t_den = 0.0
+            if den is not None:
+                kw = {}
+                if predictor == "naive":
+                    kw = dict(predictor="naive", step_noise=torch.randn(ss, 1, 128, T, generator=g))
+                t0 = time.perf_counter()
+                mel = sampler_ref.diffusion_sample(den, feats, x_init=x0, sampler_interval=1000 // ss, **kw)
+                t_den = (time.perf_counter() - t0) / ss * n_steps
+                melv = 2.30259 * mel.transpose(1, 2)
+            else:
+                melv = torch.randn(1, 128, T, generator=g) * 0.5 - 2.0
+            t0 = time.perf_counter()
+            nsf_hifigan_ref.generator_forward(gsd, nsf, melv, f0, ri, sn)
+            t_voc = time.perf_counter() - t0
+            if not warm:
+                runs.append((t_den, t_voc))
+    med = sorted(runs, key=lambda p: p[0] + p[1])[len(runs) // 2]
+    return med[0], med[1], cores, runs
 
 
 def flush_c_stdio():
@@ -270,6 +284,60 @@ def flush_c_stdio():
         C.CDLL(None).fflush(None)   # RCCL prints its version banner through C stdio: keep the JSON line the LAST line of stdout
     except Exception:
         pass
+
+
+# ====================================================================================================== launcher dry run
+def dry_run(args, cfg, steps, warmup, rank, world):
+    """`--dry-run`: the multi-rank plumbing of this file on CPU ranks over gloo -- rendezvous, one broadcast of a byte arena from
+    rank 0 (what `broadcast_model_weights` does with the packed weights), barrier-bracketed timing of a stand-in step, MAX over
+    ranks, per-rank stats gather, rank 0's JSON line.  Not a measurement: the line says so."""
+    from fish_diffusion_amd import dist as fdist
+    import torch.distributed as tdist
+    cpu = torch.device("cpu")
+    t0 = time.perf_counter()
+    arena = torch.arange(1 << 16, dtype=torch.int64).to(torch.uint8) if rank == 0 else torch.zeros(1 << 16, dtype=torch.uint8)
+    if tdist.is_initialized():
+        tdist.broadcast(arena, src=0)
+    assert int(arena[259]) == 3, "arena broadcast failed"
+    t_weights = time.perf_counter() - t0
+    lens = torch.randint(516, 862, (64,), generator=torch.Generator().manual_seed(4)).tolist()
+    mine = fdist.shard_utterances(lens, rank, world) if cfg == "sharded" else [0]
+    frames = sum(lens[i] for i in mine) if cfg == "sharded" else 861
+    audio_s = frames * 512 / 44100.0
+    a = torch.randn(64, 64, generator=torch.Generator().manual_seed(rank))
+
+    def step(k):
+        return (a @ a).sum()
+
+    def barrier():
+        if tdist.is_initialized():
+            tdist.barrier()
+    for k in range(warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    t_local = time.perf_counter()
+    barrier()
+    dt = fdist.barrier_max(time.perf_counter() - t0, cpu)
+    per_rank = fdist.gather_stats([(t_local - t0) / steps * 1e3, audio_s, float(frames), float(len(mine))], cpu)
+    audio_all = fdist.sum_over_ranks(audio_s, cpu)
+    out = {"metric": "DRY RUN (launcher / collective plumbing on CPU ranks; not a measurement)", "value": round(steps * audio_all / dt, 3),
+           "unit": "audio-seconds/sec", "n_gpus": tdist.get_world_size() if tdist.is_initialized() else 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if (cfg == "sharded" and world > 1) else "weak",
+           "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True, "backend": tdist.get_backend() if tdist.is_initialized() else None,
+           "config": {"workload": "stand-in step function", "name": cfg, "parallelism": f"utterance-sharded x{world} (no per-step collective)"},
+           "launched_by": os.environ.get("FDX_LAUNCHED_BY", "external launcher" if "WORLD_SIZE" in os.environ else "single process"),
+           "weights_pack_bcast_s": round(t_weights, 4), "rccl_ranks": 0,
+           "per_rank_ms": [round(float(v), 4) for v in per_rank[:, 0]], "per_rank_frames": [int(v) for v in per_rank[:, 2]],
+           "per_rank_utterances": [int(v) for v in per_rank[:, 3]], "roofline": None, "cpu_baseline": None}
+    if tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 # ====================================================================================================== main
@@ -294,7 +362,15 @@ def main():
     ap.add_argument("--prof-stride", type=int, default=None, help="time every N-th launch of the dominant kernel")
     ap.add_argument("--no-exact", action="store_true", help="sharded config: the reference's padded-batch semantics (x_masks / cond_masks) instead of "
                     "the library's exact-ragged batches (every utterance as if run alone; padding tiles skipped)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / collective plumbing only: CPU ranks over gloo, a stand-in step function "
+                    "(tests/test_bench_host.py runs this at world size 2; never a measurement)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` starts its own N ranks (one process per GPU, RCCL), like the reference's sharded tool spawns its
+        # own workers (tools/preprocessing/extract_features.py:262-322).  Under torch.distributed.run WORLD_SIZE is set and we are a rank.
+        from fish_diffusion_amd import dist as fdist
+        sys.stdout.flush()
+        raise SystemExit(fdist.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], need_gpus=not args.dry_run))
     cfg = ALIASES.get(str(args.config).lower())
     if cfg is None:
         raise SystemExit(f"unknown --config {args.config!r}")
@@ -304,19 +380,26 @@ def main():
 
     from fish_diffusion_amd import _lib, dist as fdist, pipeline
 
-    rank, local_rank, world = fdist.init_process_group()
-    if world != args.gpus and world > 1:
+    rank, local_rank, world = fdist.init_process_group("gloo" if args.dry_run else None)
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, cfg, steps, warmup, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but this node exposes {torch.cuda.device_count()} GPU(s)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     def sync_barrier():
+        """synchronize + barrier + synchronize; returns the time this rank reached the barrier (its own work done)."""
         torch.cuda.synchronize()
+        t_local = time.perf_counter()
         if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        return t_local
 
     nsf = NSF_V1_256 if cfg == "vocoder" else NSF_V1
     hop = nsf["hop_size"]
@@ -359,8 +442,7 @@ def main():
         prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 7   # 7 is co-prime with the 20 layers: every dilation sampled
         C_, M_ = WN_CFG["residual_channels"], B * T
         alg_bytes = 4 * (2 * C_ * 3 * C_ + C_ * M_ + 2 * C_ * M_ + C_ * M_)   # weights + Y in + conditioner slab in + Z out
-        kdesc = (("convgemm_kernel<2,splitK,OPK_BF16,EpiGateB> (v_mfma_f32_32x32x16_bf16)" if bf16 else
-                  "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + ": dilated conv k=3 + gate of the residual block")
+        kwhat = "dilated conv k=3 + gate of the residual block"
         traffic_key, traffic_expect = "convgate", {"config": "headline", "batch": B, "frames": T}
     elif cfg == "vocoder":
         B = args.batch or 32
@@ -380,8 +462,8 @@ def main():
         prof_handle = lambda: voc.model.engine(dev)   # noqa: E731
         prof_kind, stride = _lib.PROF_NSF_RESBLOCK, args.prof_stride or 5
         alg_bytes = None
-        kdesc = ("convgemm_kernel<2,noSplit,PRE_LRELU,EpiResblock> (v_mfma_f32_32x32x2_f32): the ResBlock1 convs (k = 3/7/11, leaky-relu on the "
-                 "operand, residual / MRF mean in the epilogue) of the stages with >= 64 channels; FLOP-weighted over the launches timed")
+        kwhat = ("the ResBlock1 convs (k = 3/7/11, leaky-relu on the operand, residual / MRF mean in the epilogue) of the stages with >= 64 "
+                 "channels; FLOP-weighted over the launches timed")
         traffic_key, traffic_expect = "nsf_resblock", {"config": "vocoder", "batch": B, "frames": T}
     elif cfg == "sharded":
         interval = args.interval or 10
@@ -415,8 +497,7 @@ def main():
         prof_handle = lambda: diff.denoise_fn.engine(dev)   # noqa: E731
         prof_kind, stride = _lib.PROF_WN_CONVGATE, args.prof_stride or 7
         alg_bytes = None
-        kdesc = (("bf16lds_kernel<BfEpiGate, WN, F16S> (3 x v_mfma_f32_32x32x16_f16 per product block; peak = fp16 MFMA peak / 3)" if f16s else
-                  "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + ": dilated conv k=3 + gate of the residual block (masked micro-batches)")
+        kwhat = "dilated conv k=3 + gate of the residual block (micro-batches)" + ("; peak = fp16 MFMA peak / 3" if f16s else "")
         traffic_key, traffic_expect = "convgate", {"config": "sharded" + ("_fp16x3" if f16s else ""), "batch": B, "frames": max(lens[i] for i in mine)}
     else:  # ddpm1000
         from fish_diffusion_amd import DiffSinger, pitch_to_scale
@@ -452,10 +533,7 @@ def main():
         C_, M_ = WN_CFG["residual_channels"], B * T
         esz = 2 if bf16 else 4      # (fp16x3: hi + lo = 4 bytes per element)
         alg_bytes = esz * (2 * C_ * 3 * C_ + C_ * M_ + C_ * M_) + 4 * 2 * C_ * M_    # weights + Y in + Z out (+ fp32 conditioner slab)
-        kdesc = (("bf16lds_kernel<BfEpiGate, 4> (v_mfma_f32_32x32x16_bf16; 128 x 256 tile, operands into LDS by DMA, 3 stages)" if bf16 else
-                  "bf16lds_kernel<BfEpiGate, 4, F16S> (3 x v_mfma_f32_32x32x16_f16 per product block: hi.lo + lo.hi + hi.hi; 128 x 256 tile, LDS-DMA, "
-                  "3 stages; peak = fp16 MFMA peak / 3)" if f16s else
-                  "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32)") + f": dilated conv k=3 + gate of the residual block at batch {B}")
+        kwhat = f"dilated conv k=3 + gate of the residual block at batch {B}" + ("; hi.lo + lo.hi + hi.hi, peak = fp16 MFMA peak / 3" if f16s else "")
         traffic_key, traffic_expect = "convgate", {"config": "ddpm1000" + ("_bf16" if bf16 else "_fp16x3" if f16s else ""), "batch": B, "frames": T}
 
     # ------------------------------------------------------------------------------------------------ warm-up, timed region
@@ -471,17 +549,20 @@ def main():
         out = step(warmup + k)
         if k == 0 and do_prof:       # the dominant kernel is timed on the first timed step only (it needs the eager launch path);
             prof_pause(prof_handle())   # the other steps replay the hipGraph
-    sync_barrier()
+    t_local = sync_barrier()
     dt = time.perf_counter() - t0
+    per_rank = fdist.gather_stats([(t_local - t0) / steps * 1e3, audio_s, float(cfg_extra.get("frames_this_rank", B * T)),
+                                   float(cfg_extra.get("utterances_this_rank", B))], dev)   # [world, 4]
     dt = fdist.barrier_max(dt, dev)
     del out
 
     roofline = None
     if do_prof:
-        n, avg_ms, fl = prof_end(prof_handle())
+        n, avg_ms, fl, label = prof_end(prof_handle())
         if n:
             traffic, traffic_src = pmc_traffic(cfg, traffic_key, traffic_expect)
-            roofline = roofline_entry(kdesc, n, avg_ms, fl, peak, f"every {stride}th launch of the first timed step", traffic, traffic_src, alg_bytes)
+            roofline = roofline_entry(f"{label}: {kwhat}", n, avg_ms, fl, peak, f"every {stride}th launch of the first timed step", traffic, traffic_src,
+                                      alg_bytes)
 
     # ------------------------------------------------------------------------------------------------ outside the timed region
     other = []
@@ -490,15 +571,16 @@ def main():
         prof_begin(prof_handle(), _lib.PROF_WN_OUTPROJ, stride)
         step(warmup)
         torch.cuda.synchronize()
-        n, avg_ms, fl = prof_end(prof_handle())
+        n, avg_ms, fl, label = prof_end(prof_handle())
         if n:
             tr, src = pmc_traffic(cfg, "outproj", traffic_expect)
-            e = roofline_entry(("bf16lds_kernel<BfEpiResSkip, 4> (v_mfma_f32_32x32x16_bf16; HBM-bound: the fp32 residual stream and skip sum are "
-                                "read and written every layer)" if bf16 else
-                                "bf16lds_kernel<BfEpiResSkip, 4, F16S> (3 x v_mfma_f32_32x32x16_f16 per product block)" if (f16s and cfg == "ddpm1000") else
-                                "convgemm_kernel<2,splitK,EpiResSkip> (v_mfma_f32_32x32x2_f32)")
-                               + ": 1x1 out-projection + residual / skip epilogue", n,
-                               avg_ms, fl, peak, f"every {stride}th launch of one extra step outside the timed region", tr, src)
+            C_, M_ = WN_CFG["residual_channels"], fl / (2.0 * 2 * WN_CFG["residual_channels"] ** 2)   # columns per launch, from its flops
+            esz = 2 if bf16 else 4
+            # weights [2C x C] + Z in + X in/out + SK in/out + next layer's Y out (fp32 residual stream in every mode)
+            ob = esz * (2 * C_ * C_ + C_ * M_) + 4 * (4 * C_ * M_) + esz * C_ * M_
+            e = roofline_entry(f"{label}: 1x1 out-projection + residual / skip epilogue" + (" (HBM-bound: the fp32 residual stream and skip sum "
+                               "are read and written every layer)" if bf16 else ""), n,
+                               avg_ms, fl, peak, f"every {stride}th launch of one extra step outside the timed region", tr, src, int(ob))
             if bf16:
                 e["bound"] = "hbm"
             other.append(e)
@@ -533,7 +615,8 @@ def main():
     e2e_alg = alg * steps / dt / 1e12
     e2e_exe = exe * steps / dt / 1e12
     out = {
-        "metric": metric, "value": round(value, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "metric": metric, "value": round(value, 3), "unit": "audio-seconds/sec",
+        "n_gpus": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1, "steps": steps, "warmup": warmup,
         "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if (cfg == "sharded" and world > 1) else "weak", "vs_baseline": None,
         "dtype": ("bf16 storage / f32 accumulate (opt-in mode, not parity-grade)" if bf16 else
@@ -550,7 +633,14 @@ def main():
                        "algorithmic_flops_per_step": alg, "executed_flops_per_step": exe,
                        "note": "algorithmic = the reference's op count (SURVEY 8d); executed = what the device ran (the step-invariant "
                                "conditioner projections once per utterance instead of once per sampler step)"},
-        "weights_pack_upload_s" if world == 1 and not torch.distributed.is_initialized() else "weights_pack_bcast_s": round(t_weights, 4),
+        "weights_pack_upload_s" if not torch.distributed.is_initialized() else "weights_pack_bcast_s": round(t_weights, 4),
+        "launched_by": os.environ.get("FDX_LAUNCHED_BY", "external launcher" if "WORLD_SIZE" in os.environ else "single process"),
+        "rccl_ranks": (torch.distributed.get_world_size() if torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" else 0),
+        "per_rank_ms": [round(float(v), 3) for v in per_rank[:, 0]],
+        "per_rank_audio_s": [round(float(v), 3) for v in per_rank[:, 1]],
+        "per_rank_frames": [int(v) for v in per_rank[:, 2]],
+        "per_rank_utterances": [int(v) for v in per_rank[:, 3]],
+        "imbalance": round(float(per_rank[:, 0].max() / per_rank[:, 0].mean()), 4),
         "roofline": roofline,
         "other_kernels": other or None,
     }
@@ -558,29 +648,32 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if cfg == "headline":
             ss = args.cpu_sample_steps or 100
-            td, tv, cores = cpu_chain(diff, voc, nsf, T, n_steps, ss)
+            td, tv, cores, runs = cpu_chain(diff, voc, nsf, T, n_steps, ss)
             sample = (f"1 x {args.seconds:g} s utterance (T={T}): {ss} of {n_steps} UniPC steps timed ({td / n_steps * 1e3:.0f} ms/step"
                       + ("" if ss == n_steps else f", extrapolated x{n_steps / ss:g}") + f") + full NSF-HiFiGAN pass ({tv:.2f} s)")
             cpu_audio = args.seconds
         elif cfg == "vocoder":
-            td, tv, cores = cpu_chain(None, voc, nsf, T, 0, 0)
+            td, tv, cores, runs = cpu_chain(None, voc, nsf, T, 0, 0)
             sample = f"1 of the {B} x {args.seconds:g} s mels (T={T}): one full NSF-HiFiGAN config_v1_256 pass ({tv:.2f} s)"
             cpu_audio = args.seconds
         elif cfg == "sharded":
             ss = args.cpu_sample_steps or 20
             Tm = sorted(lens[i] for i in mine)[len(mine) // 2]
-            td, tv, cores = cpu_chain(diff, voc, nsf, Tm, n_steps, ss)
+            td, tv, cores, runs = cpu_chain(diff, voc, nsf, Tm, n_steps, ss)
             sample = (f"1 utterance of median length (T={Tm}) run alone: {ss} of {n_steps} UniPC steps timed, extrapolated x{n_steps / ss:g}, + full "
                       f"NSF-HiFiGAN pass ({tv:.2f} s)")
             cpu_audio = Tm * hop / 44100.0
         else:
-            ss = args.cpu_sample_steps or 100
-            td, tv, cores = cpu_chain(diff, voc, nsf, T, n_steps, ss, predictor="naive")
+            ss = args.cpu_sample_steps or 50
+            td, tv, cores, runs = cpu_chain(diff, voc, nsf, T, n_steps, ss, predictor="naive")
             sample = (f"1 of the {B} x {args.seconds:g} s utterances (T={T}): {ss} of {n_steps} DDPM steps timed ({td / n_steps * 1e3:.0f} ms/step, "
                       f"extrapolated x{n_steps / ss:g}) + full NSF-HiFiGAN pass ({tv:.2f} s); fp32")
             cpu_audio = args.seconds
         cb = {"value": round(cpu_audio / (td + tv), 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-              "sample": sample + f"; torch {torch.__version__} CPU, {cores} threads", "denoise_s": round(td, 4), "vocoder_s": round(tv, 4)}
+              "sample": sample + f"; torch {torch.__version__} CPU, {cores} threads; 1 warm-up pass + median of {len(runs)} timed passes",
+              "denoise_s": round(td, 4), "vocoder_s": round(tv, 4), "protocol": "BASELINE.md section 3: 1 warm-up + 3 timed, median",
+              "runs_s": [[round(a, 4), round(b, 4)] for a, b in runs],
+              "runs_value": [round(cpu_audio / (a + b), 4) for a, b in runs]}
         out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = round(value / cb["value"], 1)
     else:

@@ -131,6 +131,7 @@ _SIGS = {
     "fdx_prof_enable": (C.c_int, [_P, C.c_int]),
     "fdx_prof_select": (C.c_int, [_P, C.c_int]),
     "fdx_prof_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fdx_prof_label": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "fdx_graph_stats": (C.c_int, [_P, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)]),
     "fdx_prof_calibrate": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
 }

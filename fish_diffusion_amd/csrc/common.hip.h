@@ -90,6 +90,14 @@ struct ProfEvents {
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
   double flops_total = 0;  // algorithmic FLOPs of the recorded launches
+  char label[224] = {0};   // which kernel instantiation / tile shape the recorded launches ran (fdx_prof_label)
+  void note(int k, const char* fmt, ...) __attribute__((format(printf, 3, 4))) {
+    if (!on || k != kind) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(label, sizeof label, fmt, ap);
+    va_end(ap);
+  }
   // events for this launch, or false (not selected / not sampled).  Event-creation errors simply skip the launch.
   bool take(int k, double flops, hipEvent_t& ev0, hipEvent_t& ev1) {
     if (!on || k != kind || (seen++ % stride) != 0) return false;

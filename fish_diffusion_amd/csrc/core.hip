@@ -69,6 +69,7 @@ extern "C" int fdx_prof_enable(fdx_handle h, int on) {
   h->prof.seen = 0;
   h->prof.used = 0;
   h->prof.flops_total = 0;
+  h->prof.label[0] = 0;
   return FDX_OK;
 }
 
@@ -95,6 +96,12 @@ extern "C" int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, do
   if (flops_per_launch) *flops_per_launch = h->prof.used ? h->prof.flops_total / (double)h->prof.used : 0.0;
   h->prof.used = 0;
   h->prof.flops_total = 0;
+  return FDX_OK;
+}
+
+extern "C" int fdx_prof_label(fdx_handle h, char* buf, size_t cap) {
+  if (!h || !buf || !cap) return FDX_E_ARG;
+  snprintf(buf, cap, "%s", h->prof.label);
   return FDX_OK;
 }
 

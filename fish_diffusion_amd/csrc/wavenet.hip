@@ -813,6 +813,38 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   if (f16s)
     hipLaunchKernelGGL(k_to_blocked_f16s, ew_grid(T, B * (C / 8)), dim3(kEwBlock), 0, s, Yh, bsH, Y, bsC, ld, C, T, kF16sYScale);
   const float sqrtL = (float)std::sqrt((double)L);
+  if (h->prof.on) {   // fdx_prof_label: the instantiations this call's two residual-block launches are (rocprofv3's kernel names)
+    if (f16s_small) {
+      h->prof.note(PROF_WN_CONVGATE, "f16s64_kernel<BfEpiGate> (3 x v_mfma_f32_16x16x32_f16 per product block; 64 x 64 workgroup tile, LDS-DMA, 3 stages; %ld workgroups)",
+                   (long)B * ((T + 63) / 64) * (2 * C / 64));
+      h->prof.note(PROF_WN_OUTPROJ, "f16s64_kernel<BfEpiResSkip> (3 x v_mfma_f32_16x16x32_f16 per product block; 64 x 64 workgroup tile)");
+    } else if (f16s_big || (h->wn_arena_bf16 && h->wn_bf16_lds_ok && (long)B * ((T + 127) / 128) * (C / 64) >= bf16_lds_min_tiles())) {
+      const int wn = bf16lds_pick_wn(B, T, 2 * C);
+      const char* mf = f16s_big ? "3 x v_mfma_f32_32x32x16_f16 per product block" : "v_mfma_f32_32x32x16_bf16";
+      h->prof.note(PROF_WN_CONVGATE, "bf16lds_kernel<BfEpiGate, %d, %d> (%s; 128 x %d workgroup tile, operands into LDS by DMA)", wn, (int)f16s_big, mf, 64 * wn);
+      h->prof.note(PROF_WN_OUTPROJ, "bf16lds_kernel<BfEpiResSkip, %d, %d> (%s; 128 x %d workgroup tile)", wn, (int)f16s_big, mf, 64 * wn);
+    } else if (h->wn_arena_bf16) {
+      h->prof.note(PROF_WN_CONVGATE, "convgemm_kernel<2, true, 0, EpiGateB, 4, 1, OPK_BF16> (v_mfma_f32_32x32x16_bf16; 64 x 64 split-K workgroup tile, register-direct operands)");
+      h->prof.note(PROF_WN_OUTPROJ, "convgemm_kernel<2, true, 0, EpiResSkipB, 4, 1, OPK_BF16> (v_mfma_f32_32x32x16_bf16; 64 x 64 split-K workgroup tile)");
+    } else {
+      if (!conv16())
+        h->prof.note(PROF_WN_CONVGATE, "convgemm_kernel<2, true, 0, EpiGate> (v_mfma_f32_32x32x2_f32; 64 x 64 split-K workgroup tile)");
+      else if (h->conv_shape_nr == 4 && h->conv_shape_nm == 4)
+        h->prof.note(PROF_WN_CONVGATE, "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32; 64 x 64 split-K workgroup tile)");
+      else
+        h->prof.note(PROF_WN_CONVGATE, "convgemm16s_kernel<EpiGate16S<%d>, %d, %d> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, %ld workgroups)",
+                     h->conv_shape_nm, h->conv_shape_nr, h->conv_shape_nm, 16 * h->conv_shape_nr, 16 * h->conv_shape_nm,
+                     (long)B * ((T + 16 * h->conv_shape_nm - 1) / (16 * h->conv_shape_nm)) * (2 * C / (16 * h->conv_shape_nr)));
+      if (h->outp_shape_nr)
+        h->prof.note(PROF_WN_OUTPROJ, "convgemm16s_kernel<EpiResSkip16S<%d>, %d, %d> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, %ld workgroups)",
+                     h->outp_shape_nm, h->outp_shape_nr, h->outp_shape_nm, 16 * h->outp_shape_nr, 16 * h->outp_shape_nm,
+                     (long)B * ((T + 16 * h->outp_shape_nm - 1) / (16 * h->outp_shape_nm)) * (2 * C / (16 * h->outp_shape_nr)));
+      else if (outp16())
+        h->prof.note(PROF_WN_OUTPROJ, "convgemm16_kernel<EpiResSkip16> (v_mfma_f32_16x16x4_f32; 64 x 64 split-K workgroup tile)");
+      else
+        h->prof.note(PROF_WN_OUTPROJ, "convgemm_kernel<2, true, 0, EpiResSkip> (v_mfma_f32_32x32x2_f32; 64 x 64 split-K workgroup tile)");
+    }
+  }
   for (int i = 0; i < L; ++i) {
     const int dil = l.dil[i];
     hipEvent_t ev0 = nullptr, ev1 = nullptr, eo0 = nullptr, eo1 = nullptr;   // fdx_prof_*: one of the two kernels, sampled

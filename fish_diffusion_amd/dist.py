@@ -15,6 +15,10 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import socket
+import subprocess
+import sys
+import time
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -44,6 +48,65 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: Sequence[str], need_gpus: bool = True, extra_env: Optional[dict] = None,
+                 timeout: Optional[float] = None) -> int:
+    """Start `n` copies of `argv` -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their
+    environment -- and wait for them: what `python -m torch.distributed.run --nproc-per-node n` does for one node, without
+    the wrapper.  The precedent is the reference's own sharded tool, tools/preprocessing/extract_features.py:262-322, which
+    spawns `num_workers` subprocesses itself, one GPU each.  Rank 0 keeps this process's stdout (its JSON line stays the
+    last line); the other ranks' stdout goes to stderr.  Fails loudly when the node has fewer than `n` GPUs -- never a
+    silent degrade to fewer ranks.  If a rank fails the others are stopped (by PID) and its exit code is returned."""
+    if n < 1:
+        raise ValueError("need at least one rank")
+    if need_gpus:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit(f"--gpus {n}: this node exposes {have} GPU(s); refusing to run fewer ranks than asked")
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FDX_LAUNCHED_BY="fish_diffusion_amd.dist.launch_ranks")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    t0 = time.monotonic()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[launch_ranks] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+        if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
+            if rc == 0:
+                rc = 124
+                print(f"[launch_ranks] timeout after {timeout} s", file=sys.stderr)
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        if live:
+            time.sleep(0.05)
+    return rc
 
 
 def shard_utterances(lengths: Sequence[int], rank: int, world: int) -> List[int]:

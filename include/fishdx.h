@@ -397,6 +397,10 @@ int fdx_prof_enable(fdx_handle h, int on);
  * flops_per_launch is the mean algorithmic FLOP count of the recorded launches (they differ per stage for family 2). */
 int fdx_prof_select(fdx_handle h, int kind);
 int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch);
+/* The kernel instantiation (name as rocprofv3 prints it, MFMA instruction, workgroup tile) the launches recorded since the last
+ * fdx_prof_enable actually ran -- bench.py reports this string instead of a literal, so the label cannot go stale when the
+ * library picks another tile shape or another kernel family for the geometry.  Empty if nothing was recorded. */
+int fdx_prof_label(fdx_handle h, char* buf, size_t cap);
 /* Median elapsed time (ms) of an EMPTY hipEventRecord start/stop pair on stream s (diagnostic: what
  * bracketing a launch with plain recorded events would add; fdx_prof_* does not use that method). */
 /* Recorded-sampler-graph cache of this handle: graphs captured so far, graph launches so far, graphs currently cached

@@ -67,3 +67,56 @@ def test_make_batches_rules():
     assert make_batches([], 4) == []
     flat = sorted(i for b in make_batches([7, 100, 90, 95, 20, 21, 60], 3) for i in b)
     assert flat == list(range(7))
+
+
+def _last_json(stdout: str):
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, stdout
+    return json.loads(lines[-1])
+
+
+def test_bench_gpus2_spawns_two_ranks_by_itself():
+    """`python bench.py --gpus N` (no wrapper, WORLD_SIZE unset) must start N ranks.  --dry-run runs the
+    launcher, the rendezvous, the arena broadcast, the barrier-bracketed timing and the per-rank gather on CPU ranks over gloo."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1",
+                        "--config", "sharded"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert r.stdout.strip().splitlines()[-1].startswith("{")          # rank 0's JSON line is the last line of stdout
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["backend"] == "gloo"
+    assert d["launched_by"] == "fish_diffusion_amd.dist.launch_ranks"
+    assert len(d["per_rank_ms"]) == 2 and len(d["per_rank_frames"]) == 2
+    assert sum(d["per_rank_utterances"]) == 64 and d["scaling"] == "strong"      # the 64 utterances are a partition over the two ranks
+    # without the GPUs it asks for, the real run refuses instead of degrading to fewer ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "refusing to run fewer ranks" in (r.stderr + r.stdout)
+
+
+def test_bench_under_torch_distributed_run_is_a_rank_not_a_launcher():
+    """The driver's own command line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) must not spawn again."""
+    import subprocess
+    import sys
+    from fish_diffusion_amd.dist import free_port
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["launched_by"] == "external launcher" and d["scaling"] == "weak"
+
+
+def test_launch_ranks_propagates_a_failing_rank_and_stops_the_rest():
+    import sys
+    import time
+    from fish_diffusion_amd.dist import launch_ranks
+    code = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(60)\n"
+    t0 = time.monotonic()
+    rc = launch_ranks(3, [sys.executable, "-c", code], need_gpus=False)
+    assert rc == 7 and time.monotonic() - t0 < 30          # ranks 0 and 2 were stopped, not waited for
+    assert launch_ranks(2, [sys.executable, "-c", "import os; assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'"],
+                        need_gpus=False) == 0
