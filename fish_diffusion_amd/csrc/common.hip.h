@@ -132,7 +132,7 @@ struct fdx_ctx {
   bool wn_nr2_ok = false;
   int conv_shape_nr = 4, conv_shape_nm = 4;   // tile shape of the dilated conv + gate for the prepared geometry
   fdx::DevBuf wn_outp16;                 // out-projection weights in the 16x16x4 orders (NR = 4 and NR = 2), derived at attach
-  std::vector<size_t> wn_outp16_off4, wn_outp16_off2;
+  std::vector<size_t> wn_outp16_off4, wn_outp16_off2, wn_outp16_off1;
   int outp_shape_nr = 0, outp_shape_nm = 0;   // 0: the 32x32x2 kernel
   const void* wn_arena_bf16 = nullptr;   // opt-in bf16 storage mode: residual-block weights as bf16 fragments (wavenet.hip)
   fdx::DevBuf Yb, Zb;                    // ... and the two GEMM operands in C8-blocked bf16

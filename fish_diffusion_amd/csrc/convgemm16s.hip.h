@@ -167,12 +167,13 @@ template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum o
 };
 
 // ------------------------------------------------------------------------------------------ kernel
-// Packed A: NR = 4: [m64-tile][it][h][lane] float4 (pack_convgemm16);  NR = 2: [m32-tile][it][h][lane] float2 (k_repack16_nr2).
+// Packed A: NR = 4: [m64-tile][it][h][lane] float4 (pack_convgemm16);  NR = 2: [m32-tile][it][h][lane] float2 (k_repack16_nr2);
+// NR = 1 (out-projection only): [m16-tile][it][h][lane] float (k_repack16_from32<1>) -- 16 x (16 NM) tiles, twice the workgroups of NR = 2.
 // Paired epilogues: blocks 0 .. NR/2-1 hold the tile's gate rows (16 channels each), blocks NR/2 .. NR-1 the matching filter rows.
 template <class Epi, int NR, int NM>
 __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
-  static_assert(NR == 2 || NR == 4, "2 or 4 row blocks");
+  static_assert(NR == 2 || NR == 4 || (NR == 1 && !Epi::kPaired), "1 (unpaired epilogues only), 2 or 4 row blocks");
   constexpr int NW = 4, COLS = 16 * NM, STR = NM <= 4 ? 4 : 8;      // LDS stride (floats) of a lane's NM partial sums
   a.tiles_per_item = (a.T + COLS - 1) / COLS;
   __shared__ float red[NW * NR * 4 * kWave * STR];                  // [wave][x*4 + reg][lane][m]

@@ -247,19 +247,21 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
     // the out-projection (packed for 32x32x2) in both 16x16x4 orders
     if (!outp16()) {
       size_t tot = 0;
-      for (const auto& p : l.outp) tot += 2 * packed_floats(p.n_mtiles, 2, p.cin8, 1);
+      for (const auto& p : l.outp) tot += 3 * packed_floats(p.n_mtiles, 2, p.cin8, 1);
       FDX_HIP(h, h->wn_outp16.ensure(tot * sizeof(float), false, nullptr));
-      h->wn_outp16_off4.clear(); h->wn_outp16_off2.clear();
+      h->wn_outp16_off4.clear(); h->wn_outp16_off2.clear(); h->wn_outp16_off1.clear();
       size_t c2 = 0;
       for (const auto& p : l.outp) {
         const size_t nf = packed_floats(p.n_mtiles, 2, p.cin8, 1);
-        h->wn_outp16_off4.push_back(c2); h->wn_outp16_off2.push_back(c2 + nf);
+        h->wn_outp16_off4.push_back(c2); h->wn_outp16_off2.push_back(c2 + nf); h->wn_outp16_off1.push_back(c2 + 2 * nf);
         const size_t n4 = nf / 4, n2 = nf / 2;
         hipLaunchKernelGGL(k_repack16_from32<4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, nullptr, h->wn_outp16.f() + c2, h->wn_arena + p.w_off,
                            p.n_mtiles, p.cin8);
         hipLaunchKernelGGL(k_repack16_from32<2>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, nullptr, h->wn_outp16.f() + c2 + nf, h->wn_arena + p.w_off,
                            p.n_mtiles, p.cin8);
-        c2 += 2 * nf;
+        hipLaunchKernelGGL(k_repack16_from32<1>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, nullptr, h->wn_outp16.f() + c2 + 2 * nf, h->wn_arena + p.w_off,
+                           p.n_mtiles, p.cin8);
+        c2 += 3 * nf;
       }
     }
     FDX_HIP(h, hipGetLastError());
@@ -682,7 +684,7 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
       so = Shape16{4, 4};
       if (forced_o > 0) so = Shape16{forced_o / 10, forced_o % 10};
       else if (wgo < 2 * 256) so = pick_shape16(rows16, B, T, 12000.0 / (32.0 * n_o));
-      if ((so.NR != 2 && so.NR != 4) || so.NM < 4 || so.NM > 8) so = Shape16{4, 4};
+      if ((so.NR != 1 && so.NR != 2 && so.NR != 4) || so.NM < 4 || so.NM > 8) so = Shape16{4, 4};
     }
     h->outp_shape_nr = so.NR; h->outp_shape_nm = so.NM;
   }
@@ -934,18 +936,21 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     }
     if (h->outp_shape_nr) {   // shape-adaptive 16x16x4 tiles (weights re-ordered at attach)
       const int NRo = h->outp_shape_nr, NMo = h->outp_shape_nm;
-      const ConvGeom g4{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles}, g2{B, T, l.outp[i].cin8, 1, 0, 0, 2 * l.outp[i].n_mtiles};
+      const ConvGeom g4{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles}, g2{B, T, l.outp[i].cin8, 1, 0, 0, 2 * l.outp[i].n_mtiles},
+          g1{B, T, l.outp[i].cin8, 1, 0, 0, 4 * l.outp[i].n_mtiles};
       const void* W4 = h->wn_outp16.f() + h->wn_outp16_off4[i];
       const void* W2 = h->wn_outp16.f() + h->wn_outp16_off2[i];
+      const void* W1 = h->wn_outp16.f() + h->wn_outp16_off1[i];
       hipError_t e = hipErrorInvalidValue;
 #define FDX_OUTP_SHAPE(NR_, NM_)                                                                                                   \
   if (NRo == NR_ && NMo == NM_) {                                                                                                  \
     const EpiResSkip16S<NM_> rs{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL, \
                                 (float)(1.0 / (double)sqrtL), keep, (long)ld};                                                     \
-    e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Z, bsC, ld, rs, s, eo0, eo1);     \
+    e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : NR_ == 2 ? g2 : g1, NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, Z, bsC, ld, rs, s, eo0, eo1); \
   }
       FDX_OUTP_SHAPE(4, 4) FDX_OUTP_SHAPE(4, 5) FDX_OUTP_SHAPE(4, 6) FDX_OUTP_SHAPE(4, 7) FDX_OUTP_SHAPE(4, 8)
       FDX_OUTP_SHAPE(2, 4) FDX_OUTP_SHAPE(2, 5) FDX_OUTP_SHAPE(2, 6) FDX_OUTP_SHAPE(2, 7) FDX_OUTP_SHAPE(2, 8)
+      FDX_OUTP_SHAPE(1, 4) FDX_OUTP_SHAPE(1, 5) FDX_OUTP_SHAPE(1, 6) FDX_OUTP_SHAPE(1, 7) FDX_OUTP_SHAPE(1, 8)
 #undef FDX_OUTP_SHAPE
       FDX_HIP(h, e);
     } else if (outp16()) {

@@ -108,8 +108,14 @@ class GaussianDiffusion(nn.Module):
                                                C.c_void_p(smax.data_ptr()), smin.numel(), a, b, _lib.ptr(noise), _lib.ptr(out), st), eng.h)
         return out
 
-    RAGGED_GAP = 16      # frames of hole between items: the widest dilated tap reaches 8 (dilation_cycle <= 4), the library asks for >= 16
+    RAGGED_GAP = 16      # minimum frames of hole between items (the library asks for >= 16); `_ragged_gap()` widens it to the net's widest tap
     RAGGED_BUCKET = 64   # the single row is padded to a multiple of this (bounds the number of geometries a stream produces)
+
+    def _ragged_gap(self) -> int:
+        """A hole isolates its two sides exactly when it is at least as wide as the widest dilated tap's reach, 2^(dilation_cycle-1)
+        frames (wavenet.py:88-95: k = 3, dilation 2^(i % cycle)).  16 covers dilation_cycle <= 5; a deeper cycle widens the hole."""
+        cyc = int(getattr(self.denoise_fn, "dilation_cycle", 4) or 1)
+        return max(self.RAGGED_GAP, 2 ** max(0, cyc - 1))
 
     def _forward_ragged(self, eng, cond, x, lens, kind, table, step_noise, seed, st):
         """Exact-ragged batch: items laid end to end in one row with holes between them, `fdx_sampler_run_ragged`, results scattered
@@ -119,11 +125,12 @@ class GaussianDiffusion(nn.Module):
             raise NotImplementedError("exact-ragged batches are built for the WaveNet denoiser")
         device = x.device
         B, M, T = x.shape
+        gap = self._ragged_gap()
         offs, cur = [], 0
         for n in lens:
             offs.append(cur)
-            cur += n + self.RAGGED_GAP
-        Tc = cur - self.RAGGED_GAP
+            cur += n + gap
+        Tc = cur - gap
         Tc = (Tc + self.RAGGED_BUCKET - 1) // self.RAGGED_BUCKET * self.RAGGED_BUCKET
         cond_c = torch.zeros((1, cond.shape[1], Tc), device=device, dtype=torch.float32)
         x_c = torch.zeros((1, M, Tc), device=device, dtype=torch.float32)
@@ -133,20 +140,30 @@ class GaussianDiffusion(nn.Module):
             x_c[0, :, o:o + n] = x[b, :, :n]
             hole[0, o:o + n] = 0
         n_rows = table.shape[0]
-        sn = None
-        if kind == _lib.SAMPLER_NAIVE and (step_noise is not None or self.step_rng == "torch"):
-            # (no reference RNG stream to reproduce here: the reference never runs a ragged batch this way; draws are per batch)
-            sn = torch.zeros((n_rows, 1, M, Tc), device=device, dtype=torch.float32)
-            src = step_noise if step_noise is not None else torch.randn((n_rows, B, M, T), device=device)
-            for b, (o, n) in enumerate(zip(offs, lens)):
-                sn[:, 0, :, o:o + n] = src[:, b, :, :n]
+        # DDPM with explicit / torch-drawn step noise: a bounded chunk of steps at a time, like the dense path (1000 steps x
+        # [B, M, T] up front would be 3.5 GB at batch 8 x 10 s, and the scattered copy as much again).  Draws are per batch: the
+        # reference never runs a ragged batch this way, so there is no reference RNG stream to reproduce here.
+        inject = kind == _lib.SAMPLER_NAIVE and (step_noise is not None or self.step_rng == "torch")
+        chunk = n_rows
+        if inject:
+            chunk = max(1, min(n_rows, self.naive_noise_chunk_bytes // max(1, M * Tc * 4)))
+            sn = torch.zeros((chunk, 1, M, Tc), device=device, dtype=torch.float32)
+            draw = None if step_noise is not None else torch.empty((B, M, T), device=device, dtype=torch.float32)
         mel_c = torch.empty((1, Tc, M), device=device, dtype=torch.float32)
         smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         smax = self.spec_max.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         with eng.lock:
             self.denoise_fn.prepare(cond_c, None)
-            _lib.check(_lib.lib().fdx_sampler_run_ragged(eng.h, kind, C.c_void_p(table.ctypes.data), n_rows, _lib.ptr(x_c), _lib.ptr(sn),
-                                                         seed, _lib.ptr(hole), st), eng.h)
+            for r0 in range(0, n_rows, chunk):
+                r1 = min(n_rows, r0 + chunk)
+                if inject:
+                    for i in range(r1 - r0):
+                        src = step_noise[r0 + i] if step_noise is not None else draw.normal_()
+                        for b, (o, n) in enumerate(zip(offs, lens)):
+                            sn[i, 0, :, o:o + n] = src[b, :, :n]
+                tab = table[r0:r1]
+                _lib.check(_lib.lib().fdx_sampler_run_ragged(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x_c),
+                                                             _lib.ptr(sn if inject else None), seed + r0, _lib.ptr(hole), st), eng.h)
             _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x_c), 1, M, Tc, C.c_void_p(smin.data_ptr()),
                                                   C.c_void_p(smax.data_ptr()), smin.numel(), _lib.ptr(mel_c), st), eng.h)
         mel = torch.zeros((B, T, M), device=device, dtype=torch.float32)
@@ -168,9 +185,11 @@ class GaussianDiffusion(nn.Module):
                 x_init: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None, lengths=None):
         """features [B, T, E] -> mel [B, T, M].  `x_init` / `step_noise` (extensions, default None) inject the
         random draws the reference takes from the global RNG (diffusion.py:222,232; noise_predictor.py:101).
-        `lengths` (extension): per-item valid frame counts of a padded batch -> EXACT-RAGGED mode: every item's mel[:length] is bit
-        for bit what a batch-1 call on its unpadded features returns (the reference's inference loop,
-        tools/diffusion/inference.py:336-376, runs one segment at a time); frames beyond an item's length come back as 0.  The
+        `lengths` (extension): per-item valid frame counts of a padded batch -> EXACT-RAGGED mode: every item's mel[:length] is what
+        a batch-1 call on its unpadded features returns (the reference's inference loop, tools/diffusion/inference.py:336-376, runs
+        one segment at a time) -- BIT FOR BIT in the default fp32 storage; in the opt-in `storage="fp16x3"` mode to fp32 rounding
+        only (a long ragged row and a short single item may run different fp32-class kernel families: hi+lo fp16 tiles vs fp32
+        MFMA, chosen by tile count); frames beyond an item's length come back as 0.  The
         batch is laid out as ONE row -- items separated by 16-frame holes, nothing padded to a common length -- and run through
         `fdx_sampler_run_ragged`, whose holes isolate the items exactly (include/fishdx.h).  Mutually exclusive with x_masks /
         cond_masks (the reference's own padded-batch semantics)."""

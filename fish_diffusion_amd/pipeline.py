@@ -85,9 +85,12 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     utterances this rank owns.  `x_init_fn(idx_list, M, T)` / `source_noise_fn(idx_list, L)` let tests inject the random
     draws (initial x_T; (rand_ini, src_noise)) -- by default they are drawn on the device.  `bucket`: every micro-batch is padded
     to a multiple of this many frames (0 / 1 = pad to the longest member only).
-    `exact` (default: True for the fp32 WaveNet denoiser): padded batches run in the library's EXACT-RAGGED mode -- every utterance's
-    result is bit for bit what a batch-1 run of it alone gives (the reference's one-segment-at-a-time loop), padding costs no
-    arithmetic (tiles beyond an item's length are skipped).  False: the reference's own padded-batch semantics with x_masks /
+    `exact` (default: True for the WaveNet denoiser in fp32 or fp16x3 storage): padded batches run in the library's EXACT-RAGGED mode
+    -- every utterance's result is what a batch-1 run of it alone gives (the reference's one-segment-at-a-time loop): bit for bit in
+    fp32 storage, to fp32 rounding in the opt-in fp16x3 storage (a long row may run the hi+lo fp16 tiles where the short item alone
+    runs the fp32 MFMA kernels: both fp32-class, not bit-identical to each other) -- and padding costs no arithmetic.  If the library
+    cannot run exact-mask mode in its current configuration (tuning switches FDX_OUTP_SHAPE=0 / FDX_RESBLOCK_MFMA) a defaulted
+    `exact` falls back to masked batches; an explicit `exact=True` raises.  False: the reference's own padded-batch semantics with x_masks /
     cond_masks (the masked tail stays alive inside the receptive field: the last ~75 frames of every padded item differ slightly
     from a run alone)."""
     if len(features) != len(f0s):
@@ -101,9 +104,10 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     if mel_scale is None:   # nsf_hifigan.py:79-80: a log10 mel is rescaled to natural log
         mel_scale = 2.30259 if getattr(vocoder, "use_natural_log", True) is False else 1.0
     dev = features[mine[0]].device
+    exact_defaulted = exact is None
     if exact is None:
         den = getattr(diffusion, "denoise_fn", None)
-        exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")   # (fp16x3: ragged runs take the fp32 kernels)
+        exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")
     out = []
     for group in make_batches([lengths[i] for i in mine], max_batch, padding_free=bool(exact)):
         idx = [mine[g] for g in group]
@@ -126,7 +130,15 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
             kw["lengths"] = [lengths[i] for i in idx]
         elif ragged:
             kw["x_masks"] = kw["cond_masks"] = masks
-        mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
+        try:
+            mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
+        except NotImplementedError:
+            if not (ragged and exact and exact_defaulted):
+                raise
+            exact = False          # the library's current tuning configuration has no exact-mask kernels: the reference's masked batches
+            kw.pop("lengths")
+            kw["x_masks"] = kw["cond_masks"] = masks
+            mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)
         for b, i in enumerate(idx):
             n = lengths[i]
             vkw = {}

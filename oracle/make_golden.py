@@ -52,7 +52,8 @@ def save(name, **arrays):
 
 # which make_golden section writes which fixture (prefix match), for tests/golden/MANIFEST.json
 FIXTURE_SECTIONS = (("convnext_cross", "convnext_cross"), ("convnext", "convnext"), ("frontend_expand", "frontend_expand"), ("frontend_svs", "frontend_svs"),
-                    ("tfdec", "tfdec"), ("refinegan_sine", "refinegan_sine"), ("nsf_v1_256_full", "round2"), ("chain_", "round2"))
+                    ("tfdec", "tfdec"), ("refinegan_sine", "refinegan_sine"), ("nsf_v1_256_full", "round2"), ("chain_c1", "round2"), ("chain_c2", "round2"),
+                    ("chain_", "round3"), ("ddpm1000_", "round3"))
 
 
 def write_manifest():
@@ -548,6 +549,119 @@ def golden_round2(R):
              ref_vs_f64_wav_abs=np.float64(e_wav), ref_vs_f64_mel_rel=np.float64(e_mel))
 
 
+def _ref_frontend(R, sd, n_speakers=10):
+    """A module carrying REAL reference encoder instances whose `forward_features` / `get_mask_from_lengths` are the reference's own
+    method source (archs/diffsinger/diffsinger.py:41-134) -- DiffSinger.__init__ itself pulls lightning / wandb and is skipped."""
+    get_mask, fwd_features = R["diffsinger_methods"]()
+    Enc = R["NaiveProjectionEncoder"]
+
+    class RefFrontEnd(torch.nn.Module):
+        forward_features = fwd_features
+
+        def __init__(self):
+            super().__init__()
+            self.get_mask_from_lengths = get_mask.__func__ if hasattr(get_mask, "__func__") else get_mask
+            self.text_encoder = Enc(256, 256)
+            self.speaker_encoder = Enc(n_speakers, 256, use_embedding=True)
+            self.pitch_encoder = Enc(1, 256, preprocessing=R["pitch_to_scale"])
+            self.load_state_dict(sd, strict=True)
+
+    return RefFrontEnd().eval()
+
+
+@torch.no_grad()
+def golden_round3(R):
+    """Round-3 fixtures (VERDICT r2 "missing 2", "weak 3").
+    (a) ddpm1000_full_T430 / ddpm1000_full_T861: BASELINE configs[4]'s sampler AT FULL SIZE from the real `GaussianDiffusion`:
+        `noise_predictor="naive"`, `sampler_interval=1` => 1000 denoiser calls (diffusions/diffusion.py:246-253,
+        noise_predictor.py:73-104), diff_svc_v2 WaveNet C = 512 x 20 layers, batch 1, 5 s and 10 s.  The 1000 injected noises
+        (220 / 441 MB) are not stored: `ddpm_noise(seed, ...)` regenerates the reference's own draw sequence, verified by SHA-1.
+    (b) ddpm1000_spk_chain: the multi-speaker shape of configs[4] -- the reference's `DiffSinger.forward_features` (speaker
+        embedding + content + pitch encoders, its own masks for two different lengths) feeding the same 1000-step run, batch 2.
+    (c) chain_c3 / c4 / c5: three more seeded draws of the chained features -> 100-step UniPC -> NSF-HiFiGAN -> waveform fixture
+        (golden_round2 (b)), so that the 1e-4 chained bar is shown on five draws instead of two.
+    """
+    import time
+    sd = wavenet_ref.seeded_wavenet_state(1234, **{k: v for k, v in WN_FULL.items() if k != "dilation_cycle"})
+    diff = build_ref_diffusion(R, WN_FULL, sd)
+    den = oracle_denoiser(sd, WN_FULL)
+    for T, seed, check_oracle in ((430, 4301, True), (861, 4302, False)):
+        print(f"round 3: full-size 1000-step DDPM, T = {T}")
+        feats = torch.randn(1, T, 256, generator=torch.Generator().manual_seed(seed))
+        t0 = time.perf_counter()
+        torch.manual_seed(seed + 100)
+        ref = diff(feats, sampler_interval=1, noise_predictor="naive")
+        print(f"  reference: {time.perf_counter() - t0:.1f} s")
+        x_init, step_noise = sampler_ref.ddpm_noise(seed + 100, 1, 128, T, 1000)
+        if check_oracle:
+            mine = sampler_ref.diffusion_sample(den, feats, x_init=x_init, sampler_interval=1, predictor="naive", step_noise=step_noise)
+            assert torch.equal(mine, ref), "oracle 1000-step DDPM (full net) != reference"
+        # T = 861: the oracle's equality with the reference is the T = 430 case (same code, same draw order); here the reference runs alone
+        save(f"ddpm1000_full_T{T}", features=feats, x_init=x_init, mel=ref, interval=np.int64(1), noise_seed=np.int64(seed + 100),
+             step_noise_sha1=np.array(sha1_of([step_noise])), step_noise_first=step_noise[0, 0, :4, :8].clone(),
+             weights_seed=np.int64(1234), weights_sha1=np.array(state_sha1(sd)))
+        del step_noise
+
+    print("round 3: multi-speaker front end -> 1000-step DDPM (full net), batch 2 with masks")
+    sd_f = features_ref.seeded_frontend_state(11)
+    fe = _ref_frontend(R, sd_f)
+    g = torch.Generator().manual_seed(4310)
+    B, T = 2, 215
+    contents = torch.randn(B, T, 256, generator=g)
+    f0 = torch.stack([synth_f0(T), synth_f0(T) * 1.5])
+    lens = torch.tensor([215, 176])
+    spk = torch.tensor([7, 2])
+    fr = fe.forward_features(spk, contents, lens, T, mel_lens=lens, mel_max_len=T, pitches=f0.clone())
+    mine_f = features_ref.forward_features(sd_f, contents, spk, f0, None, None, lens, T)
+    assert torch.equal(mine_f["features"], fr["features"]) and torch.equal(mine_f["x_masks"], fr["x_masks"])
+    torch.manual_seed(4311)
+    ref = diff(fr["features"], sampler_interval=1, noise_predictor="naive", x_masks=fr["x_masks"], cond_masks=fr["cond_masks"])
+    x_init, step_noise = sampler_ref.ddpm_noise(4311, B, 128, T, 1000)
+    mine = sampler_ref.diffusion_sample(den, fr["features"], x_init=x_init, sampler_interval=1, predictor="naive", step_noise=step_noise,
+                                        x_masks=fr["x_masks"], cond_masks=fr["cond_masks"])
+    assert torch.equal(mine, ref), "oracle multi-speaker 1000-step DDPM != reference"
+    save("ddpm1000_spk_chain", contents=contents, f0=f0, lens=lens, speakers=spk, features=fr["features"], masks=fr["x_masks"],
+         x_init=x_init, mel=ref, noise_seed=np.int64(4311), step_noise_sha1=np.array(sha1_of([step_noise])),
+         frontend_sha1=np.array(state_sha1(sd_f)), weights_sha1=np.array(state_sha1(sd)))
+    del step_noise
+
+    print("round 3: three more chained features -> waveform draws")
+    hv = nsf_hifigan_ref.CONFIG_V1
+    vsd = nsf_hifigan_ref.seeded_generator_state(55, hv)
+    gen = R["Generator"](R["AttrDict"](hv))
+    gen.remove_weight_norm()
+    gen.eval()
+    gen.load_state_dict(vsd, strict=True)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    vsd64 = {k: v.double() for k, v in vsd.items()}
+    den64_ = oracle_denoiser(sd64, WN_FULL)
+    den64 = lambda x, t, c, xm, cm: den64_(x, t.double(), c, xm, cm)   # noqa: E731
+    for tag, T, interval, seed in (("c3", 861, 10, 1236), ("c4", 645, 10, 1237), ("c5", 517, 10, 1238)):
+        gg = torch.Generator().manual_seed(seed)
+        feats = torch.randn(1, T, 256, generator=gg)
+        f0 = synth_f0(T)[None] * (1.0 + 0.25 * (seed - 1236))
+        torch.manual_seed(seed + 100)
+        mel_ref = diff(feats, sampler_interval=interval)
+        torch.manual_seed(seed + 200)
+        wav_ref = gen(2.30259 * mel_ref.transpose(1, 2), f0)
+        torch.manual_seed(seed + 100)
+        x_init = torch.randn(1, 128, T)
+        torch.manual_seed(seed + 200)
+        rand_ini = torch.rand(1, 9)
+        rand_ini[:, 0] = 0
+        src_noise = torch.randn(1, T * hv["hop_size"], 9)
+        mel64 = sampler_ref.diffusion_sample(den64, feats.double(), x_init=x_init.double(), sampler_interval=interval)
+        wav64 = nsf_hifigan_ref.generator_forward(vsd64, hv, 2.30259 * mel64.transpose(1, 2), f0.double(), rand_ini.double(),
+                                                  src_noise.double())
+        e_mel = float((mel_ref.double() - mel64).abs().max() / mel64.abs().max())
+        e_wav = float((wav_ref.double() - wav64).abs().max())
+        print(f"  chain_{tag}: reference fp32 vs fp64 data path: mel rel {e_mel:.3e}, wav abs {e_wav:.3e}")
+        save(f"chain_{tag}", features=feats, f0=f0, x_init=x_init, rand_ini=rand_ini, mel=mel_ref, wav=wav_ref,
+             mel64=mel64.float(), wav64=wav64.float(), interval=np.int64(interval), noise_seed=np.int64(seed + 200),
+             src_noise_sha1=np.array(sha1_of([src_noise])), wn_sha1=np.array(state_sha1(sd)), voc_sha1=np.array(state_sha1(vsd)),
+             ref_vs_f64_wav_abs=np.float64(e_wav), ref_vs_f64_mel_rel=np.float64(e_mel))
+
+
 @torch.no_grad()
 def main():
     os.makedirs(GOLD, exist_ok=True)
@@ -852,6 +966,7 @@ def main():
     golden_convnext_cross(R)
     golden_refinegan_sine(R)
     golden_frontend_svs(R)
+    golden_round3(R)
 
     write_manifest()
     print("done")
@@ -859,7 +974,7 @@ def main():
 
 if __name__ == "__main__":
     SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2, "convnext_cross": golden_convnext_cross, "refinegan_sine": golden_refinegan_sine,
-                "frontend_svs": golden_frontend_svs}
+                "frontend_svs": golden_frontend_svs, "round3": golden_round3}
     if len(sys.argv) == 2 and sys.argv[1] == "manifest":   # re-index the fixtures on disk (no reference needed)
         write_manifest()
     elif len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only

@@ -257,3 +257,19 @@ def q_sample(x_start, t: int, noise, betas: np.ndarray):
     """diffusion.py:120-127."""
     ac = np.cumprod(1.0 - betas, axis=0)
     return f32(np.sqrt(ac))[t] * x_start + f32(np.sqrt(1.0 - ac))[t] * noise
+
+
+def ddpm_noise_stream(seed, B, M, T, n_steps):
+    """The draws GaussianDiffusion.forward makes from torch's global RNG in a `noise_predictor="naive"` run, in order
+    (diffusion.py:222 `torch.randn(shape)`, then one `torch.randn_like(x)` per step, noise_predictor.py:101): yields x_T, then the
+    n_steps step noises.  Restores nothing: callers own the global RNG while iterating."""
+    torch.manual_seed(seed)
+    yield torch.randn(B, M, T)
+    for _ in range(n_steps):
+        yield torch.randn(B, M, T)
+
+
+def ddpm_noise(seed, B, M, T, n_steps):
+    it = ddpm_noise_stream(seed, B, M, T, n_steps)
+    x_init = next(it)
+    return x_init, torch.stack(list(it))

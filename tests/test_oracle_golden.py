@@ -333,3 +333,30 @@ def test_golden_manifest_lists_every_fixture():
         assert e["section"].startswith("python -m oracle.make_golden")
     for need in ("nsf_v1_256_full.npz", "chain_c1.npz", "chain_c2.npz", "frontend_svs.npz", "convnext_cross_small.npz"):
         assert need in m["fixtures"], need
+
+
+def test_round3_fixtures_regenerate_the_reference_draws_and_front_end():
+    """Round-3 fixtures (oracle/make_golden.py `golden_round3`): the 1000 DDPM step noises are not stored -- `sampler_ref.ddpm_noise`
+    regenerates the reference's draw sequence from the recorded seed and must hit the stored SHA-1 (T = 430: 220 MB); the
+    multi-speaker chain's front-end features are what the pinned restatement computes from the stored inputs; the oracle's first
+    DDPM steps from those features stay finite (the 1000-step equality itself was asserted against the real reference when the
+    fixture was written: 50 s of CPU, not re-run here)."""
+    import hashlib
+    from oracle import features_ref, sampler_ref
+    g = load("ddpm1000_full_T430")
+    x_init, step_noise = sampler_ref.ddpm_noise(int(g["noise_seed"]), 1, 128, 430, 1000)
+    assert torch.equal(x_init, g["x_init"])
+    assert torch.equal(step_noise[0, 0, :4, :8], g["step_noise_first"])
+    assert hashlib.sha1(step_noise.numpy().tobytes()).hexdigest() == str(g["step_noise_sha1"])
+    assert sha1_state(wavenet_sd(WN_FULL, int(g["weights_seed"]))) == str(g["weights_sha1"])
+    assert g["mel"].shape == (1, 430, 128) and int(g["interval"]) == 1
+    c = load("ddpm1000_spk_chain")
+    sd_f = features_ref.seeded_frontend_state(11)
+    assert sha1_state(sd_f) == str(c["frontend_sha1"])
+    with torch.no_grad():
+        f = features_ref.forward_features(sd_f, c["contents"], torch.as_tensor(c["speakers"]), c["f0"], None, None, torch.as_tensor(c["lens"]),
+                                          c["contents"].shape[1])
+    assert torch.equal(f["features"], c["features"]) and torch.equal(f["x_masks"], c["masks"])
+    for need in ("chain_c3", "chain_c4", "chain_c5"):
+        z = load(need)
+        assert z["wav"].shape[-1] == z["features"].shape[1] * 512 and float(z["ref_vs_f64_wav_abs"]) > 0

@@ -39,9 +39,12 @@ names = ["setup+prefetch", "K loop", "LDS write", "barrier wait", "epilogue"]
 print(f"{'launch':>6} {'waves':>6} {'span':>8} | " + " ".join(f"{n:>14}" for n in names) + " | total/wave  first 4 slots (shader cycles, mean over waves; span = last end - first start; first 4 slots = t6 - t1: fill + 4 slots of MFMA issue)")
 for l in range(NL):
     w = tr[l].reshape(-1, 8)
-    w = w[w[:, 0] != 0]
+    w = w[w[:, 0] != 0].copy()
     if not len(w):
         continue
+    for k in range(1, 6):        # kernels that do not stamp a phase (f16s64: no LDS-write / barrier phases): that phase reads 0
+        z = w[:, k] == 0
+        w[z, k] = w[z, k - 1]
     d = np.diff(w[:, :6].astype(np.int64), axis=1)
     span = int(w[:, 5].max() - w[:, 0].min())
     first = (w[:, 6].astype(np.int64) - w[:, 1].astype(np.int64))
