@@ -358,7 +358,7 @@ def main():
     ap.add_argument("--storage", choices=("fp32", "bf16", "fp16x3"), default="fp32",
                     help="bf16: the WaveNet's OPT-IN bf16 storage mode (BASELINE configs[4]); not parity-grade, reported as its own dtype.  "
                          "fp16x3: the OPT-IN fp16-split mode (hi + lo operands, three fp16 MFMAs per product block, fp32 accumulate): fp32-class "
-                         "results, used by launches with enough LDS tiles (batch >= 2 at 10 s); reported as its own dtype")
+                         "results (64 x 64 tiles below 200 wide tiles, 128-wide LDS tiles above); reported as its own dtype")
     ap.add_argument("--prof-stride", type=int, default=None, help="time every N-th launch of the dominant kernel")
     ap.add_argument("--no-exact", action="store_true", help="sharded config: the reference's padded-batch semantics (x_masks / cond_masks) instead of "
                     "the library's exact-ragged batches (every utterance as if run alone; padding tiles skipped)")
@@ -620,7 +620,7 @@ def main():
         "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if (cfg == "sharded" and world > 1) else "weak", "vs_baseline": None,
         "dtype": ("bf16 storage / f32 accumulate (opt-in mode, not parity-grade)" if bf16 else
-                  "fp16 hi+lo split operands x3 MFMA / f32 accumulate (opt-in mode, fp32-class; launches with too few LDS tiles run the f32 kernels)" if f16s
+                  "fp16 hi+lo split operands x3 MFMA / f32 accumulate (opt-in mode, fp32-class: held to the fp32 parity bars)" if f16s
                   else "f32"),
         "data": "synthetic (seeded N(0,1) features, vibrato f0 with an unvoiced gap; random-init weights of the named architecture)",
         "config": dict({"workload": workload, "name": cfg,

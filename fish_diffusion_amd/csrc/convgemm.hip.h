@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <cstdlib>
 
 namespace fdx {
 
@@ -44,6 +45,7 @@ struct ConvArgs {
   int tiles_per_item;             // ceil(T / cols_per_block)
   int n_tiles_n;                  // B * tiles_per_item
   int n_mtiles;
+  int xcd_rect;                   // tile -> XCD map: 0 = row runs (batch 1); large grids: 1 = 2 row halves x 4 column quarters, 2 = 4 row quarters x 2 column halves
   float in_slope;                 // leaky-relu slope applied to the B operand (PRE == 1 instantiations)
   // PRE == PRE_LN (LayerNorm over the K = channel axis folded into the GEMM, convnext.hip).  The B operand holds
   // GROUP-centred values u - mean_g (groups of 32 channels); col_stats [item][T][2][16] = {mean_g[16], M2_g[16]} per frame;
@@ -77,11 +79,58 @@ struct ConvArgsCold {
 #define FDX_CONV_HOT_PARAMS                                                                                                   \
   const float4 *__restrict__ h_Wp, const float *__restrict__ h_X, long h_xbs, int h_ldx, int h_n_it, int h_taps, int h_shift0, \
       int h_dshift, int h_T, int h_ntn, int h_nmt
-#define FDX_CONV_HOT_ARGS(a) (a).Wp, (a).X, (a).x_bstride, (a).ldx, (a).n_it, (a).taps, (a).shift0, (a).dshift, (a).T, (a).n_tiles_n, (a).n_mtiles
+// (the tile -> XCD map choice rides in the signs of the n_mtiles / n_tiles_n dwords: hot arguments, no extra kernarg load)
+#define FDX_CONV_HOT_ARGS(a) (a).Wp, (a).X, (a).x_bstride, (a).ldx, (a).n_it, (a).taps, (a).shift0, (a).dshift, (a).T, \
+  ((a).xcd_rect == 2 ? -(a).n_tiles_n : (a).n_tiles_n), ((a).xcd_rect ? -(a).n_mtiles : (a).n_mtiles)
+
+// Tile -> XCD map of the 16x16x4 residual-block kernels (block b runs on XCD b % 8, the 8 L2s are private).
+//   row runs (batch 1):  XCD x owns a contiguous run of G/8 logical tiles in row-major order = a couple of row tiles x all column tiles:
+//     the weights are fetched once chip-wide, the (small) activation operand once per XCD.  Right while the activations fit an L2.
+//   rectangles (large grids, `xcd_rect`):  XCD x owns row half (x & 1) x column quarter (x >> 1), walked row-fastest: the resident
+//     workgroups of an XCD cover ALL its row tiles (their weights, 3.1 MB for the dilated conv, stay L2-resident by constant re-use)
+//     and a few column tiles at a time (the activations stream through once).  Batch 16 x 10 s, dilated conv + gate: 625 MB of HBM
+//     traffic per launch with row runs (every XCD streams all 28 MB of activations twice) against 119 MB algorithmic.
+//   The host only sets `xcd_rect` when n_mt is even and n_tiles_n % 4 == 0.
+__device__ __forceinline__ void conv_tile_of_block(int n_tiles_n, int n_mt, int rect, int bid, int& mt, int& nt) {
+  const int G = n_tiles_n * n_mt, xcd = bid & 7, slot = bid >> 3;     // G == gridDim.x, from preloaded arguments
+  if (rect) {
+    const int rs = rect == 2 ? 2 : 1;                                  // log2(row groups)
+    const int MH = n_mt >> rs, NQ = n_tiles_n >> (3 - rs);
+    const int ntl = slot / MH;
+    mt = (xcd & ((1 << rs) - 1)) * MH + (slot - ntl * MH);
+    nt = (xcd >> rs) * NQ + ntl;
+  } else {
+    const int q8 = G >> 3, r8 = G & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    mt = L / n_tiles_n;
+    nt = L - mt * n_tiles_n;
+  }
+}
+// Grids of at least this many workgroups take the rectangle map (FDX_XCD_RECT=<n>; 0: never).
+inline long xcd_rect_min_grid() {
+  static const long v = [] { const char* e = getenv("FDX_XCD_RECT"); return e ? atol(e) : 2048L; }();
+  return v;
+}
+// Row split by measurement (batch 16 x 10 s, HBM bytes per launch from rocprofv3 PMC passes, profiles/r03_ddpm1000_pmc_traffic*.json;
+// row runs | 2 row halves | 4 row quarters): dilated conv + gate (3 taps: 6.3 MB of weights) 625 | 302 | 232 MB against 119 MB algorithmic --
+// a half's 3.1 MB of weights do not stay resident in a 4 MB L2 next to the streaming operands, a quarter's 1.6 MB do; out-projection
+// (1 tap: 2.1 MB of weights) 615 | 208 | 262 MB against 171 MB -- fewer, wider row groups halve the activation re-reads instead.
+// FDX_XCD_RECT_ROWS=2|4 forces one split (A/B runs).
+inline int use_xcd_rect(int n_tiles_n, int n_mt, int taps) {
+  static const int rows = [] { const char* e = getenv("FDX_XCD_RECT_ROWS"); return e ? atoi(e) : 0; }();
+  const long g = (long)n_tiles_n * n_mt, m = xcd_rect_min_grid();
+  if (m <= 0 || g < m) return 0;
+  const bool ok2 = (n_mt & 1) == 0 && (n_tiles_n & 3) == 0, ok4 = (n_mt & 3) == 0 && (n_tiles_n & 1) == 0;
+  if (rows == 2) return ok2 ? 1 : 0;
+  if (rows == 4) return ok4 ? 2 : 0;
+  if (taps > 1) return ok4 ? 2 : (ok2 ? 1 : 0);
+  return ok2 ? 1 : (ok4 ? 2 : 0);
+}
 #define FDX_CONV_ARGS_FROM_HOT(cold)                                                                                   \
   ConvArgs a;                                                                                                          \
   a.Wp = h_Wp; a.X = h_X; a.x_bstride = h_xbs; a.ldx = h_ldx; a.n_it = h_n_it; a.taps = h_taps; a.shift0 = h_shift0;   \
-  a.dshift = h_dshift; a.T = h_T; a.n_tiles_n = h_ntn; a.n_mtiles = h_nmt;                                            \
+  a.dshift = h_dshift; a.T = h_T; a.n_tiles_n = h_ntn < 0 ? -h_ntn : h_ntn; a.n_mtiles = h_nmt < 0 ? -h_nmt : h_nmt; \
+  a.xcd_rect = h_nmt < 0 ? (h_ntn < 0 ? 2 : 1) : 0; \
   conv_args_cold(a, cold)
 
 #ifdef FDX_KTRACE
@@ -920,6 +969,7 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   a.tiles_per_item = (g.T + cols - 1) / cols;
   a.n_tiles_n = g.B * a.tiles_per_item;
   a.n_mtiles = g.n_mtiles;
+  a.xcd_rect = 0;                      // (this family keeps the row-run map; VAR_XCD_RECT is its own experiment)
   a.in_slope = in_slope;
   a.col_stats = col_stats; a.ln_R = ln_R; a.n_groups = n_groups; a.ln_eps = ln_eps;
   if (g.n_mtiles % MT) return hipErrorInvalidValue;

@@ -105,11 +105,8 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
   const int lj = lane & 15, lk = lane >> 4;           // B: column group / k-row;  A: row-in-block / k;  D: column group / row quad
   FDX_STAMP(0);
 
-  const int G = a.n_tiles_n * a.n_mtiles, bid = blockIdx.x;   // == gridDim.x, from preloaded arguments
-  const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
-  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int mt = L / a.n_tiles_n;
-  const int nt = L - mt * a.n_tiles_n;
+  int mt, nt;
+  conv_tile_of_block(a.n_tiles_n, a.n_mtiles, a.xcd_rect, blockIdx.x, mt, nt);
   const int item = nt / a.tiles_per_item;
   const int t0 = (nt - item * a.tiles_per_item) * 64;
   const int tc = t0 + 4 * lj;                         // this lane's column quad
@@ -258,6 +255,7 @@ inline hipError_t launch_convgemm16(const ConvGeom& g, const float4* Wp, const f
   a.tiles_per_item = (g.T + 63) / 64;
   a.n_tiles_n = g.B * a.tiles_per_item;
   a.n_mtiles = g.n_mtiles;
+  a.xcd_rect = use_xcd_rect(a.n_tiles_n, a.n_mtiles, a.taps);
   a.in_slope = 1.f;
   a.col_stats = nullptr; a.ln_R = nullptr; a.n_groups = 0; a.ln_eps = 0.f;
   const int grid = a.n_tiles_n * a.n_mtiles;

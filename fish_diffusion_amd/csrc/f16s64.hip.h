@@ -25,11 +25,19 @@ namespace fdx {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kS64Win = 64 + 16;            // staged columns per block: tile + 8 either side (dilation <= 8)
-constexpr int kS64Waves = 4, kS64Stages = 3;
+constexpr int kS64Waves = 4;
+constexpr int kS64StagesConv = 3, kS64StagesOutp = 4;   // defaults (measured, 1 x 10 s, ms per 50 calls: 3/3 27.07, 3/4 26.09, 4/4 26.62, 3/6 26.93, 4/8 27.32)
 
-template <class Epi, int DBG = 0>
+template <int... I, class F>
+__device__ __forceinline__ void s64_for_each_stage(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+// NST: LDS stages (a stage is 34 KB for the conv, 18 KB for the one-tap out-projection).  The K loop is bound by LDS-DMA latency, not
+// by its MFMAs (tools/ktrace.py: 1340 cycles per 32-channel block of the conv against 576 cycles of MFMA issue with three stages, i.e.
+// one stage of look-ahead), so the stage count is how many blocks the DMA runs ahead: NST - 2 whole stages stay in flight across a barrier.
+template <class Epi, int NST = 3, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
-  constexpr int TAPS = Epi::kTaps, NW = kS64Waves, WIN = kS64Win, NST = kS64Stages;
+  constexpr int TAPS = Epi::kTaps, NW = kS64Waves, WIN = kS64Win;
+  static_assert(NST >= 3, "at least three stages");
   constexpr int A_G = TAPS * 2 * 4 * 64;            // 16-byte groups of A per stage: [tap][hl][kg][64 rows]
   constexpr int B_G = 8 * WIN;                      // ... of B: 8 group rows of the 32-channel block
   constexpr int A_LD = A_G / (64 * NW);             // A pieces (1 KiB) per wave per stage
@@ -92,9 +100,10 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
     else if (q < A_LD + QB) glds16(pb + bo[q - A_LD], l + (A_G + (q - A_LD) * NW * 64) * 16);
     else if (wave < RB) glds16(pb + bo[QB], l + (A_G + QB * NW * 64) * 16);
   };
-  auto wait_landed = [&]() {                          // the newest stage stays in flight across the barrier
-    if (wave < RB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + QB + 1) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + QB) : "memory");
+  auto wait_landed = [&]() {                          // the newest NST - 2 stages stay in flight across the barrier
+    static_assert((NST - 2) * (A_LD + QB + 1) <= 63, "vmcnt is a 6-bit counter");
+    if (wave < RB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (A_LD + QB + 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (A_LD + QB)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -142,14 +151,60 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
     }
   };
 
-  // ---- K loop over the 32-channel blocks, three stages with compile-time indices (see bf16lds_kernel)
-  const int last = a.n_blk - 1;
+  // ---- the epilogue's operands (conditioner slab | residual stream / skip sum, biases, keep mask), requested HERE so that they land
+  // behind the K loop: issued after it they were 3.6 k (conv + gate) / 6.4 k (out-projection) cycles of exposed latency per workgroup
+  // (tools/ktrace.py, round 3).  Unconditional loads: a column >= T lies in the rows' right pad (readable, the value is not used).
+  // They are older than every DMA piece, so the counted waits below cover them.
+  float e_a[2][2][4];          // paired: [nb][gate | filter][k]      unpaired: [nb][x][k] = old X / SK
+  float e_b[2][4], e_c[2][4];  // unpaired: bias [x][k], next layer's step bias [x][k]
+  float e_k[2];                // unpaired: keep [nb]
   FDX_STAMP(0);
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int t = t0 + wc * 32 + nb * 16 + li;
+    if constexpr (Epi::kPaired) {
+      const int ch0 = mt * 32 + wr * 16 + 4 * kg;
+      const float* Pg = epi.P + item * epi.p_bs + t;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e_a[nb][0][k] = Pg[(long)(ch0 + k) * epi.ldp];
+        e_a[nb][1][k] = Pg[(long)(ch0 + k + epi.C) * epi.ldp];
+      }
+    } else {
+      const float* kp = (epi.Yb && epi.keep) ? epi.keep + item * epi.keep_bs + t : epi.bias;
+      e_k[nb] = *kp;
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int blk0 = mt * 64 + wr * 32 + x * 16, row0 = blk0 + 4 * kg;
+        const bool res = blk0 < epi.C;
+        const float* RW = (res ? epi.X : epi.SK) + item * epi.bs + (long)(res ? row0 : row0 - epi.C) * epi.ld + t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e_a[nb][x][k] = RW[(long)k * epi.ld];
+      }
+    }
+  }
+  if constexpr (!Epi::kPaired) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int blk0 = mt * 64 + wr * 32 + x * 16, row0 = blk0 + 4 * kg;
+      const bool use_sb = blk0 < epi.C && epi.Yb;
+      const float* sbp = use_sb ? epi.sb + item * epi.sb_bs : epi.bias;
+      const long sbs = use_sb ? epi.sb_ld : 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e_b[x][k] = epi.bias[row0 + k];
+        e_c[x][k] = sbp[(long)(row0 + k) * sbs];
+      }
+    }
+  }
+
+  // ---- K loop over the 32-channel blocks, NST stages with compile-time indices (see bf16lds_kernel)
+  const int last = a.n_blk - 1;
   if (!(DBG & 1)) {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) piece(q, 0, 0);
+    for (int st = 0; st < NST - 1; ++st)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) piece(q, min(1, last), 1);
+      for (int q = 0; q < NP; ++q) piece(q, min(st, last), st);
   }
   wait_landed();
   FDX_STAMP(1);
@@ -158,11 +213,10 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
     compute(S, min(blk + NST - 1, last), (S + NST - 1) % NST);
     wait_landed();
   };
-  for (int blk = 0; blk < a.n_blk; blk += NST) {
-    body(std::integral_constant<int, 0>{}, blk);
-    if (blk + 1 < a.n_blk) body(std::integral_constant<int, 1>{}, blk + 1);
-    if (blk + 2 < a.n_blk) body(std::integral_constant<int, 2>{}, blk + 2);
-  }
+  for (int blk = 0; blk < a.n_blk; blk += NST)
+    s64_for_each_stage(std::make_integer_sequence<int, NST>{}, [&](auto S_) {
+      if (blk + decltype(S_)::value < a.n_blk) body(S_, blk + decltype(S_)::value);
+    });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-loads must have landed before this workgroup's LDS is released
   FDX_STAMP(2);
 
@@ -174,20 +228,13 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
     if (t >= a.T) continue;
     if constexpr (Epi::kPaired) {
       const int ch0 = mt * 32 + wr * 16 + 4 * kg;               // this lane's 4 channels: gate rows = acc[0], filter rows = acc[1]
-      const float* Pg = epi.P + item * epi.p_bs + t;
-      float pg[4], pf[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        pg[k] = Pg[(long)(ch0 + k) * epi.ldp];
-        pf[k] = Pg[(long)(ch0 + k + epi.C) * epi.ldp];
-      }
       float z[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) z[k] = EpiGate::gate1(acc[0][nb][k] * epi.acc_scale + pg[k], acc[1][nb][k] * epi.acc_scale + pf[k]);
+      for (int k = 0; k < 4; ++k)
+        z[k] = EpiGate::gate1(acc[0][nb][k] * epi.acc_scale + e_a[nb][0][k], acc[1][nb][k] * epi.acc_scale + e_a[nb][1][k]);
       bf_store_quad<1>(epi.Zb, item * epi.zb_bs, epi.ldz, ch0, t, z, epi.out_scale);
     } else {
-      const float* kp = (epi.Yb && epi.keep) ? epi.keep + item * epi.keep_bs + t : epi.bias;
-      const float kraw = *kp;
+      const float kraw = e_k[nb];
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const int blk0 = mt * 64 + wr * 32 + x * 16;            // 16 rows entirely on one side of C
@@ -196,25 +243,15 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
         const long o0 = item * epi.bs + (long)(res ? row0 : row0 - epi.C) * epi.ld + t;
         float* __restrict__ RW = res ? epi.X : epi.SK;
         const bool rd = res || epi.skip_mode == 1 || epi.skip_mode == 2;
-        const bool use_sb = res && epi.Yb;
-        const float* sbp = use_sb ? epi.sb + item * epi.sb_bs : epi.bias;
-        const long sbs = use_sb ? epi.sb_ld : 1;
-        float old[4], bi[4], sbv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          bi[k] = epi.bias[row0 + k];
-          old[k] = RW[o0 + (long)k * epi.ld];
-          sbv[k] = sbp[(long)(row0 + k) * sbs];
-        }
         float y[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float v = acc[x][nb][k] * epi.acc_scale + bi[k];
+          float v = acc[x][nb][k] * epi.acc_scale + e_b[x][k];
           if (res) {
-            v = div_const(old[k] + v, 1.41421356237309504880f, 0.70710678118654752440f);
-            y[k] = (epi.Yb && (!epi.keep || kraw != 0.f)) ? v + sbv[k] : 0.f;
+            v = div_const(e_a[nb][x][k] + v, 1.41421356237309504880f, 0.70710678118654752440f);
+            y[k] = (epi.Yb && (!epi.keep || kraw != 0.f)) ? v + e_c[x][k] : 0.f;
           } else {
-            if (rd) v = old[k] + v;
+            if (rd) v = e_a[nb][x][k] + v;
             if (epi.skip_mode >= 2) v = div_const(v, epi.inv_div, epi.r_inv_div);
           }
           RW[o0 + (long)k * epi.ld] = v;
@@ -242,8 +279,20 @@ inline hipError_t launch_f16s64(const uint4* Wp, const uint4* Xb, long x_bs, int
   if (g_trace.buf && g_trace.n < g_trace.max_launches && grid <= g_trace.blocks_cap)
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
-  if (ev0) hipExtLaunchKernelGGL((f16s64_kernel<Epi>), dim3(grid), dim3(256), 0, s, ev0, ev1, 0, a, epi);
-  else hipLaunchKernelGGL((f16s64_kernel<Epi>), dim3(grid), dim3(256), 0, s, a, epi);
+  // stage count: FDX_F16S_NST (conv: 3 | 4) / FDX_F16S_NST_O (out-projection: 3 | 4 | 6 | 8) override the defaults (A/B runs)
+  static const int nst_c = [] { const char* e = getenv("FDX_F16S_NST"); const int k = e ? atoi(e) : 0; return (k == 3 || k == 4) ? k : kS64StagesConv; }();
+  static const int nst_o = [] { const char* e = getenv("FDX_F16S_NST_O"); const int k = e ? atoi(e) : 0; return (k == 3 || k == 4 || k == 6 || k == 8) ? k : kS64StagesOutp; }();
+#define FDX_S64_LAUNCH(N)                                                                                       \
+  do {                                                                                                          \
+    if (ev0) hipExtLaunchKernelGGL((f16s64_kernel<Epi, N>), dim3(grid), dim3(256), 0, s, ev0, ev1, 0, a, epi);  \
+    else hipLaunchKernelGGL((f16s64_kernel<Epi, N>), dim3(grid), dim3(256), 0, s, a, epi);                      \
+  } while (0)
+  if constexpr (Epi::kTaps == 3) {
+    if (nst_c == 4) FDX_S64_LAUNCH(4); else FDX_S64_LAUNCH(3);
+  } else {
+    if (nst_o == 8) FDX_S64_LAUNCH(8); else if (nst_o == 6) FDX_S64_LAUNCH(6); else if (nst_o == 4) FDX_S64_LAUNCH(4); else FDX_S64_LAUNCH(3);
+  }
+#undef FDX_S64_LAUNCH
   return hipGetLastError();
 }
 

@@ -56,11 +56,12 @@ static long bf16_lds_min_tiles() {
   return v;
 }
 static bool bf16_lds_enabled() { return bf16_lds_min_tiles() > 0; }
-// fp16-split mode: its alternative is the fp32 kernels (3x the MFMA time), not the register-direct bf16 ones, so it pays from 112 tiles
-// (batch 2 at 10 s: 67 vs 71 ms per 50 steps; batch 3: 70 vs 117; batch 4: 71 vs 146; batch 1 = 56 tiles: 61 vs 41 -- fp32 stays).
-// FDX_BF16_LDS overrides this threshold too (the tests force the mode for every geometry with FDX_BF16_LDS=1).
+// fp16-split mode, 128-wide LDS tiles (bf16lds.hip.h, F16S): taken from 200 tiles of 128 x 128 (batch 4 at 10 s); below that the 64 x 64
+// tiles of f16s64.hip.h run.  Measured crossover (round 3, ms per 50 UniPC steps, 10 s items; fp32 kernels | 64 x 64 | 128-wide):
+// batch 1: 37.1 | 27.2 | 59.4;  2: 66.3 | 40.3 | 66.0;  3: 114.8 | 64.9 | 67.9;  4: 141.8 | 75.0 | 67.9;  6: 208 | 107 | 98.7;  8: 252 | 132 | 104.
+// FDX_BF16_LDS overrides this threshold too (the tests force the wide tiles for every geometry with FDX_BF16_LDS=1).
 static long f16s_min_tiles() {
-  static const long v = [] { const char* e = getenv("FDX_BF16_LDS"); return e ? atol(e) : 112L; }();
+  static const long v = [] { const char* e = getenv("FDX_BF16_LDS"); return e ? atol(e) : 200L; }();
   return v;
 }
 constexpr size_t kBfTileSlack = 8192;   // bytes behind the blocked 16-bit operand buffers (see wn_alloc)
@@ -554,10 +555,12 @@ static __global__ void k_f16s64_from_arena(_Float16* __restrict__ dst, const flo
   const size_t out = (size_t)layer * (per_conv + per_outp) + (conv ? 0 : per_conv) + g;
   *reinterpret_cast<f16x8*>(dst + out * 8) = v;
 }
-// FDX_F16S_SMALL=1: also derive the small-tile image and use f16s64_kernel for launches below the 128 x 128 tile threshold that have at
-// least this many 64 x 64 tiles (1: 160; n > 1: n).  Default off: only the forward / sampler golden tests have run with it so far.
+// The small-tile image is derived alongside and f16s64_kernel serves every launch below the wide-tile threshold: it is never slower than
+// the fp32 kernels (1 x 1.25 s: 23.5 vs 23.8 ms per 50 steps -- both launch-bound; 1 x 5 s: 24.8 vs 25.4; 1 x 7.5 s: 26.5 vs 33.4; 1 x 10 s:
+// 27.2 vs 37.1).  FDX_F16S_SMALL=0 switches it off (the fp32 kernels below the wide-tile threshold, round 2's behaviour); =<n>: only
+// launches with at least n 64 x 64 tiles.
 static long f16s_small_min_tiles() {
-  static const long v = [] { const char* e = getenv("FDX_F16S_SMALL"); const long k = e ? atol(e) : 0; return k == 1 ? 160L : k; }();
+  static const long v = [] { const char* e = getenv("FDX_F16S_SMALL"); return e ? atol(e) : 1L; }();
   return v;
 }
 

@@ -153,11 +153,12 @@ def test_exact_ragged_contract_per_storage_mode_default_thresholds(dev):
     """with the library's DEFAULT kernel thresholds a ragged row long enough for the fp16-split tiles runs them while
     each item alone (a quarter of the tiles) runs the fp32 MFMA kernels.  Contract, as documented in include/fishdx.h and
     GaussianDiffusion.forward: fp32 storage -> every item bit for bit its batch-1 run; fp16x3 storage -> to fp32 rounding (2e-5 of the
-    peak over a 10-step run), both fp32-class.  Full-size net, 4 x ~5 s items (one ragged row of ~1800 frames)."""
+    peak over a 10-step run), both fp32-class.  Full-size net, 8 x ~5 s items: the row runs the 128-wide fp16-split tiles, an item
+    alone the 64 x 64 ones."""
     sd = wavenet_sd(WN_FULL, 1234)
     diff = _diffusion(WN_FULL, sd, dev)
     g = torch.Generator().manual_seed(90)
-    lens, T = [430, 401, 470, 388], 470
+    lens, T = [430, 401, 470, 388, 455, 410, 466, 397], 470      # one row of ~3500 frames: 224 tiles of 128 x 128 (wide-tile threshold: 200)
     B = len(lens)
     feats, x0 = torch.randn(B, T, 256, generator=g).to(dev), torch.randn(B, 128, T, generator=g).to(dev)
     start = diff.denoise_fn.storage

@@ -572,3 +572,36 @@ def test_wavenet_bf16_packing_and_blocked_layout_match_kernel_index_math(lib):
     assert net.storage == "bf16"
     with pytest.raises(ValueError):
         net.storage = "fp16"
+
+
+def test_xcd_rect_tile_map_is_a_bijection():
+    """csrc/convgemm.hip.h `conv_tile_of_block` (mirrored here): block b runs on XCD b % 8; with a rectangle map XCD x owns one of
+    2 row halves x 4 column quarters (mode 1) or 4 row quarters x 2 column halves (mode 2), walked row-fastest.  Every logical tile
+    exactly once, every XCD inside its rectangle, and the tiles an XCD has in flight at once (32 consecutive slots) cover all of its
+    row tiles."""
+    def tile_of_block(n_tiles_n, n_mt, rect, bid):
+        G, xcd, slot = n_tiles_n * n_mt, bid & 7, bid >> 3
+        if rect:
+            rs = 2 if rect == 2 else 1
+            MH, NQ = n_mt >> rs, n_tiles_n >> (3 - rs)
+            ntl = slot // MH
+            return (xcd & ((1 << rs) - 1)) * MH + (slot - ntl * MH), (xcd >> rs) * NQ + ntl
+        q8, r8 = G >> 3, G & 7
+        L = (xcd * (q8 + 1) if xcd < r8 else r8 * (q8 + 1) + (xcd - r8) * q8) + slot
+        return L // n_tiles_n, L % n_tiles_n
+    for rect in (1, 2):
+        rs = rect
+        for n_tiles_n, n_mt in ((224, 16), (128, 32), (4, 4), (12, 16)):
+            G = n_tiles_n * n_mt
+            seen = {tile_of_block(n_tiles_n, n_mt, rect, b) for b in range(G)}
+            assert seen == {(m, n) for m in range(n_mt) for n in range(n_tiles_n)}
+            for b in range(G):
+                m, n = tile_of_block(n_tiles_n, n_mt, rect, b)
+                x = b & 7
+                assert m // (n_mt >> rs) == (x & ((1 << rs) - 1)) and n // (n_tiles_n >> (3 - rs)) == (x >> rs)
+            if G // 8 >= 32 and (n_mt >> rs) <= 32:
+                first = {tile_of_block(n_tiles_n, n_mt, rect, 8 * s)[0] for s in range(32)}
+                assert first == set(range(n_mt >> rs))
+    for n_tiles_n, n_mt in ((14, 16), (8, 32), (7, 3)):      # the row-run map, any shape
+        G = n_tiles_n * n_mt
+        assert {tile_of_block(n_tiles_n, n_mt, 0, b) for b in range(G)} == {(m, n) for m in range(n_mt) for n in range(n_tiles_n)}

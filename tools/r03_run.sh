@@ -22,9 +22,31 @@ for what in "$@"; do
     sweep-outp) for v in ${SWEEP_OUTP:-27 24 25 26 28 44 45}; do echo "FDX_OUTP_SHAPE=$v"; FDX_OUTP_SHAPE=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/sweep_outp_$v.json 2> $O/sweep_outp_$v.err; line $O/sweep_outp_$v.json; done ;;
     sweep-conv) for v in ${SWEEP_CONV:-27 24 25 26 28 44 45}; do echo "FDX_CONV_SHAPE=$v"; FDX_CONV_SHAPE=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/sweep_conv_$v.json 2> $O/sweep_conv_$v.err; line $O/sweep_conv_$v.json; done ;;
     sweep-voc) for v in ${SWEEP_VOC:-512 400 200 100}; do echo "FDX_NOSPLIT_MIN_WGS=$v"; FDX_NOSPLIT_MIN_WGS=$v python bench.py --no-cpu-baseline --no-pcie --no-prof --steps 5 --warmup 2 > $O/sweep_voc_$v.json 2> $O/sweep_voc_$v.err; line $O/sweep_voc_$v.json; done ;;
-    ktrace-f16s) FDX_F16S_SMALL=1 python tools/ktrace.py 1 20 fp16x3 > $O/ktrace_f16s64.txt 2>&1; head -n 8 $O/ktrace_f16s64.txt ;;
+    ktrace-f16s) python tools/ktrace.py 1 20 fp16x3 > $O/ktrace_f16s64.txt 2>&1; head -n 8 $O/ktrace_f16s64.txt ;;
     ktrace) python tools/ktrace.py 1 20 > $O/ktrace_fp32.txt 2>&1; head -n 8 $O/ktrace_fp32.txt ;;
-    f16s-small) for v in 1; do echo "FDX_F16S_SMALL=$v --storage fp16x3"; FDX_F16S_SMALL=$v python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json; done ;;
+    cross) G="${CROSS_GEO:-1x108 1x215 1x430 1x645 1x861 2x430 2x861 3x861 4x861 6x861 8x861}"
+           python tools/f16s_cross.py fp32 $G 2>&1 | grep CROSS | tee $O/cross_fp32.txt
+           FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 $G 2>&1 | grep CROSS | tee $O/cross_small.txt
+           FDX_BF16_LDS=1 python tools/f16s_cross.py fp16x3 $G 2>&1 | grep CROSS | tee $O/cross_big.txt ;;
+    nst) for c in 3 4; do for o in 3 4 6 8; do FDX_F16S_NST=$c FDX_F16S_NST_O=$o FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 1x861 1x430 2>&1 | grep CROSS; done; done | tee $O/nst.txt ;;
+    sweep-outp1) SWEEP_OUTP="14 15 16 17 18" bash tools/r03_run.sh $tag sweep-outp ;;
+    tests-f16s-small) K=$(python -c "import tests.test_gpu_round2 as t; print(t.FP16X3_SUBSET)")
+           ( time FDX_WAVENET_STORAGE=fp16x3 FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round3.py -m gpu -q -x -s -k "$K" ) > $O/gpu_tests_f16s_small.log 2>&1
+           echo "pytest rc $?" >> $O/gpu_tests_f16s_small.log; grep -E "passed|failed|error|rel err|chain|ragged" $O/gpu_tests_f16s_small.log | tail -n 40 ;;
+    rect) for v in 0 2048; do echo "FDX_XCD_RECT=$v ddpm1000 (100 of 1000 steps), batch 16"; FDX_XCD_RECT=$v python bench.py --config ddpm1000 --steps 2 --warmup 1 --interval 10 --no-cpu-baseline > $O/rect_$v.json 2> $O/rect_$v.err; line $O/rect_$v.json; done
+          for v in 0 1024; do echo "FDX_XCD_RECT=$v ddpm1000 (100 steps), batch 8"; FDX_XCD_RECT=$v python bench.py --config ddpm1000 --batch 8 --steps 2 --warmup 1 --interval 10 --no-cpu-baseline > $O/rect8_$v.json 2> $O/rect8_$v.err; line $O/rect8_$v.json; done
+          for v in 0 512; do echo "FDX_XCD_RECT=$v headline batch 4"; FDX_XCD_RECT=$v python bench.py --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-pcie > $O/rect4_$v.json 2> $O/rect4_$v.err; line $O/rect4_$v.json; done ;;
+    rect-rows) for r in 2 4; do echo "FDX_XCD_RECT_ROWS=$r ddpm1000 (100 steps), batch 16"; FDX_XCD_RECT_ROWS=$r python bench.py --config ddpm1000 --steps 2 --warmup 1 --interval 10 --no-cpu-baseline > $O/rectrows_$r.json 2> $O/rectrows_$r.err; line $O/rectrows_$r.json
+               FDX_XCD_RECT_ROWS=$r bash tools/r02_run.sh $tag pmc-ddpm1000 > /dev/null 2>&1; mv $O/ddpm1000_pmc_traffic.json $O/ddpm1000_pmc_traffic_rows$r.json
+               python -c "
+import json,sys
+d=json.load(open('$O/ddpm1000_pmc_traffic_rows$r.json'))
+for k,v in d['kernels'].items():
+    if 'Gate' in k or 'ResSkip' in k: print('   ', k[:60], 'fetch MB', round(v['fetch_bytes']/1e6,1), 'write MB', round(v['write_bytes']/1e6,1), 'total', round(v['hbm_bytes']/1e6,1))
+"; done ;;
+    test-shapes) python -m pytest tests/test_gpu_round2.py -m gpu -x -q -s -k every_conv_tile_shape 2>&1 | tail -n 5 ;;
+    f16s-small) echo "--storage fp16x3"; python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json ;;
+    cross-small) FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 ${CROSS_GEO:-1x430 1x861 2x861} 2>&1 | grep CROSS | tee $O/cross_small2.txt ;;
     headline) python bench.py > $O/bench_headline.json 2> $O/bench_headline.err; echo "headline rc $?"; tail -n 3 $O/bench_headline.err; line $O/bench_headline.json ;;
     *) bash tools/r02_run.sh $tag $what ;;
   esac
