@@ -20,6 +20,17 @@ def main():
         for name, ctr, n, mean, tot in rows:
             print(f"{short(name):<70} {ctr:<28} {n:>7} {mean:>16.1f} {tot:>18.0f}")
         return
+    if "--sequence" in sys.argv:      # the last N launches in start order: name, duration, grid (one vocoder pass is ~140 launches)
+        n = int(sys.argv[sys.argv.index("--sequence") + 1])
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+        gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else "0")
+        wx = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else "1")
+        rows = db.execute(f"select name, (end - start) / 1e3, {gx}, {wx}, start from kernels order by start desc limit {n}").fetchall()[::-1]
+        t0 = rows[0][4] if rows else 0
+        print(f"{'#':>4} {'t_us':>10} {'dur_us':>9} {'wgs':>7}  kernel      (columns of `kernels`: {cols})")
+        for i, (name, dur, g, w, st) in enumerate(rows):
+            print(f"{i:>4} {(st - t0) / 1e3:>10.1f} {dur:>9.2f} {int(g) // max(1, int(w)):>7}  {short(name, 110)}")
+        return
     rows = db.execute("""select name, count(*), sum(end - start) / 1e3, avg(end - start) / 1e3, min(end - start) / 1e3,
                          max(end - start) / 1e3 from kernels group by name order by 3 desc""").fetchall()
     total = sum(r[2] for r in rows) or 1.0

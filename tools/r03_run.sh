@@ -44,6 +44,8 @@ d=json.load(open('$O/ddpm1000_pmc_traffic_rows$r.json'))
 for k,v in d['kernels'].items():
     if 'Gate' in k or 'ResSkip' in k: print('   ', k[:60], 'fetch MB', round(v['fetch_bytes']/1e6,1), 'write MB', round(v['write_bytes']/1e6,1), 'total', round(v['hbm_bytes']/1e6,1))
 "; done ;;
+    voc-seq) ( cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof_voc -o p -- python $GRAFT_REPO_ROOT/tools/vocbench.py 1 > $GRAFT_REPO_ROOT/$O/vocbench.log 2>&1 )
+             db=$(ls $O/prof_voc/*/*.db $O/prof_voc/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db --sequence 150 > $O/voc_sequence.txt; tail -n 3 $O/vocbench.log; head -n 5 $O/voc_sequence.txt; rm -rf $O/prof_voc ;;
     test-shapes) python -m pytest tests/test_gpu_round2.py -m gpu -x -q -s -k every_conv_tile_shape 2>&1 | tail -n 5 ;;
     f16s-small) echo "--storage fp16x3"; python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json ;;
     cross-small) FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 ${CROSS_GEO:-1x430 1x861 2x861} 2>&1 | grep CROSS | tee $O/cross_small2.txt ;;
