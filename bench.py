@@ -443,7 +443,7 @@ def main():
         C_, M_ = WN_CFG["residual_channels"], B * T
         alg_bytes = 4 * (2 * C_ * 3 * C_ + C_ * M_ + 2 * C_ * M_ + C_ * M_)   # weights + Y in + conditioner slab in + Z out
         kwhat = "dilated conv k=3 + gate of the residual block"
-        traffic_key, traffic_expect = "convgate", {"config": "headline", "batch": B, "frames": T}
+        traffic_key, traffic_expect = "convgate", {"config": "headline" + ("_bf16" if bf16 else "_fp16x3" if f16s else ""), "batch": B, "frames": T}
     elif cfg == "vocoder":
         B = args.batch or 32
         n_steps = 0

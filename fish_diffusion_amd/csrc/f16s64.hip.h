@@ -24,7 +24,6 @@ namespace fdx {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kS64Win = 64 + 16;            // staged columns per block: tile + 8 either side (dilation <= 8)
 constexpr int kS64Waves = 4;
 constexpr int kS64StagesConv = 3, kS64StagesOutp = 4;   // defaults (measured, 1 x 10 s, ms per 50 calls: 3/3 27.07, 3/4 26.09, 4/4 26.62, 3/6 26.93, 4/8 27.32)
 
@@ -36,7 +35,9 @@ __device__ __forceinline__ void s64_for_each_stage(std::integer_sequence<int, I.
 // one stage of look-ahead), so the stage count is how many blocks the DMA runs ahead: NST - 2 whole stages stay in flight across a barrier.
 template <class Epi, int NST = 3, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
-  constexpr int TAPS = Epi::kTaps, NW = kS64Waves, WIN = kS64Win;
+  constexpr int TAPS = Epi::kTaps, NW = kS64Waves;
+  constexpr int PAD = TAPS == 3 ? 8 : 0;            // columns staged either side of the tile: the dilated taps reach 8; the one-tap GEMM none
+  constexpr int WIN = 64 + 2 * PAD;                 // (out-projection without pads: 18 -> 16 KB per stage, 10.7 -> 9.3 us per launch with 4 stages)
   static_assert(NST >= 3, "at least three stages");
   constexpr int A_G = TAPS * 2 * 4 * 64;            // 16-byte groups of A per stage: [tap][hl][kg][64 rows]
   constexpr int B_G = 8 * WIN;                      // ... of B: 8 group rows of the 32-channel block
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
   const int t0 = (nt - item * a.tiles_per_item) * 64;
 
   const uint4* Ag = a.Wp + (size_t)mt * a.n_blk * A_G;
-  const uint4* Bg = a.Xb + item * a.x_bs + (t0 - 8);
+  const uint4* Bg = a.Xb + item * a.x_bs + (t0 - PAD);
 
   f32x4_t acc[2][2];
 #pragma unroll
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
   auto piece = [&](int q, int bk, int st) {
     const unsigned l = lds0 + (unsigned)st * (STAGE_G * 16);
     const uint4* pb = Bg + (size_t)bk * b_blk;
-    if (q < A_LD) glds16(Ag + (size_t)bk * A_G + tid + q * NW * 64, l + q * NW * 1024);
+    if (q < A_LD) glds16(Ag + (size_t)bk * A_G + tid + q * NW * 64, l + q * NW * 1024);   // (an `nt` policy on this weight stream measured 5 % slower)
     else if (q < A_LD + QB) glds16(pb + bo[q - A_LD], l + (A_G + (q - A_LD) * NW * 64) * 16);
     else if (wave < RB) glds16(pb + bo[QB], l + (A_G + QB * NW * 64) * 16);
   };
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
     const uint4* lb = lds + st * STAGE_G + A_G + ((kg >> 1) * 4 + (kg & 1)) * WIN + wc * 32 + li;
     uint4 fa[2][2][2], fb[2][2][2];                  // [set][hl][x | nb]
     auto frag = [&](int tap, int set) {
-      const int shift = TAPS == 3 ? 8 + (tap - 1) * a.dil : 8;
+      const int shift = TAPS == 3 ? PAD + (tap - 1) * a.dil : 0;
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl) {
 #pragma unroll
@@ -151,10 +152,13 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
     }
   };
 
-  // ---- the epilogue's operands (conditioner slab | residual stream / skip sum, biases, keep mask), requested HERE so that they land
-  // behind the K loop: issued after it they were 3.6 k (conv + gate) / 6.4 k (out-projection) cycles of exposed latency per workgroup
-  // (tools/ktrace.py, round 3).  Unconditional loads: a column >= T lies in the rows' right pad (readable, the value is not used).
-  // They are older than every DMA piece, so the counted waits below cover them.
+  // ---- the epilogue's operands (conditioner slab | residual stream / skip sum, biases, keep mask), requested HERE, in front of the first
+  // operand stage: their (cold) latency overlaps that stage's own and they land behind the K loop.  Unconditional loads: a column >= T
+  // lies in the rows' right pad (readable, the value is not used).  They are older than every DMA piece, so the counted waits cover them.
+  // Round-3 measurements, batch 1 x 10 s, us per launch (conv + gate / out-projection; FDX_F16S_DBG builds): operands loaded after the K loop
+  // 15.2 / 12.1;  HERE as register loads 15.1 / 10.7 (9.3 with the pad-free window);  the same 64 x 64 fp32 tile by LDS-DMA in front of the
+  // first stage 15.2 / 10.1, by LDS-DMA in the K loop's last two bodies 16.0 / 11.0 (two stages do not cover a cold fetch);  with neither
+  // epilogue nor operands 9.1 / 6.2 -- the rest is the K loop's DMA (its MFMAs alone: 7.5 / 4.3).
   float e_a[2][2][4];          // paired: [nb][gate | filter][k]      unpaired: [nb][x][k] = old X / SK
   float e_b[2][4], e_c[2][4];  // unpaired: bias [x][k], next layer's step bias [x][k]
   float e_k[2];                // unpaired: keep [nb]
@@ -279,20 +283,30 @@ inline hipError_t launch_f16s64(const uint4* Wp, const uint4* Xb, long x_bs, int
   if (g_trace.buf && g_trace.n < g_trace.max_launches && grid <= g_trace.blocks_cap)
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
-  // stage count: FDX_F16S_NST (conv: 3 | 4) / FDX_F16S_NST_O (out-projection: 3 | 4 | 6 | 8) override the defaults (A/B runs)
+  // stage count: FDX_F16S_NST (conv: 3 | 4) / FDX_F16S_NST_O (out-projection: 3 | 4; 6 and 8 measured no better) override the defaults (A/B runs)
   static const int nst_c = [] { const char* e = getenv("FDX_F16S_NST"); const int k = e ? atoi(e) : 0; return (k == 3 || k == 4) ? k : kS64StagesConv; }();
-  static const int nst_o = [] { const char* e = getenv("FDX_F16S_NST_O"); const int k = e ? atoi(e) : 0; return (k == 3 || k == 4 || k == 6 || k == 8) ? k : kS64StagesOutp; }();
-#define FDX_S64_LAUNCH(N)                                                                                       \
-  do {                                                                                                          \
-    if (ev0) hipExtLaunchKernelGGL((f16s64_kernel<Epi, N>), dim3(grid), dim3(256), 0, s, ev0, ev1, 0, a, epi);  \
-    else hipLaunchKernelGGL((f16s64_kernel<Epi, N>), dim3(grid), dim3(256), 0, s, a, epi);                      \
+  static const int nst_o = [] { const char* e = getenv("FDX_F16S_NST_O"); const int k = e ? atoi(e) : 0; return (k == 3 || k == 4) ? k : kS64StagesOutp; }();
+  // FDX_F16S_DBG=1 | 4 | 5 | 8: timing-only builds of the default instantiation WITHOUT its DMA / its MFMAs and fragment reads / both / its
+  // epilogue (results are garbage): which side bounds the kernel (tools/f16s_cross.py and bench.py do not look at the numbers)
+  static const int dbg = [] { const char* e = getenv("FDX_F16S_DBG"); return e ? atoi(e) : 0; }();
+#define FDX_S64_LAUNCH_D(N, D)                                                                                     \
+  do {                                                                                                             \
+    if (ev0) hipExtLaunchKernelGGL((f16s64_kernel<Epi, N, D>), dim3(grid), dim3(256), 0, s, ev0, ev1, 0, a, epi);  \
+    else hipLaunchKernelGGL((f16s64_kernel<Epi, N, D>), dim3(grid), dim3(256), 0, s, a, epi);                      \
   } while (0)
-  if constexpr (Epi::kTaps == 3) {
+#define FDX_S64_LAUNCH(N) FDX_S64_LAUNCH_D(N, 0)
+  constexpr int NDEF = Epi::kTaps == 3 ? kS64StagesConv : kS64StagesOutp;
+  if (dbg == 1) FDX_S64_LAUNCH_D(NDEF, 1);
+  else if (dbg == 4) FDX_S64_LAUNCH_D(NDEF, 4);
+  else if (dbg == 8) FDX_S64_LAUNCH_D(NDEF, 8);
+  else if (dbg == 5) FDX_S64_LAUNCH_D(NDEF, 5);
+  else if constexpr (Epi::kTaps == 3) {
     if (nst_c == 4) FDX_S64_LAUNCH(4); else FDX_S64_LAUNCH(3);
   } else {
-    if (nst_o == 8) FDX_S64_LAUNCH(8); else if (nst_o == 6) FDX_S64_LAUNCH(6); else if (nst_o == 4) FDX_S64_LAUNCH(4); else FDX_S64_LAUNCH(3);
+    if (nst_o == 3) FDX_S64_LAUNCH(3); else FDX_S64_LAUNCH(4);
   }
 #undef FDX_S64_LAUNCH
+#undef FDX_S64_LAUNCH_D
   return hipGetLastError();
 }
 

@@ -15,8 +15,31 @@ except Exception as e:
     print("  (no JSON line)", e)
 PY
 }
+# do_prof <name> <bench.py args...>: rocprofv3 --kernel-trace --stats of the bench command -> $O/<name>_kernel_stats.txt (+ the bench line run under the profiler)
+do_prof() { n=$1; shift
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_$n -o p -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-pcie > $GRAFT_REPO_ROOT/$O/${n}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/prof_$n.log )
+  db=$(ls $O/prof_$n/*/*.db $O/prof_$n/*.db 2>/dev/null | head -1)
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $* --no-cpu-baseline --no-pcie   (round 3)"; python tools/prof_summary.py $db; } > $O/${n}_kernel_stats.txt; head -n 8 $O/${n}_kernel_stats.txt | cut -c1-200; rm -rf $O/prof_$n; }
+# do_pmc <name> <workload tag for tools/pmc_traffic.py> <bench.py args...>: FETCH_SIZE and WRITE_SIZE in separate passes -> $O/<name>_pmc_traffic.json
+do_pmc() { n=$1; wl=$2; shift 2
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && rocprofv3 --pmc $ctr -d $GRAFT_REPO_ROOT/$O/pmc_${n}_$ctr -o p -- python $GRAFT_REPO_ROOT/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-pcie --no-prof > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_${n}_$ctr.log )
+  done
+  f=$(ls $O/pmc_${n}_FETCH_SIZE/*/*.db $O/pmc_${n}_FETCH_SIZE/*.db 2>/dev/null | head -1); w=$(ls $O/pmc_${n}_WRITE_SIZE/*/*.db $O/pmc_${n}_WRITE_SIZE/*.db 2>/dev/null | head -1)
+  python tools/pmc_traffic.py $f $w $wl > $O/${n}_pmc_traffic.json; head -c 400 $O/${n}_pmc_traffic.json; echo; rm -rf $O/pmc_${n}_FETCH_SIZE $O/pmc_${n}_WRITE_SIZE; }
 for what in "$@"; do
   case $what in
+    r3prof-headline) do_prof headline --config headline ;;
+    r3prof-headline_fp16x3) do_prof headline_fp16x3 --config headline --storage fp16x3 ;;
+    r3prof-ddpm1000) do_prof ddpm1000 --config ddpm1000 --interval 10 --steps 2 --warmup 1 ;;
+    r3prof-ddpm1000_fp16x3) do_prof ddpm1000_fp16x3 --config ddpm1000 --storage fp16x3 --interval 10 --steps 2 --warmup 1 ;;
+    r3prof-sharded) do_prof sharded --config sharded ;;
+    r3prof-vocoder) do_prof vocoder --config vocoder ;;
+    r3pmc-headline) do_pmc headline headline --config headline ;;
+    r3pmc-headline_fp16x3) do_pmc headline_fp16x3 headline_fp16x3 --config headline --storage fp16x3 ;;
+    r3pmc-ddpm1000) do_pmc ddpm1000 ddpm1000 --config ddpm1000 --interval 10 ;;
+    r3bench) for c in headline vocoder sharded ddpm1000; do python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc $?"; line $O/bench_$c.json; done
+             for c in headline sharded ddpm1000; do python bench.py --config $c --storage fp16x3 > $O/bench_${c}_fp16x3.json 2> $O/bench_${c}_fp16x3.err; echo "$c fp16x3 rc $?"; line $O/bench_${c}_fp16x3.json; done ;;
     tests-r3) python -m pytest tests/test_gpu_round3.py -m gpu -x -q -s > $O/gpu_tests_r3.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests_r3.log; grep -v "^$" $O/gpu_tests_r3.log | tail -n 40 ;;
     tests) ( time python -m pytest tests -m gpu -x -q ) > $O/gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests.log; tail -n 15 $O/gpu_tests.log ;;
     sweep-outp) for v in ${SWEEP_OUTP:-27 24 25 26 28 44 45}; do echo "FDX_OUTP_SHAPE=$v"; FDX_OUTP_SHAPE=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/sweep_outp_$v.json 2> $O/sweep_outp_$v.err; line $O/sweep_outp_$v.json; done ;;
@@ -48,6 +71,8 @@ for k,v in d['kernels'].items():
              db=$(ls $O/prof_voc/*/*.db $O/prof_voc/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db --sequence 150 > $O/voc_sequence.txt; tail -n 3 $O/vocbench.log; head -n 5 $O/voc_sequence.txt; rm -rf $O/prof_voc ;;
     test-shapes) python -m pytest tests/test_gpu_round2.py -m gpu -x -q -s -k every_conv_tile_shape 2>&1 | tail -n 5 ;;
     f16s-small) echo "--storage fp16x3"; python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json ;;
+    cross-nt) for v in 0 1; do FDX_F16S_NT=$v FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 1x861 2x861 2>&1 | grep CROSS | sed "s/^/nt=$v /"; done | tee $O/cross_nt.txt ;;
+    f16s-dbg) for v in 0 1 4 5 8; do echo "FDX_F16S_DBG=$v"; FDX_F16S_DBG=$v python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie --steps 3 --warmup 1 > $O/f16s_dbg_$v.json 2> $O/f16s_dbg_$v.err; line $O/f16s_dbg_$v.json | head -1; done ;;
     cross-small) FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 ${CROSS_GEO:-1x430 1x861 2x861} 2>&1 | grep CROSS | tee $O/cross_small2.txt ;;
     headline) python bench.py > $O/bench_headline.json 2> $O/bench_headline.err; echo "headline rc $?"; tail -n 3 $O/bench_headline.err; line $O/bench_headline.json ;;
     *) bash tools/r02_run.sh $tag $what ;;
