@@ -13,10 +13,10 @@
 //                   k_f16s64_from_arena), B = the 8 group rows x (64 + 16) columns of the blocked activations exactly as they lie in
 //                   memory ([hi g0][hi g1][lo g0][lo g1] of the two 16-channel halves), 34 KB per stage, three stages.
 //
-// Status (end of round 2, the last GPU minutes): the WaveNet-forward and sampler golden tests pass with this kernel forced for every
-// geometry (9 tests, fp32 tolerances), and batch 1 x 10 s runs 50 denoiser calls in 29 ms against 40 ms on the fp32 kernels (untuned,
-// first build).  The broad parity subset the large-tile kernels are held to, and the tile thresholds, are not measured yet, so it
-// stays behind FDX_F16S_SMALL=1 (off by default).
+// Status (round 3): on by default in the fp16-split mode for every launch below 200 wide tiles (wavenet.hip: f16s_small_min_tiles); held to the
+// same broad parity subset as the wide tiles with this kernel forced for every geometry (42 tests: reference goldens incl. the full-size
+// 1000-step DDPM fixtures, chained waveforms, exact-ragged batches).  Batch 1 x 10 s: 24.6 ms per 50 denoiser calls against 37.1 on the
+// fp32 kernels; `python bench.py --storage fp16x3`: 179x real-time per GPU.  DESIGN.md section 5 has what bounds it (LDS-DMA, ~5 us fixed).
 #pragma once
 #include "bf16lds.hip.h"
 
