@@ -377,6 +377,11 @@ struct Shape16 { int NR, NM; };
 // so only the per-iteration count matters) + a fixed ~12 k cycles of set-up / pipeline fill / reduction / epilogue measured with
 // tools/ktrace.py, expressed in MFMA-equivalents of this launch's K loop by the caller (fixed_per_k).  NR = 4 reads a third fewer
 // operand bytes per MFMA, so it wins ties (2 % margin).
+// The model deliberately does NOT credit two co-resident half-size workgroups with hiding each other's fixed phases: measured in round 3
+// on the headline geometry (profiles/r03_shape_sweeps.txt), 448 workgroups of 32 x 64 or 512 of 16 x 112 (two per CU, half the MFMA work
+// each) run the out-projection in 14.1 / 13.3 us against 13.3 us for 256 of 32 x 112, and the dilated conv in 28.6 against 25.5 -- the
+// fixed part of a launch is a serial chain (dispatch ramp, one cold round trip in front of the first MFMA, the store drain), not idle
+// issue slots a second workgroup could fill.  NR = 1 (16-row tiles, out-projection only) is therefore instantiated but never picked.
 inline Shape16 pick_shape16(int rows16, int B, int T, double fixed_mfma_equiv, int n_cu = 256) {
   Shape16 best{4, 4};
   double best_cost = 1e300;

@@ -69,6 +69,8 @@ for k,v in d['kernels'].items():
 "; done ;;
     voc-seq) ( cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof_voc -o p -- python $GRAFT_REPO_ROOT/tools/vocbench.py 1 > $GRAFT_REPO_ROOT/$O/vocbench.log 2>&1 )
              db=$(ls $O/prof_voc/*/*.db $O/prof_voc/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db --sequence 150 > $O/voc_sequence.txt; tail -n 3 $O/vocbench.log; head -n 5 $O/voc_sequence.txt; rm -rf $O/prof_voc ;;
+    fwd-seq) ( cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof_fwd -o p -- python $GRAFT_REPO_ROOT/tools/fwdseq.py > $GRAFT_REPO_ROOT/$O/fwdseq.log 2>&1 )
+             db=$(ls $O/prof_fwd/*/*.db $O/prof_fwd/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db --sequence 50 > $O/fwd_sequence.txt; cut -c1-150 $O/fwd_sequence.txt | tail -n 52; rm -rf $O/prof_fwd ;;
     test-shapes) python -m pytest tests/test_gpu_round2.py -m gpu -x -q -s -k every_conv_tile_shape 2>&1 | tail -n 5 ;;
     f16s-small) echo "--storage fp16x3"; python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json ;;
     cross-nt) for v in 0 1; do FDX_F16S_NT=$v FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 1x861 2x861 2>&1 | grep CROSS | sed "s/^/nt=$v /"; done | tee $O/cross_nt.txt ;;
