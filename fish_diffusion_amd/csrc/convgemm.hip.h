@@ -135,10 +135,15 @@ inline int use_xcd_rect(int n_tiles_n, int n_mt, int taps) {
 
 #ifdef FDX_KTRACE
 #define FDX_STAMP(k) do { if (a.trace && lane == 0) a.trace[((long)blockIdx.x * (blockDim.x >> 6) + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// slot 7: the wave's lifetime on the constant 100 MHz real-time counter (s_memrealtime): shader cycles / real time = the clock the kernel ran at
+#define FDX_STAMP_RT0() const unsigned long long fdx_rt0 = __builtin_amdgcn_s_memrealtime()
+#define FDX_STAMP_RT1() do { if (a.trace && lane == 0) a.trace[((long)blockIdx.x * (blockDim.x >> 6) + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - fdx_rt0; } while (0)
 struct TraceState { unsigned long long* buf = nullptr; int max_launches = 0, n = 0, blocks_cap = 0; };
 inline TraceState g_trace;
 #else
 #define FDX_STAMP(k) do { } while (0)
+#define FDX_STAMP_RT0() do { } while (0)
+#define FDX_STAMP_RT1() do { } while (0)
 #endif
 
 __device__ __forceinline__ void conv_args_cold(ConvArgs& a, const ConvArgsCold& c) {

@@ -924,7 +924,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
 #define FDX_GATE_SHAPE(NR_, NM_)                                                                                              \
   if (NRs == NR_ && NMs == NM_) {                                                                                             \
     const EpiGate16S<NM_> gs{Z, bsC, ld, Pl, p_bs, ld, C};                                                                    \
-    e = launch_convgemm16s<EpiGate16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Y, bsC, ld, gs, s, ev0, ev1);   \
+    e = launch_convgemm16s<EpiGate16S<NM_>, NR_, NM_, (NR_ == 2 && NM_ == 7) ? 3 : 0>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Y, bsC, ld, gs, s, ev0, ev1); \
   }
         FDX_GATE_SHAPE(4, 5) FDX_GATE_SHAPE(4, 6) FDX_GATE_SHAPE(4, 7) FDX_GATE_SHAPE(4, 8)
         FDX_GATE_SHAPE(2, 4) FDX_GATE_SHAPE(2, 5) FDX_GATE_SHAPE(2, 6) FDX_GATE_SHAPE(2, 7) FDX_GATE_SHAPE(2, 8)
@@ -949,7 +949,8 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   if (NRo == NR_ && NMo == NM_) {                                                                                                  \
     const EpiResSkip16S<NM_> rs{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL, \
                                 (float)(1.0 / (double)sqrtL), keep, (long)ld};                                                     \
-    e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : NR_ == 2 ? g2 : g1, NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, Z, bsC, ld, rs, s, eo0, eo1); \
+    e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_, (NR_ == 2 && NM_ == 7) ? 1 : 0>(NR_ == 4 ? g4 : NR_ == 2 ? g2 : g1,                 \
+                                                                                             NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, Z, bsC, ld, rs, s, eo0, eo1); \
   }
       FDX_OUTP_SHAPE(4, 4) FDX_OUTP_SHAPE(4, 5) FDX_OUTP_SHAPE(4, 6) FDX_OUTP_SHAPE(4, 7) FDX_OUTP_SHAPE(4, 8)
       FDX_OUTP_SHAPE(2, 4) FDX_OUTP_SHAPE(2, 5) FDX_OUTP_SHAPE(2, 6) FDX_OUTP_SHAPE(2, 7) FDX_OUTP_SHAPE(2, 8)

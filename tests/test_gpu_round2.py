@@ -370,6 +370,11 @@ print("DIGEST", h.hexdigest())
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIGEST" in r.stdout, "xcd_rect\n" + r.stdout + r.stderr
     digests["xcd_rect"] = r.stdout.split("DIGEST")[1].split()[0]
+    # (round 3) the LDS-staged operand path (FDX_LDS_OPS=1: operands by LDS-DMA into per-wave rings, asm-sequenced K loop) on the shape that has it
+    env = dict(os.environ, FDX_LDS_OPS="1", FDX_CONV_SHAPE="27", FDX_OUTP_SHAPE="27")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIGEST" in r.stdout, "lds_ops\n" + r.stdout + r.stderr
+    digests["lds_ops"] = r.stdout.split("DIGEST")[1].split()[0]
     # (round 3) the out-projection's shape is forced alongside (FDX_OUTP_SHAPE), incl. the 16-row tiles (NR = 1) that only it has
     outp = {"44": "44", "auto": None, "45": "45", "46": "14", "47": "15", "48": "16", "24": "17", "25": "18", "26": "24", "27": "27", "28": "28"}
     for shape in ("44", "auto", "45", "46", "47", "48", "24", "25", "26", "27", "28"):

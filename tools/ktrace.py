@@ -49,4 +49,7 @@ for l in range(NL):
     span = int(w[:, 5].max() - w[:, 0].min())
     first = (w[:, 6].astype(np.int64) - w[:, 1].astype(np.int64))
     first = first[w[:, 6] != 0]
-    print(f"{l:>6} {len(w):>6} {span:>8} | " + " ".join(f"{d[:, i].mean():>14.0f}" for i in range(5)) + f" | {d.sum(1).mean():>10.0f} {first.mean() if len(first) else 0:>10.0f}")
+    rt = w[:, 7].astype(np.int64)
+    rt = rt[(rt > 0) & (rt < 10 ** 7)]
+    clk = f"  {d.sum(1).mean() / (rt.mean() * 10e-9) / 1e9:5.2f} GHz ({rt.mean() * 10:.0f} ns per wave)" if len(rt) else ""
+    print(f"{l:>6} {len(w):>6} {span:>8} | " + " ".join(f"{d[:, i].mean():>14.0f}" for i in range(5)) + f" | {d.sum(1).mean():>10.0f} {first.mean() if len(first) else 0:>10.0f}{clk}")

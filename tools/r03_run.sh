@@ -46,7 +46,7 @@ for what in "$@"; do
     sweep-conv) for v in ${SWEEP_CONV:-27 24 25 26 28 44 45}; do echo "FDX_CONV_SHAPE=$v"; FDX_CONV_SHAPE=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/sweep_conv_$v.json 2> $O/sweep_conv_$v.err; line $O/sweep_conv_$v.json; done ;;
     sweep-voc) for v in ${SWEEP_VOC:-512 400 200 100}; do echo "FDX_NOSPLIT_MIN_WGS=$v"; FDX_NOSPLIT_MIN_WGS=$v python bench.py --no-cpu-baseline --no-pcie --no-prof --steps 5 --warmup 2 > $O/sweep_voc_$v.json 2> $O/sweep_voc_$v.err; line $O/sweep_voc_$v.json; done ;;
     ktrace-f16s) python tools/ktrace.py 1 20 fp16x3 > $O/ktrace_f16s64.txt 2>&1; head -n 8 $O/ktrace_f16s64.txt ;;
-    ktrace) python tools/ktrace.py 1 20 > $O/ktrace_fp32.txt 2>&1; head -n 8 $O/ktrace_fp32.txt ;;
+    ktrace) for v in 0 1; do FDX_LDS_OPS=$v python tools/ktrace.py 1 20 > $O/ktrace_fp32_lds$v.txt 2>&1; echo "FDX_LDS_OPS=$v"; head -n 8 $O/ktrace_fp32_lds$v.txt | cut -c1-200; done ;;
     cross) G="${CROSS_GEO:-1x108 1x215 1x430 1x645 1x861 2x430 2x861 3x861 4x861 6x861 8x861}"
            python tools/f16s_cross.py fp32 $G 2>&1 | grep CROSS | tee $O/cross_fp32.txt
            FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 $G 2>&1 | grep CROSS | tee $O/cross_small.txt
@@ -71,6 +71,8 @@ for k,v in d['kernels'].items():
              db=$(ls $O/prof_voc/*/*.db $O/prof_voc/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db --sequence 150 > $O/voc_sequence.txt; tail -n 3 $O/vocbench.log; head -n 5 $O/voc_sequence.txt; rm -rf $O/prof_voc ;;
     fwd-seq) ( cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof_fwd -o p -- python $GRAFT_REPO_ROOT/tools/fwdseq.py > $GRAFT_REPO_ROOT/$O/fwdseq.log 2>&1 )
              db=$(ls $O/prof_fwd/*/*.db $O/prof_fwd/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db --sequence 50 > $O/fwd_sequence.txt; cut -c1-150 $O/fwd_sequence.txt | tail -n 52; rm -rf $O/prof_fwd ;;
+    dynlds) for v in 0 60000 90000; do echo "FDX_DYN_LDS=$v"; FDX_DYN_LDS=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/dynlds_$v.json 2> $O/dynlds_$v.err; line $O/dynlds_$v.json | head -1; done ;;
+    ldsops) for v in 0 1; do echo "FDX_LDS_OPS=$v"; FDX_LDS_OPS=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/ldsops_$v.json 2> $O/ldsops_$v.err; line $O/ldsops_$v.json; done ;;
     test-shapes) python -m pytest tests/test_gpu_round2.py -m gpu -x -q -s -k every_conv_tile_shape 2>&1 | tail -n 5 ;;
     f16s-small) echo "--storage fp16x3"; python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json ;;
     cross-nt) for v in 0 1; do FDX_F16S_NT=$v FDX_F16S_SMALL=2 FDX_BF16_LDS=1000000000 python tools/f16s_cross.py fp16x3 1x861 2x861 2>&1 | grep CROSS | sed "s/^/nt=$v /"; done | tee $O/cross_nt.txt ;;
