@@ -224,6 +224,8 @@ def roofline_entry(kernel_desc, n, avg_ms, flops, peak, sampling, traffic=None, 
             "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
             "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
             "hbm_fraction": (round(traffic / (avg_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if traffic else None),
+            "peak_note": "nominal peak at the 2.4 GHz boost clock; tools/ktrace.py (s_memtime vs s_memrealtime, instrumented build) measured the fp32 "
+                         "residual-block kernels at 2.05-2.19 GHz on this chip, i.e. an attainable matrix roof of ~134 TFLOP/s (profiles/r03_ktrace_headline_fp32.txt)",
             "launches_timed": n, "sampling": sampling, "avg_launch_us": round(avg_ms * 1e3, 2),
             "timing": "hipExtLaunchKernel start/stop events on the launch stream, timed region", "flops_per_launch": flops}
 

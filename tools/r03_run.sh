@@ -72,6 +72,8 @@ for k,v in d['kernels'].items():
     fwd-seq) ( cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof_fwd -o p -- python $GRAFT_REPO_ROOT/tools/fwdseq.py > $GRAFT_REPO_ROOT/$O/fwdseq.log 2>&1 )
              db=$(ls $O/prof_fwd/*/*.db $O/prof_fwd/*.db 2>/dev/null | head -1); python tools/prof_summary.py $db --sequence 50 > $O/fwd_sequence.txt; cut -c1-150 $O/fwd_sequence.txt | tail -n 52; rm -rf $O/prof_fwd ;;
     dynlds) for v in 0 60000 90000; do echo "FDX_DYN_LDS=$v"; FDX_DYN_LDS=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/dynlds_$v.json 2> $O/dynlds_$v.err; line $O/dynlds_$v.json | head -1; done ;;
+    bigshapes) for v in 44 46 47 48; do echo "FDX_OUTP_SHAPE=$v batch 16"; FDX_OUTP_SHAPE=$v python bench.py --config ddpm1000 --steps 2 --warmup 1 --interval 10 --no-cpu-baseline > $O/big_outp_$v.json 2> $O/big_outp_$v.err; line $O/big_outp_$v.json | head -1; done
+               for v in 46 47 48; do echo "FDX_CONV_SHAPE=$v batch 16"; FDX_CONV_SHAPE=$v python bench.py --config ddpm1000 --steps 2 --warmup 1 --interval 10 --no-cpu-baseline > $O/big_conv_$v.json 2> $O/big_conv_$v.err; line $O/big_conv_$v.json | head -1; done ;;
     ldsops) for v in 0 1; do echo "FDX_LDS_OPS=$v"; FDX_LDS_OPS=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/ldsops_$v.json 2> $O/ldsops_$v.err; line $O/ldsops_$v.json; done ;;
     test-shapes) python -m pytest tests/test_gpu_round2.py -m gpu -x -q -s -k every_conv_tile_shape 2>&1 | tail -n 5 ;;
     f16s-small) echo "--storage fp16x3"; python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json ;;
