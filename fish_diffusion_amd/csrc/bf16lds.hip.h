@@ -261,6 +261,7 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
   // nobody reads again: every iteration issues the same number of pieces, so the counted wait holds to the end.
   const int last = a.n_blk - 1;
   FDX_STAMP(0);
+  FDX_STAMP_RT0();
   if (!(DBG & 1)) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) piece(q, 0, 0);
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
     }
   }
   FDX_STAMP(5);
+  FDX_STAMP_RT1();
 }
 
 template <class Epi, int WN, int F16S>

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lj = lane & 15, lk = lane >> 4;           // B: column group / k-row;  A: row-in-block / k;  D: column group / row quad
   FDX_STAMP(0);
+  FDX_STAMP_RT0();
 
   int mt, nt;
   conv_tile_of_block(a.n_tiles_n, a.n_mtiles, a.xcd_rect, blockIdx.x, mt, nt);
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
     else epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), pre[i]);
   }
   FDX_STAMP(5);
+  FDX_STAMP_RT1();
 }
 
 template <class Epi, int VAR = 0>

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
   float e_b[2][4], e_c[2][4];  // unpaired: bias [x][k], next layer's step bias [x][k]
   float e_k[2];                // unpaired: keep [nb]
   FDX_STAMP(0);
+  FDX_STAMP_RT0();
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int t = t0 + wc * 32 + nb * 16 + li;
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
     }
   }
   FDX_STAMP(5);
+  FDX_STAMP_RT1();
 }
 
 template <class Epi>

@@ -74,6 +74,7 @@ for k,v in d['kernels'].items():
     dynlds) for v in 0 60000 90000; do echo "FDX_DYN_LDS=$v"; FDX_DYN_LDS=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/dynlds_$v.json 2> $O/dynlds_$v.err; line $O/dynlds_$v.json | head -1; done ;;
     bigshapes) for v in 44 46 47 48; do echo "FDX_OUTP_SHAPE=$v batch 16"; FDX_OUTP_SHAPE=$v python bench.py --config ddpm1000 --steps 2 --warmup 1 --interval 10 --no-cpu-baseline > $O/big_outp_$v.json 2> $O/big_outp_$v.err; line $O/big_outp_$v.json | head -1; done
                for v in 46 47 48; do echo "FDX_CONV_SHAPE=$v batch 16"; FDX_CONV_SHAPE=$v python bench.py --config ddpm1000 --steps 2 --warmup 1 --interval 10 --no-cpu-baseline > $O/big_conv_$v.json 2> $O/big_conv_$v.err; line $O/big_conv_$v.json | head -1; done ;;
+    clocks) for a in "1 20 fp32" "1 20 fp16x3" "16 20 fp32" "16 20 fp16x3" "16 20 bf16"; do echo "ktrace $a"; python tools/ktrace.py $a 2>&1 | grep -v amdgpu.ids | cut -c1-220 | sed -n 1,8p | tee -a $O/ktrace_clocks.txt; done ;;
     ldsops) for v in 0 1; do echo "FDX_LDS_OPS=$v"; FDX_LDS_OPS=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/ldsops_$v.json 2> $O/ldsops_$v.err; line $O/ldsops_$v.json; done ;;
     test-shapes) python -m pytest tests/test_gpu_round2.py -m gpu -x -q -s -k every_conv_tile_shape 2>&1 | tail -n 5 ;;
     f16s-small) echo "--storage fp16x3"; python bench.py --storage fp16x3 --no-cpu-baseline --no-pcie > $O/bench_headline_fp16x3.json 2> $O/bench_headline_fp16x3.err; line $O/bench_headline_fp16x3.json ;;
