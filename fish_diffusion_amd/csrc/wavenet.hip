@@ -214,6 +214,11 @@ extern "C" int fdx_wavenet_pack(const fdx_wavenet_desc* d, const float* const* w
   return FDX_OK;
 }
 
+static __global__ void k_acc_vec(float* __restrict__ dst, const float* __restrict__ src, int n) {   // dst += src (attach-time bias sums)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
 extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const void* dev, size_t bytes) {
   GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
@@ -263,6 +268,42 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
         hipLaunchKernelGGL(k_repack16_from32<1>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, nullptr, h->wn_outp16.f() + c2 + 2 * nf, h->wn_arena + p.w_off,
                            p.n_mtiles, p.cin8);
         c2 += 3 * nf;
+      }
+      // Deferred skip sum (experiment, FDX_DEFER_SKIP=<layers per group>): per group, the skip rows' weights of its layers side by side
+      // along K in the chosen tile order ([m-tile][layer][it]), and the sum of their biases.
+      h->defer_group = 0;
+      const int Gd = [] { const char* e = getenv("FDX_DEFER_SKIP"); return e ? atoi(e) : 0; }();
+      if (Gd > 0 && !l.outp.empty()) {
+        const int shp = [] { const char* e = getenv("FDX_DEFER_SHAPE"); return e ? atoi(e) : 27; }();
+        const int rshp = [] { const char* e = getenv("FDX_DEFER_RES_SHAPE"); return e ? atoi(e) : 0; }();
+        const int NRd = shp / 10, NMd = shp % 10;
+        if ((NRd != 1 && NRd != 2 && NRd != 4) || NMd < 4 || NMd > 8) return fail(h, FDX_E_ARG, "FDX_DEFER_SHAPE=%d: NR in {1,2,4}, NM in 4..8", shp);
+        if (rshp && (((rshp / 10) != 1 && (rshp / 10) != 2 && (rshp / 10) != 4) || rshp % 10 < 4 || rshp % 10 > 8))
+          return fail(h, FDX_E_ARG, "FDX_DEFER_RES_SHAPE=%d: NR in {1,2,4}, NM in 4..8", rshp);
+        const int Ld = (int)l.outp.size(), Cd = d->residual_channels, n_it = l.outp[0].cin8;
+        const int n_groups = (Ld + Gd - 1) / Gd;
+        const size_t nf = packed_floats(l.outp[0].n_mtiles, 2, l.outp[0].cin8, 1);   // one layer's [2C x C] matrix
+        FDX_HIP(h, h->wn_skipcat.ensure((size_t)Ld * (nf / 2) * sizeof(float), false, nullptr));
+        FDX_HIP(h, h->wn_skipbias.ensure((size_t)n_groups * Cd * sizeof(float), true, nullptr));
+        const auto& offs = NRd == 4 ? h->wn_outp16_off4 : NRd == 2 ? h->wn_outp16_off2 : h->wn_outp16_off1;
+        const int n_mtp = Cd / (16 * NRd);                     // m-tiles of the skip half
+        const size_t row_f = (size_t)n_it * 128 * NRd;          // floats of one m-tile of one layer
+        h->wn_skipcat_off.clear();
+        size_t cur = 0;
+        for (int g = 0; g < n_groups; ++g) {
+          const int a = g * Gd, lg = std::min(Gd, Ld - a);
+          h->wn_skipcat_off.push_back(cur);
+          for (int j = 0; j < lg; ++j) {
+            FDX_HIP(h, hipMemcpy2DAsync(h->wn_skipcat.f() + cur + (size_t)j * row_f, (size_t)lg * row_f * sizeof(float),
+                                        h->wn_outp16.f() + offs[a + j] + (size_t)n_mtp * row_f, row_f * sizeof(float), row_f * sizeof(float),
+                                        n_mtp, hipMemcpyDeviceToDevice, nullptr));
+            hipLaunchKernelGGL(k_acc_vec, dim3((Cd + 255) / 256), dim3(256), 0, nullptr, h->wn_skipbias.f() + (size_t)g * Cd,
+                               h->wn_arena + l.outp[a + j].b_off + Cd, Cd);
+          }
+          cur += (size_t)lg * (nf / 2);
+        }
+        h->defer_group = Gd; h->defer_nr = NRd; h->defer_nm = NMd; h->defer_res_nr = rshp / 10; h->defer_res_nm = rshp % 10;
+        h->defer_side = [] { const char* e = getenv("FDX_DEFER_SIDE"); return e && atoi(e) != 0; }();
       }
     }
     FDX_HIP(h, hipGetLastError());
@@ -697,6 +738,15 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   FDX_HIP(h, h->X.ensure(sz(C), geom, s));
   FDX_HIP(h, h->Y.ensure(sz(C), geom, s));
   FDX_HIP(h, h->Z.ensure(sz(C), geom, s));
+  if (h->defer_group) {   // deferred skip sum: every layer's gated output; side stream + events made here, never inside a stream capture
+    FDX_HIP(h, h->Zs.ensure(sz(L * C), geom, s));
+    if (h->defer_side && !h->side_stream) FDX_HIP(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    while (h->defer_side && (int)h->side_ev.size() < (L + h->defer_group - 1) / h->defer_group + 1) {
+      hipEvent_t e;
+      FDX_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->side_ev.push_back(e);
+    }
+  }
   FDX_HIP(h, h->SK.ensure(sz(C), geom, s));
   FDX_HIP(h, h->H.ensure(sz(C), geom, s));
   FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
@@ -850,6 +900,19 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
         h->prof.note(PROF_WN_OUTPROJ, "convgemm_kernel<2, true, 0, EpiResSkip> (v_mfma_f32_32x32x2_f32; 64 x 64 split-K workgroup tile)");
     }
   }
+  // Deferred skip sum (FDX_DEFER_SKIP): fp32 shape-adaptive path only
+  const int Gd = (h->defer_group && !f16s && !h->wn_arena_bf16 && conv16() && h->outp_shape_nr &&
+                  !(h->conv_shape_nr == 4 && h->conv_shape_nm == 4)) ? h->defer_group : 0;
+  float* Zs = Gd ? h->Zs.f() + kHalo : nullptr;
+  const long bsZ = Gd ? (long)L * C * ld : bsC;
+  hipStream_t sg = s;                       // the stream the group GEMMs go to
+  int side_used = 0;
+  auto side_event = [&](hipEvent_t& ev) -> hipError_t {
+    if (side_used >= (int)h->side_ev.size()) return hipErrorInvalidValue;   // (made in prepare)
+    ev = h->side_ev[side_used++];
+    return hipSuccess;
+  };
+  if (Gd && h->defer_side && h->side_stream) sg = h->side_stream;
   for (int i = 0; i < L; ++i) {
     const int dil = l.dil[i];
     hipEvent_t ev0 = nullptr, ev1 = nullptr, eo0 = nullptr, eo1 = nullptr;   // fdx_prof_*: one of the two kernels, sampled
@@ -923,7 +986,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
         hipError_t e = hipErrorInvalidValue;
 #define FDX_GATE_SHAPE(NR_, NM_)                                                                                              \
   if (NRs == NR_ && NMs == NM_) {                                                                                             \
-    const EpiGate16S<NM_> gs{Z, bsC, ld, Pl, p_bs, ld, C};                                                                    \
+    const EpiGate16S<NM_> gs{Gd ? Zs + (size_t)i * C * ld : Z, bsZ, ld, Pl, p_bs, ld, C};                                     \
     e = launch_convgemm16s<EpiGate16S<NM_>, NR_, NM_, (NR_ == 2 && NM_ == 7) ? 3 : 0>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Y, bsC, ld, gs, s, ev0, ev1); \
   }
         FDX_GATE_SHAPE(4, 5) FDX_GATE_SHAPE(4, 6) FDX_GATE_SHAPE(4, 7) FDX_GATE_SHAPE(4, 8)
@@ -938,9 +1001,11 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       FDX_HIP(h, (run_gemm<true, false>(A, l.conv[i], B, T, Y, bsC, ld, -dil, dil, 1.f, g, s, ev0, ev1)));
     }
     if (h->outp_shape_nr) {   // shape-adaptive 16x16x4 tiles (weights re-ordered at attach)
-      const int NRo = h->outp_shape_nr, NMo = h->outp_shape_nm;
-      const ConvGeom g4{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles}, g2{B, T, l.outp[i].cin8, 1, 0, 0, 2 * l.outp[i].n_mtiles},
-          g1{B, T, l.outp[i].cin8, 1, 0, 0, 4 * l.outp[i].n_mtiles};
+      const int NRo = (Gd && h->defer_res_nr) ? h->defer_res_nr : h->outp_shape_nr, NMo = (Gd && h->defer_res_nr) ? h->defer_res_nm : h->outp_shape_nm;
+      const int hv = Gd ? 2 : 1;      // deferred skip sum: the residual rows only (the first half of the m-tiles)
+      const float* Zin = Gd ? Zs + (size_t)i * C * ld : Z;
+      const ConvGeom g4{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles / hv}, g2{B, T, l.outp[i].cin8, 1, 0, 0, 2 * l.outp[i].n_mtiles / hv},
+          g1{B, T, l.outp[i].cin8, 1, 0, 0, 4 * l.outp[i].n_mtiles / hv};
       const void* W4 = h->wn_outp16.f() + h->wn_outp16_off4[i];
       const void* W2 = h->wn_outp16.f() + h->wn_outp16_off2[i];
       const void* W1 = h->wn_outp16.f() + h->wn_outp16_off1[i];
@@ -950,13 +1015,38 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     const EpiResSkip16S<NM_> rs{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL, \
                                 (float)(1.0 / (double)sqrtL), keep, (long)ld};                                                     \
     e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_, (NR_ == 2 && NM_ == 7) ? 1 : 0>(NR_ == 4 ? g4 : NR_ == 2 ? g2 : g1,                 \
-                                                                                             NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, Z, bsC, ld, rs, s, eo0, eo1); \
+                                                                                             NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, Zin, bsZ, ld, rs, s, eo0, eo1); \
   }
       FDX_OUTP_SHAPE(4, 4) FDX_OUTP_SHAPE(4, 5) FDX_OUTP_SHAPE(4, 6) FDX_OUTP_SHAPE(4, 7) FDX_OUTP_SHAPE(4, 8)
       FDX_OUTP_SHAPE(2, 4) FDX_OUTP_SHAPE(2, 5) FDX_OUTP_SHAPE(2, 6) FDX_OUTP_SHAPE(2, 7) FDX_OUTP_SHAPE(2, 8)
       FDX_OUTP_SHAPE(1, 4) FDX_OUTP_SHAPE(1, 5) FDX_OUTP_SHAPE(1, 6) FDX_OUTP_SHAPE(1, 7) FDX_OUTP_SHAPE(1, 8)
 #undef FDX_OUTP_SHAPE
       FDX_HIP(h, e);
+      if (Gd && ((i + 1) % Gd == 0 || i + 1 == L)) {   // the skip rows of layers [a, i] as one GEMM with K = (i + 1 - a) C
+        const int g = i / Gd, a = g * Gd, lg = i + 1 - a, n_groups = (L + Gd - 1) / Gd;
+        const int gmode = n_groups == 1 ? 3 : (g == 0 ? 0 : (g + 1 == n_groups ? 2 : 1));
+        if (sg != s) {
+          hipEvent_t ev;
+          FDX_HIP(h, side_event(ev));
+          FDX_HIP(h, hipEventRecord(ev, s));
+          FDX_HIP(h, hipStreamWaitEvent(sg, ev, 0));
+        }
+        const int NRd = h->defer_nr, NMd = h->defer_nm;
+        const ConvGeom gg{B, T, lg * (C / 8), 1, 0, 0, C / (16 * NRd)};
+        const void* Wg = h->wn_skipcat.f() + h->wn_skipcat_off[g];
+        hipError_t eg = hipErrorInvalidValue;
+#define FDX_DEFER_SHAPE(NR_, NM_)                                                                                                       \
+  if (NRd == NR_ && NMd == NM_) {                                                                                                       \
+    const EpiResSkip16S<NM_> rs{X, nullptr, SK, bsC, ld, h->wn_skipbias.f() + (size_t)g * C, sbn, ldn, sb_bs, 0, gmode, sqrtL,          \
+                                (float)(1.0 / (double)sqrtL), nullptr, (long)ld};                                                       \
+    eg = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_, 0>(gg, Wg, Zs + (size_t)a * C * ld, bsZ, ld, rs, sg);                          \
+  }
+        FDX_DEFER_SHAPE(4, 4) FDX_DEFER_SHAPE(4, 7) FDX_DEFER_SHAPE(4, 8)
+        FDX_DEFER_SHAPE(2, 4) FDX_DEFER_SHAPE(2, 5) FDX_DEFER_SHAPE(2, 6) FDX_DEFER_SHAPE(2, 7) FDX_DEFER_SHAPE(2, 8)
+        FDX_DEFER_SHAPE(1, 4) FDX_DEFER_SHAPE(1, 7) FDX_DEFER_SHAPE(1, 8)
+#undef FDX_DEFER_SHAPE
+        FDX_HIP(h, eg);
+      }
     } else if (outp16()) {
       const ConvGeom go{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles};
       EpiResSkip16 r{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL,
@@ -979,6 +1069,12 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
         default: FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s, eo0, eo1)));
       }
     }
+  }
+  if (Gd && sg != s) {   // join: skip_projection reads the group GEMMs' sum
+    hipEvent_t ev;
+    FDX_HIP(h, side_event(ev));
+    FDX_HIP(h, hipEventRecord(ev, sg));
+    FDX_HIP(h, hipStreamWaitEvent(s, ev, 0));
   }
   {
     EpiBias e = epi_bias(H, bsC, ld, A + l.skip_proj.b_off, C, ACT_RELU);

@@ -40,6 +40,12 @@ for what in "$@"; do
     r3pmc-ddpm1000) do_pmc ddpm1000 ddpm1000 --config ddpm1000 --interval 10 ;;
     r3bench) for c in headline vocoder sharded ddpm1000; do python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc $?"; line $O/bench_$c.json; done
              for c in headline sharded ddpm1000; do python bench.py --config $c --storage fp16x3 > $O/bench_${c}_fp16x3.json 2> $O/bench_${c}_fp16x3.err; echo "$c fp16x3 rc $?"; line $O/bench_${c}_fp16x3.json; done ;;
+    defer) [ -n "$DEFER_TESTS" ] && FDX_DEFER_SKIP=20 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "wavenet_forward or baseline_configs" 2>&1 | tail -n 3
+           [ -n "$DEFER_TESTS" ] && FDX_DEFER_SKIP=5 FDX_DEFER_SIDE=1 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "wavenet_forward or baseline_configs" 2>&1 | tail -n 3
+           DS=${DEFER_SET:-0:27:0:0 20:27:0:0 20:24:0:0 20:17:0:0 20:24:17:0 20:24:24:0 5:24:0:0 5:24:0:1 5:24:17:1 4:27:17:1 10:24:17:1}
+           for v in $DS; do
+             G=$(echo $v | cut -d: -f1); SH=$(echo $v | cut -d: -f2); RS=$(echo $v | cut -d: -f3); SIDE=$(echo $v | cut -d: -f4); echo "FDX_DEFER_SKIP=$G SHAPE=$SH RES_SHAPE=$RS SIDE=$SIDE"
+             FDX_DEFER_SKIP=$G FDX_DEFER_SHAPE=$SH FDX_DEFER_RES_SHAPE=$RS FDX_DEFER_SIDE=$SIDE python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/defer_${G}_${SH}_${RS}_${SIDE}.json 2> $O/defer.err; line $O/defer_${G}_${SH}_${RS}_${SIDE}.json; done ;;
     tests-r3) python -m pytest tests/test_gpu_round3.py -m gpu -x -q -s > $O/gpu_tests_r3.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests_r3.log; grep -v "^$" $O/gpu_tests_r3.log | tail -n 40 ;;
     tests) ( time python -m pytest tests -m gpu -x -q ) > $O/gpu_tests.log 2>&1; echo "pytest rc $?" >> $O/gpu_tests.log; tail -n 15 $O/gpu_tests.log ;;
     sweep-outp) for v in ${SWEEP_OUTP:-27 24 25 26 28 44 45}; do echo "FDX_OUTP_SHAPE=$v"; FDX_OUTP_SHAPE=$v python bench.py --no-cpu-baseline --no-pcie --steps 5 --warmup 2 > $O/sweep_outp_$v.json 2> $O/sweep_outp_$v.err; line $O/sweep_outp_$v.json; done ;;
