@@ -242,7 +242,6 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
   __shared__ uint4 ring[LTAPS > 0 ? NW * kLD * kStage16 : 1];           // projection: 2 / 3 stages 29.7 / 18.2;  3 / 4: 26.6 / 14.7;  4 / 6: 26.8 / 15.2
   if constexpr (LTAPS > 0) {
     static_assert(NR == 2, "LDS-staged path: one 1-KiB piece of A per K iteration");
-    typedef float avec __attribute__((ext_vector_type(NR)));
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     prefetch_epilogue();                                                // oldest vector-memory ops of the wave: the first counted wait covers them
     const int n_cb = (it_end - it_begin) / LTAPS;                       // host guarantees: whole channel blocks per wave, an even number
