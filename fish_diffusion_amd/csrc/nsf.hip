@@ -272,10 +272,10 @@ static int nsf_source_core(fdx_ctx* h, const float* f0, int B, int T, const floa
   double* part = reinterpret_cast<double*>(h->scan_part.p);
   const dim3 g3(n_chunks, H, B);
   hipLaunchKernelGGL(k_scan_partial<1>, g3, dim3(kScanThreads), 0, s, part, h->vf0up.f(), (const float*)nullptr, rini, L, H, n_chunks, sr);
-  hipLaunchKernelGGL(k_scan_offsets, dim3((B * H + 63) / 64), dim3(64), 0, s, part, B * H, n_chunks);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(B * H), dim3(64), 0, s, part, B * H, n_chunks);
   hipLaunchKernelGGL(k_scan_tmp, g3, dim3(kScanThreads), 0, s, h->vscan.f(), part, h->vf0up.f(), rini, L, H, n_chunks, sr);
   hipLaunchKernelGGL(k_scan_partial<2>, g3, dim3(kScanThreads), 0, s, part, h->vf0up.f(), h->vscan.f(), rini, L, H, n_chunks, sr);
-  hipLaunchKernelGGL(k_scan_offsets, dim3((B * H + 63) / 64), dim3(64), 0, s, part, B * H, n_chunks);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(B * H), dim3(64), 0, s, part, B * H, n_chunks);
   hipLaunchKernelGGL(k_source_final, dim3(n_chunks, B), dim3(kScanThreads), 0, s, har, har_bs, part, h->vf0up.f(), h->vscan.f(), rini,
                      src_noise, h->nsf_arena + h->nl.src_w, h->nsf_arena + h->nl.src_b, L, H, n_chunks, sr, 0.1f, 0.003f);
   FDX_HIP(h, hipGetLastError());

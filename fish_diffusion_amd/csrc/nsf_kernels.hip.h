@@ -88,16 +88,32 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_partial(double* __
   if (threadIdx.x == 0) partial[((long)b * H + h) * n_chunks + chunk] = total;
 }
 
-// in-place exclusive scan of each row of `partial` ([rows][n_chunks]); one thread per row (n_chunks ~ 100)
-static __global__ void k_scan_offsets(double* __restrict__ partial, int rows, int n_chunks) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// in-place exclusive scan of each row of `partial` ([rows][n_chunks]); one wave per row (n_chunks ~ 100).  The adds stay one serial
+// chain in chunk order (bit-identical to a single thread walking the row); what the wave buys is the loads and stores: 256 chunks
+// at a time go through LDS with every lane moving four, instead of one thread waiting for ~100 dependent-looking global loads (16 us).
+static __global__ __launch_bounds__(64) void k_scan_offsets(double* __restrict__ partial, int rows, int n_chunks) {
+  __shared__ double buf[256];
+  const int r = blockIdx.x, lane = threadIdx.x;
   if (r >= rows) return;
-  double acc = 0;
   double* p = partial + (long)r * n_chunks;
-  for (int c = 0; c < n_chunks; ++c) {
-    const double v = p[c];
-    p[c] = acc;
-    acc += v;
+  double acc = 0;                                  // (lane 0's; carried across slabs)
+  for (int c0 = 0; c0 < n_chunks; c0 += 256) {
+    const int n = min(256, n_chunks - c0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < n) buf[lane + 64 * j] = p[c0 + lane + 64 * j];
+    __syncthreads();
+    if (lane == 0)
+      for (int c = 0; c < n; ++c) {
+        const double v = buf[c];
+        buf[c] = acc;
+        acc += v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < n) p[c0 + lane + 64 * j] = buf[lane + 64 * j];
+    __syncthreads();
   }
 }
 

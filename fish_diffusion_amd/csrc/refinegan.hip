@@ -314,7 +314,7 @@ extern "C" int fdx_refinegan_forward(fdx_handle h, const float* mel, const float
   float* tmpl = b.tmpl.f() + kHalo;
   if (!d.template_sine) {
     hipLaunchKernelGGL(k_comb_partial, dim3(n_chunks, B), dim3(kScanThreads), 0, s, part, b.f0up.f(), L, n_chunks, sr);
-    hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(B), dim3(64), 0, s, part, B, n_chunks);
     hipLaunchKernelGGL(k_comb_final, dim3(n_chunks, B), dim3(kScanThreads), 0, s, tmpl, (long)ldL, part, b.f0up.f(),
                        next_noise((size_t)B * L), L, n_chunks, sr, 0.1f, 0.003f);
   } else {
@@ -326,10 +326,10 @@ extern "C" int fdx_refinegan_forward(fdx_handle h, const float* mel, const float
     const float* rini = b.zero.f();
     const dim3 g3(n_chunks, 1, B);
     hipLaunchKernelGGL(k_scan_partial<1>, g3, dim3(kScanThreads), 0, s, part, b.f0up.f(), (const float*)nullptr, rini, L, 1, n_chunks, sr);
-    hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(B), dim3(64), 0, s, part, B, n_chunks);
     hipLaunchKernelGGL(k_scan_tmp, g3, dim3(kScanThreads), 0, s, b.scan.f(), part, b.f0up.f(), rini, L, 1, n_chunks, sr);
     hipLaunchKernelGGL(k_scan_partial<2>, g3, dim3(kScanThreads), 0, s, part, b.f0up.f(), b.scan.f(), rini, L, 1, n_chunks, sr);
-    hipLaunchKernelGGL(k_scan_offsets, dim3((B + 63) / 64), dim3(64), 0, s, part, B, n_chunks);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(B), dim3(64), 0, s, part, B, n_chunks);
     hipLaunchKernelGGL(k_source_final, dim3(n_chunks, B), dim3(kScanThreads), 0, s, tmpl, (long)ldL, part, b.f0up.f(), b.scan.f(), rini,
                        next_noise((size_t)B * L), A + l.sine_w, A + l.sine_b, L, 1, n_chunks, sr, 0.1f, 0.003f, (float)(d.sampling_rate / 2));
   }
