@@ -216,14 +216,20 @@ static __global__ void k_noise_conv_add(float* __restrict__ y, long y_bs, int ld
 }
 
 // Register-window variant: thread n keeps its K-sample window of the source in VGPRs (loaded once, 16-byte loads) and
-// walks a group of CG channels; the weights are wave-uniform (scalar loads, SGPR operands of the FMAs) and the y
-// read-modify-write is coalesced across the wave.  Same summation order as k_noise_conv_add (k ascending).
-// Stage 0 of config_v1 (C=256, K=128, stride 64): 804 us -> tens of us.
+// walks a group of CG channels; the y read-modify-write is coalesced across the wave.  Same summation order as k_noise_conv_add
+// (k ascending).  Stage 0 of config_v1 (C=256, K=128, stride 64): 804 us -> tens of us.
+// The weights of up to kSlab / K channels at a time are staged in LDS by the whole workgroup and read back as broadcast
+// ds_read_b128 (round 3): as wave-uniform scalar loads straight from memory every 16-weight piece was its own dependent
+// s_load -> wait -> 16 multiply-adds round with one wave per SIMD and nothing to hide it behind -- 90 us for stage 0 at batch 1
+// whatever the channel grouping.
 template <int K>
 static __global__ __launch_bounds__(256) void k_noise_conv_add_win(float* __restrict__ y, long y_bs, int ldy,
                                                                    const float* __restrict__ har, long har_bs,
                                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                                    int C, int CG, int Lout, int stride, int pad) {
+  constexpr int kSlab = 1024;                      // floats of weights per LDS slab
+  constexpr int CH = kSlab / K;                    // channels per slab (8 at K = 128)
+  __shared__ __attribute__((aligned(16))) float ws[kSlab];
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * CG;
@@ -231,15 +237,23 @@ static __global__ __launch_bounds__(256) void k_noise_conv_add_win(float* __rest
   const float* hp = har + b * har_bs + (long)min(n, Lout - 1) * stride - pad;   // clamp: overhang lanes read valid memory
 #pragma unroll
   for (int k = 0; k < K; ++k) h[k] = hp[k];
-  if (n >= Lout) return;
+  const bool live = n < Lout;                      // (no early return: every thread carries weights into LDS and meets the barriers)
   const int c1 = min(C, c0 + CG);
-  for (int c = c0; c < c1; ++c) {
-    const float* wp = w + (long)c * K;
-    float acc = 0.f;
+  for (int cb = c0; cb < c1; cb += CH) {
+    const int nc = min(CH, c1 - cb);
+    __syncthreads();                               // the previous slab has been consumed
+    for (int i = threadIdx.x; i < nc * K; i += 256) ws[i] = w[(long)cb * K + i];
+    __syncthreads();
+    for (int j = 0; j < nc; ++j) {
+      const float* wp = ws + j * K;
+      float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc += wp[k] * h[k];
-    const long o = b * y_bs + (long)c * ldy + n;
-    y[o] = y[o] + (acc + bias[c]);
+      for (int k = 0; k < K; ++k) acc += wp[k] * h[k];
+      if (live) {
+        const long o = b * y_bs + (long)(cb + j) * ldy + n;
+        y[o] = y[o] + (acc + bias[cb + j]);
+      }
+    }
   }
 }
 
