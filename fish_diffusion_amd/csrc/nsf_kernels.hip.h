@@ -92,7 +92,7 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_partial(double* __
 // chain in chunk order (bit-identical to a single thread walking the row); what the wave buys is the loads and stores: 256 chunks
 // at a time go through LDS with every lane moving four, instead of one thread waiting for ~100 dependent-looking global loads (16 us).
 static __global__ __launch_bounds__(64) void k_scan_offsets(double* __restrict__ partial, int rows, int n_chunks) {
-  __shared__ double buf[256];
+  __shared__ double buf[256], pre[256];            // inputs / exclusive prefixes (two arrays: the serial walk's reads do not wait on its writes)
   const int r = blockIdx.x, lane = threadIdx.x;
   if (r >= rows) return;
   double* p = partial + (long)r * n_chunks;
@@ -103,16 +103,17 @@ static __global__ __launch_bounds__(64) void k_scan_offsets(double* __restrict__
     for (int j = 0; j < 4; ++j)
       if (lane + 64 * j < n) buf[lane + 64 * j] = p[c0 + lane + 64 * j];
     __syncthreads();
-    if (lane == 0)
+    if (lane == 0) {
+#pragma unroll 8
       for (int c = 0; c < n; ++c) {
-        const double v = buf[c];
-        buf[c] = acc;
-        acc += v;
+        pre[c] = acc;
+        acc += buf[c];
       }
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (lane + 64 * j < n) p[c0 + lane + 64 * j] = buf[lane + 64 * j];
+      if (lane + 64 * j < n) p[c0 + lane + 64 * j] = pre[lane + 64 * j];
     __syncthreads();
   }
 }
