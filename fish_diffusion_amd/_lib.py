@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("FDX_LIB_PATH") or os.path.join(_HERE, "csrc", "libfis
 FDX_ROW = 16
 SAMPLER_NAIVE, SAMPLER_UNIPC, SAMPLER_PLMS = 0, 1, 2
 MEL_LINEAR, MEL_LN, MEL_LOG10 = 0, 1, 2
-PROF_WN_CONVGATE, PROF_WN_OUTPROJ, PROF_NSF_RESBLOCK = 0, 1, 2
+PROF_WN_CONVGATE, PROF_WN_OUTPROJ, PROF_NSF_RESBLOCK, PROF_RG_RESBLOCK, PROF_CN_PWCONV1, PROF_TD_ATTN = 0, 1, 2, 3, 4, 5
 MAX_STAGES, MAX_RESK, MAX_DIL = 8, 4, 4
 
 

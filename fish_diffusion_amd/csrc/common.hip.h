@@ -79,9 +79,13 @@ struct NsfLayout {
 };
 
 // Which launches fdx_prof_* times (fdx_prof_select): one kernel family at a time
-enum { PROF_WN_CONVGATE = 0,    // WaveNet: dilated conv k=3 + gate (convgemm16_kernel<EpiGate16> / convgemm_kernel<..., EpiGate>)
-       PROF_WN_OUTPROJ = 1,     // WaveNet: out-projection + residual / skip (convgemm_kernel<2,true,0,EpiResSkip>)
-       PROF_NSF_RESBLOCK = 2 }; // NSF-HiFiGAN: the ResBlock convs on convgemm_kernel<2,false,PRE_LRELU,EpiResblock> (C >= 64 stages)
+enum { PROF_WN_CONVGATE = 0,    // WaveNet: dilated conv k=3 + gate (convgemm16s_kernel<EpiGate16S> / ...)
+       PROF_WN_OUTPROJ = 1,     // WaveNet: out-projection + residual / skip
+       PROF_NSF_RESBLOCK = 2,   // NSF-HiFiGAN: the ResBlock convs on convgemm_kernel<2,false,PRE_LRELU,EpiResblock> (C >= 64 stages)
+       PROF_RG_RESBLOCK = 3,    // RefineGAN: the same instantiation inside its ResBlocks (down path + ParallelResBlocks)
+       PROF_CN_PWCONV1 = 4,     // ConvNext: pwconv1 (LayerNorm folded in, GELU epilogue)
+       PROF_TD_ATTN = 5,        // TransformerDecoder: k_attn (fp32 flash attention, self + cross)
+       PROF_KINDS = 6 };
 struct ProfEvents {
   bool on = false;
   int kind = PROF_WN_CONVGATE;
@@ -90,12 +94,14 @@ struct ProfEvents {
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
   double flops_total = 0;  // algorithmic FLOPs of the recorded launches
-  char label[224] = {0};   // which kernel instantiation / tile shape the recorded launches ran (fdx_prof_label)
+  char label[256] = {0};   // which kernel instantiation / tile shape the RECORDED launches ran (fdx_prof_label)
+  char pending[224] = {0}; // what the next launch of the selected family is (note()); becomes `label` when take() samples it
+  bool mixed = false;
   void note(int k, const char* fmt, ...) __attribute__((format(printf, 3, 4))) {
     if (!on || k != kind) return;
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(label, sizeof label, fmt, ap);
+    vsnprintf(pending, sizeof pending, fmt, ap);
     va_end(ap);
   }
   // events for this launch, or false (not selected / not sampled).  Event-creation errors simply skip the launch.
@@ -109,6 +115,14 @@ struct ProfEvents {
     }
     ev0 = start[used]; ev1 = stop[used]; ++used;
     flops_total += flops;
+    // the label names what was SAMPLED: the first sampled launch's instantiation, flagged once if a later sampled launch ran another
+    // one (micro-batches of different size may pick different tile shapes / kernel families)
+    if (!label[0]) snprintf(label, sizeof label, "%s", pending);
+    else if (!mixed && pending[0] && strncmp(label, pending, strlen(pending)) != 0) {
+      mixed = true;
+      const size_t n = strlen(label);
+      snprintf(label + n, sizeof label - n, " [+ other instantiations among the sampled launches]");
+    }
     return true;
   }
 };

@@ -466,8 +466,12 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
     {  // pwconv1 over LayerNorm(u): centring + rstd inside the GEMM, affine folded into the packed weights
       const PackedW& p = l.pw1[i];
       ConvGeom gg{B, T, p.cin8, 1, 0, 0, p.n_mtiles};
+      hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: the denoiser's dominant kernel
+      h->prof.note(PROF_CN_PWCONV1, "convgemm_kernel<2, true, PRE_LN, EpiBias> (v_mfma_f32_32x32x2_f32; 64 x 64 split-K workgroup tile, LayerNorm folded in, GELU epilogue; %ld workgroups)",
+                   (long)B * ((T + 63) / 64) * p.n_mtiles);
+      h->prof.take(PROF_CN_PWCONV1, 2.0 * (double)H * D * (double)B * T, ev0, ev1);
       FDX_HIP(h, (launch_convgemm<2, true, PRE_LN, EpiBias>(gg, reinterpret_cast<const float4*>(A + p.w_off), N, bsD, ld, 1.f,
-                                                            bias_epi(G, bsH, ld, A + p.b_off, H, ACT_GELU), s, nullptr, nullptr,
+                                                            bias_epi(G, bsH, ld, A + p.b_off, H, ACT_GELU), s, ev0, ev1,
                                                             b.ST.f(), A + l.lnR[i], D / kCnCh, 1e-6f)));
     }
     EpiScaleRes e{};

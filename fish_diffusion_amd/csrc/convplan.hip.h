@@ -47,10 +47,12 @@ inline hipError_t run_conv(const float* arena, const PackedW& p, int B, int T, c
   const long wg_nosplit = (long)B * ((T + 255) / 256) * p.n_mtiles;
   if (p.RB == 1) return launch_convgemm<1, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);
   if (wg_nosplit >= no_split_min_wgs() || p.cin8 * p.taps < 4) {
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: this instantiation is the vocoder's dominant kernel
-    if (prof && prof->take(prof_kind, 2.0 * p.rows * (8.0 * p.cin8) * p.taps * (double)B * T, ev0, ev1))
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: this instantiation is the vocoders' dominant kernel (only their ResBlock convs pass `prof`)
+    if (prof) {
       prof->note(prof_kind, "convgemm_kernel<2, false, %d, EpiResblock> (v_mfma_f32_32x32x2_f32; one 64 x 64 tile per wave, no split-K, 64 x 256 per workgroup)",
-                 (int)LRELU);   // only the vocoders' ResBlock convs pass `prof`
+                 (int)LRELU);
+      prof->take(prof_kind, 2.0 * p.rows * (8.0 * p.cin8) * p.taps * (double)B * T, ev0, ev1);
+    }
     return launch_convgemm<2, false, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s, ev0, ev1);
   }
   return launch_convgemm<2, true, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s);

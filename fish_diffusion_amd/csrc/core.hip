@@ -72,13 +72,15 @@ extern "C" int fdx_prof_enable(fdx_handle h, int on) {
   h->prof.used = 0;
   h->prof.flops_total = 0;
   h->prof.label[0] = 0;
+  h->prof.pending[0] = 0;
+  h->prof.mixed = false;
   return FDX_OK;
 }
 
 extern "C" int fdx_prof_select(fdx_handle h, int kind) {
   GenScope gen_scope(h);
   if (!h) return FDX_E_ARG;
-  if (kind < PROF_WN_CONVGATE || kind > PROF_NSF_RESBLOCK) return fail(h, FDX_E_ARG, "fdx_prof_select: unknown kernel family %d", kind);
+  if (kind < PROF_WN_CONVGATE || kind >= PROF_KINDS) return fail(h, FDX_E_ARG, "fdx_prof_select: unknown kernel family %d", kind);
   h->prof.kind = kind;
   return FDX_OK;
 }

@@ -307,17 +307,28 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 }
 
 template <int NQ>
-hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s) {
+hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const dim3 grid((a.Tq + 32 * NQ - 1) / (32 * NQ), kHeads, B), blk(256);
-  if (DH == 64) hipLaunchKernelGGL((k_attn<64, NQ>), grid, blk, 0, s, a);
-  else if (DH == 32) hipLaunchKernelGGL((k_attn<32, NQ>), grid, blk, 0, s, a);
-  else hipLaunchKernelGGL((k_attn<16, NQ>), grid, blk, 0, s, a);
+#define FDX_ATTN(DH_)                                                                                   \
+  if (ev0) hipExtLaunchKernelGGL((k_attn<DH_, NQ>), grid, blk, 0, s, ev0, ev1, 0, a);                    \
+  else hipLaunchKernelGGL((k_attn<DH_, NQ>), grid, blk, 0, s, a);
+  if (DH == 64) { FDX_ATTN(64) }
+  else if (DH == 32) { FDX_ATTN(32) }
+  else { FDX_ATTN(16) }
+#undef FDX_ATTN
   return hipGetLastError();
 }
-hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s) {
+hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s, ProfEvents* prof = nullptr) {
   // 64-query workgroups only when they already give every CU one (B * heads * T/64 >= 256); else 32-query ones
-  if ((long)B * kHeads * ((a.Tq + 63) / 64) >= 256) return launch_attn_nq<2>(DH, a, B, s);
-  return launch_attn_nq<1>(DH, a, B, s);
+  const bool nq2 = (long)B * kHeads * ((a.Tq + 63) / 64) >= 256;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: QK^T and PV of one attention launch = 2 * 2 * Tq * Tk * D flops per item
+  if (prof) {
+    prof->note(PROF_TD_ATTN, "k_attn<%d, %d> (v_mfma_f32_32x32x2_f32 fp32 flash attention, %d-query workgroups; %ld workgroups)", DH, nq2 ? 2 : 1,
+               nq2 ? 64 : 32, (long)B * kHeads * ((a.Tq + (nq2 ? 63 : 31)) / (nq2 ? 64 : 32)));
+    prof->take(PROF_TD_ATTN, 4.0 * (double)a.Tq * a.Tk * (double)(DH * kHeads) * B, ev0, ev1);
+  }
+  if (nq2) return launch_attn_nq<2>(DH, a, B, s, ev0, ev1);
+  return launch_attn_nq<1>(DH, a, B, s, ev0, ev1);
 }
 
 // Scratch of one decoder layer (owned by the caller; padded rows [B][ch][ld], pointers past the left halo)
@@ -327,7 +338,7 @@ struct DecScratch { float* QKV; float* O; float* G; };   // [3D], [D], [H]
 // on X.  The cross-attention keys / values come from `KV` [B][2D][ld] (already projected with y.ca_kv: the caller decides whether
 // that projection is per call or hoisted; kv_bs = floats between batch items of KV).  tgt_kpm / mem_kpm: [B][T] key-padding masks (1 = ignored) or null.
 inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV, long kv_bs,
-                               const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s) {
+                               const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s, ProfEvents* prof = nullptr) {
   const long bsD = (long)D * ld, bsH = (long)H * ld;
   const int DH = D / kHeads;
   auto residual = [&](const PackedW& p, const float* in, long in_bs) {   // X += W in + b
@@ -344,14 +355,14 @@ inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, i
   at.K = sc.QKV + (size_t)D * ld; at.k_bs = 3 * bsD; at.ldk = ld;
   at.V = sc.QKV + (size_t)2 * D * ld; at.v_bs = 3 * bsD; at.ldv = ld;
   at.kmask = tgt_kpm;
-  if ((e = launch_attn(DH, at, B, s)) != hipSuccess) return e;
+  if ((e = launch_attn(DH, at, B, s, prof)) != hipSuccess) return e;
   if ((e = residual(y.sa_out, sc.O, bsD)) != hipSuccess) return e;
   launch_layernorm(X, bsD, ld, A + y.n1w, A + y.n1b, B, D, T, s);
   // ---- cross-attention block
   if ((e = gemm(A, y.ca_q, B, T, X, bsD, ld, bias_epi(sc.QKV, 3 * bsD, ld, A + y.ca_q.b_off, D, ACT_NONE), s)) != hipSuccess) return e;
   at.K = KV; at.k_bs = kv_bs; at.V = KV + (size_t)D * ld; at.v_bs = kv_bs;
   at.kmask = mem_kpm;
-  if ((e = launch_attn(DH, at, B, s)) != hipSuccess) return e;
+  if ((e = launch_attn(DH, at, B, s, prof)) != hipSuccess) return e;
   if ((e = residual(y.ca_out, sc.O, bsD)) != hipSuccess) return e;
   launch_layernorm(X, bsD, ld, A + y.n2w, A + y.n2b, B, D, T, s);
   // ---- feed-forward block

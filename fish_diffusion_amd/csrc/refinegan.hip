@@ -241,12 +241,12 @@ int resblock(fdx_ctx* h, const float* A, const RgRes& r, int k, int cout, bool s
     const int dil = kDil[j], sh = -(k - 1) / 2 * dil;
     EpiResblock e1{};
     e1.out = tm.p; e1.resid = nullptr; e1.bs = tm.bs; e1.ld = tm.ld; e1.bias = A + r.c1[j].b_off; e1.M = cout; e1.mode = 0;
-    FDX_HIP(h, (run_conv<true>(A, r.c1[j], B, L, cur.p, cur.bs, cur.ld, sh, dil, slope, e1, s)));
+    FDX_HIP(h, (run_conv<true>(A, r.c1[j], B, L, cur.p, cur.bs, cur.ld, sh, dil, slope, e1, s, &h->prof, PROF_RG_RESBLOCK)));
     EpiResblock e2{};
     e2.out = out.p; e2.bs = out.bs; e2.ld = out.ld; e2.bias = A + r.c2[j].b_off; e2.M = cout; e2.mode = 0;
     e2.resid = (j != 0 || same) ? cur.p : nullptr;
     if (e2.resid && (cur.bs != out.bs || cur.ld != out.ld)) return fail(h, FDX_E_STATE, "refinegan: residual layout mismatch");
-    FDX_HIP(h, (run_conv<true>(A, r.c2[j], B, L, tm.p, tm.bs, tm.ld, sh, dil, slope, e2, s)));
+    FDX_HIP(h, (run_conv<true>(A, r.c2[j], B, L, tm.p, tm.bs, tm.ld, sh, dil, slope, e2, s, &h->prof, PROF_RG_RESBLOCK)));
     cur = out;
   }
   return FDX_OK;

@@ -238,7 +238,7 @@ int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
   for (const auto& y : l.layers) {
     // every layer projects its own keys / values from the per-call memory (it contains the diffusion step: not hoistable)
     FDX_HIP(h, gemm(A, y.ca_kv, B, T, mem, bsD, ld, bias_epi(KV, 2 * bsD, ld, A + y.ca_kv.b_off, 2 * D, ACT_NONE), s));
-    FDX_HIP(h, run_declayer(A, y, B, T, D, H, ld, X, KV, 2 * bsD, sc, mask, cmask, s));
+    FDX_HIP(h, run_declayer(A, y, B, T, D, H, ld, X, KV, 2 * bsD, sc, mask, cmask, s, &h->prof));
   }
   FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
   {

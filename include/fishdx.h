@@ -396,8 +396,9 @@ int fdx_debug_conv1d(fdx_handle h, const float* x, int B, int Cin, int T, const 
  * -1: pause -- stop recording but keep the recorded launches for fdx_prof_read. */
 int fdx_prof_enable(fdx_handle h, int on);
 /* Which kernel family fdx_prof_enable times: 0 = WaveNet dilated conv + gate (default), 1 = WaveNet out-projection + residual/skip,
- * 2 = NSF-HiFiGAN ResBlock convs (the no-split 64-row instantiation, i.e. the stages with >= 64 channels).  fdx_prof_read's
- * flops_per_launch is the mean algorithmic FLOP count of the recorded launches (they differ per stage for family 2). */
+ * 2 = NSF-HiFiGAN ResBlock convs (the no-split 64-row instantiation, i.e. the stages with >= 64 channels), 3 = the same instantiation
+ * inside RefineGAN's ResBlocks, 4 = ConvNext pwconv1 (LayerNorm folded in, GELU), 5 = TransformerDecoder attention (self + cross).
+ * fdx_prof_read's flops_per_launch is the mean algorithmic FLOP count of the recorded launches (they differ per stage for 2 / 3). */
 int fdx_prof_select(fdx_handle h, int kind);
 int fdx_prof_read(fdx_handle h, int* n_launches, double* total_ms, double* flops_per_launch);
 /* The kernel instantiation (name as rocprofv3 prints it, MFMA instruction, workgroup tile) the launches recorded since the last

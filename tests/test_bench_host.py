@@ -38,6 +38,30 @@ def test_config_aliases_cover_every_baseline_config():
     assert {b.ALIASES[str(i)] for i in range(1, len(base["configs"]))} == {"headline", "vocoder", "sharded", "ddpm1000"}
     assert b.ALIASES["c2"] == "vocoder" and b.ALIASES["c3"] == "sharded" and b.ALIASES["c5"] == "ddpm1000"
     assert set(b.DEFAULT_STEPS) == set(b.ALIASES.values())
+    # the default line carries every other BASELINE config and every SURVEY 8(f) row as a short run of its own
+    assert set(b.EXTRA_CONFIGS) == {"vocoder", "sharded", "ddpm1000"} and set(b.EXTRA_WIDENING) == {"hifisinger_v2", "convnext", "tfdec"}
+    assert set(b.EXTRA_CONFIGS) | set(b.EXTRA_WIDENING) | {"headline"} == set(b.ALIASES.values())
+
+
+def test_widening_flop_formulas():
+    """The SURVEY 8(f) rows' algorithmic work; tools/flops_reference.py checks the same formulas against torch.utils.flop_counter on the
+    real reference modules (profiles/r04_flops_reference_check.json: ratio 1.0)."""
+    b = _bench()
+    assert abs(b.refinegan_flops(1722, b.RG_HIFISINGER) / 1e9 - 1246.98) < 0.01          # one 10 s item at hop 256, num_mels = 256
+    assert b.refinegan_flops(1722, dict(b.RG_HIFISINGER, num_mels=128)) < b.refinegan_flops(1722, b.RG_HIFISINGER)
+    cn, cn_h = b.convnext_flops_per_frame()
+    assert abs(cn / 1e6 - 98.447) < 0.01 and abs(cn_h / 1e6 - 13.631) < 0.01
+    td, td_h = b.tfdec_flops_per_frame(861)
+    D, H, L = 512, 2048, 12
+    assert td - td_h == 2.0 * (128 * H + H * D + L * (8 * D * D + 2 * D * H) + D * D + D * 128) + L * 2 * 4.0 * 861 * D
+    assert b.hifisinger_frontend_flops(1722) == 2.0 * 1722 * (768 * 256 + 2 * 256 * 256)
+    ref = os.path.join(ROOT, "profiles", "r04_flops_reference_check.json")
+    if os.path.exists(ref):
+        with open(ref) as f:
+            rows = json.load(f)["rows"]
+        for k, v in rows.items():
+            if isinstance(v, dict):
+                assert abs(v.get("ratio", v.get("ratio_without_attention_products")) - 1.0) < 1e-9, k
 
 
 def test_usable_cores_and_traffic_file():
