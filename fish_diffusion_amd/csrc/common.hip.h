@@ -143,19 +143,10 @@ struct fdx_ctx {
   fdx::DevBuf xin, X, Y, Z, SK, H, EPS, P, condp, condraw, P2;
   fdx::DevBuf wn_nr2;                    // dilated-conv weights in the NR = 2 fragment order (convgemm16s.hip.h), derived at attach
   std::vector<size_t> wn_nr2_off;        // per layer, in floats
-  bool wn_nr2_ok = false;
   int conv_shape_nr = 4, conv_shape_nm = 4;   // tile shape of the dilated conv + gate for the prepared geometry
   fdx::DevBuf wn_outp16;                 // out-projection weights in the 16x16x4 orders (NR = 4 and NR = 2), derived at attach
   std::vector<size_t> wn_outp16_off4, wn_outp16_off2, wn_outp16_off1;
-  int outp_shape_nr = 0, outp_shape_nm = 0;   // 0: the 32x32x2 kernel
-  // Deferred skip sum (experiment, FDX_DEFER_SKIP=<layers per group>, wavenet.hip): the per-layer out-projection forms only its residual
-  // rows, every layer's gated output stays in Zs ([B][L*C][ld]) and the skip rows of a group of layers run as ONE GEMM with K = group*C.
-  int defer_group = 0, defer_nr = 2, defer_nm = 7, defer_res_nr = 0, defer_res_nm = 0;
-  bool defer_side = false;               // group GEMMs on a side stream, joined in front of skip_projection
-  fdx::DevBuf wn_skipcat, wn_skipbias, Zs;
-  std::vector<size_t> wn_skipcat_off;    // per group, in floats
-  hipStream_t side_stream = nullptr;
-  std::vector<hipEvent_t> side_ev;
+  int outp_shape_nr = 4, outp_shape_nm = 4;   // tile shape of the out-projection for the prepared geometry
   const void* wn_arena_bf16 = nullptr;   // opt-in bf16 storage mode: residual-block weights as bf16 fragments (wavenet.hip)
   fdx::DevBuf Yb, Zb;                    // ... and the two GEMM operands in C8-blocked bf16
   fdx::DevBuf wn_bf16_lds;               // the same bf16 weights in the LDS-tiled kernels' order (bf16lds.hip.h), derived at bf16 attach

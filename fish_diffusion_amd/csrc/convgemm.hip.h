@@ -64,7 +64,7 @@ struct ConvArgs {
 // in SGPRs at wave launch; by-value structs are never preloaded, they are fetched with s_load from the kernarg segment -- a
 // cold read from beyond the L2 on every launch of a replayed graph, i.e. a fabric round trip before the first address can be
 // formed.  The rest (ConvArgsCold, the epilogue) is only needed behind the pipeline prologue.  For the same reason the kernels
-// never read gridDim (a hidden kernel argument, i.e. another kernarg-segment load): the grid size is n_tiles_n * n_mtiles / MT
+// never read gridDim (a hidden kernel argument, i.e. another kernarg-segment load): the grid size is n_tiles_n * n_mtiles
 // and tiles_per_item is recomputed from T.
 struct ConvArgsCold {
   float in_slope;
@@ -535,20 +535,16 @@ constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result tra
 
 // (PRE_LN keeps its statistics in registers across the K loop: the second launch-bounds argument holds that instantiation to
 // the 256 VGPRs that let two workgroups share a CU, like every other instantiation already does unprompted.)
-// VAR: tuning variants (bit flags).  VAR_XCD_RECT: the tile -> XCD map deals 2-D rectangles (4 row groups x 2 column groups) instead of
-// runs of whole rows -- for GEMMs whose weight tile is small next to the activation tile (the out-projection: K = C, one tap) the
-// rectangle halves what every XCD's private L2 must fetch of the activation operand.  VAR_LATE_EPI: the epilogue's global reads
-// are issued after the first pass over the register ring instead of in front of the K loop (they ride behind the start-up burst).
-constexpr int VAR_XCD_RECT = 1, VAR_LATE_EPI = 2;
-template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32, int VAR = 0>
-__global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
+// (Measured and removed, round 4 -- see profiles/NOTES.md: 8 K-splitting waves per workgroup (2 % slower), 128-row MT = 2 tiles (+1 % at batch 2,
+// -10 % at batch 8), a 2-D tile -> XCD map and a late epilogue prefetch for this family.)
+template <int RB, bool SPLITK, int PRE, class Epi, int OPK = OPK_F32>
+__global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
   a.tiles_per_item = (a.T + (SPLITK ? 63 : 255)) / (SPLITK ? 64 : 256);
-  static_assert(NW == 4 || (SPLITK && NW == 8), "4 waves per workgroup, or 8 K-splitting waves (2 per SIMD)");
+  constexpr int NW = 4;                       // waves per workgroup
   static_assert(!Epi::kPaired || RB == 2, "paired epilogues need both row blocks");
-  static_assert(MT == 1 || (SPLITK && MT == 2), "MT = 2 (two packed m-tiles per workgroup) is a split-K variant");
   constexpr int NB = 2;                       // two 32-column MFMA blocks per wave tile (interleaved columns)
-  constexpr int RBX = MT * RB;                // 32-row accumulator blocks per wave: (m-tile mtl, row block rb) = (x / RB, x % RB)
+  constexpr int RBX = RB;                     // 32-row accumulator blocks per wave
   constexpr int V = RBX * NB;                 // accumulator values per (lane, accumulator row r)
   constexpr int ROWS = Epi::kPaired ? 32 : 32 * RB;   // logical rows per packed m-tile
   __shared__ float red[SPLITK ? NW * V * 16 * kWave : 1];
@@ -559,29 +555,18 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
   FDX_STAMP(0);
 
   // ---- XCD-aware logical tile id (block b runs on XCD b % 8; give each XCD a contiguous chunk)
-  const int G = a.n_tiles_n * (a.n_mtiles / MT), bid = blockIdx.x;   // == gridDim.x, from preloaded arguments
+  const int G = a.n_tiles_n * a.n_mtiles, bid = blockIdx.x;   // == gridDim.x, from preloaded arguments
   const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
   const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  int mtg = L / a.n_tiles_n;                  // group of MT consecutive packed m-tiles
-  int nt = L - mtg * a.n_tiles_n;
-  if constexpr ((VAR & VAR_XCD_RECT) != 0 && MT == 1) {
-    // 8 equal rectangles of (n_mtiles / 4) x (n_tiles_n / 2) tiles when both divide (G = 8 rectangles => q8 tiles each, r8 = 0:
-    // XCD x owns exactly rectangle x); any other shape keeps the row-run order above
-    if ((a.n_mtiles & 3) == 0 && (a.n_tiles_n & 1) == 0) {
-      const int H = a.n_mtiles >> 2, W = a.n_tiles_n >> 1, per = H * W;
-      const int rect = L / per, within = L - rect * per;
-      const int wr = within / W;
-      mtg = (rect >> 1) * H + wr;
-      nt = (rect & 1) * W + (within - wr * W);
-    }
-  }
+  const int mtg = L / a.n_tiles_n;            // packed m-tile
+  const int nt = L - mtg * a.n_tiles_n;
   const int item = nt / a.tiles_per_item;
   const int tile_in_item = nt - item * a.tiles_per_item;
   constexpr int COLS = SPLITK ? 64 : 256;
   const int t0 = tile_in_item * COLS + (SPLITK ? 0 : wave * 64);
   const int tc = t0 + 2 * li;                 // this lane's column pair (tc, tc+1)
   const bool col_ok = tc < a.T, col_two = tc + 1 < a.T;
-  const int row_base = mtg * MT * ROWS;
+  const int row_base = mtg * ROWS;
 
   int it_begin = 0, it_end = a.n_it;
   if (SPLITK) {
@@ -593,13 +578,12 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
   // ---- split-K: the epilogue sites of this wave are static -> their global reads are issued right after the pipeline's
   // first operand loads (so they do not delay the K loop's start) and land behind the K loop.
   // The tile's sites are dealt to the NW waves in order, site s = wave*NS + i:
-  //   paired / RB=1: m-tile s >> 4, accumulator row r = s & 15;   unpaired RB=2: m-tile s >> 5, row block (s >> 4) & 1, r = s & 15.
-  constexpr int NS = SPLITK ? ((Epi::kPaired || RB == 1) ? MT * 16 / NW : MT * 32 / NW) : 1;
+  //   paired / RB=1: accumulator row r = s & 15;   unpaired RB=2: row block (s >> 4) & 1, r = s & 15.
+  constexpr int NS = SPLITK ? ((Epi::kPaired || RB == 1) ? 16 / NW : 32 / NW) : 1;
   auto site_row = [&](int sidx) {             // first logical row of the 32-row block the site lives in, + its row inside
     const int blk = sidx >> 4, r = sidx & 15;
-    const int mtl = (Epi::kPaired || RB == 1) ? blk : (blk >> 1);
     const int rb = (Epi::kPaired || RB == 1) ? 0 : (blk & 1);
-    return row_base + mtl * ROWS + rb * 32 + acc_row(r, half);
+    return row_base + rb * 32 + acc_row(r, half);
   };
   typename Epi::Pre pre[NS];
   auto prefetch_epilogue = [&]() {
@@ -626,8 +610,8 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
   // no E[u^2] - mean^2 or acc - mean*rowsum cancellation.  The K loop is untouched; the statistics' loads are issued with the
   // epilogue prefetch and consumed after the reduction.
   static_assert(PRE != PRE_LN || (SPLITK && !Epi::kPaired), "PRE_LN: split-K, unpaired epilogues");
-  static_assert(PRE != PRE_LN || (MT * ROWS * 4 == NW * 64 && NW == 4), "PRE_LN: one float4 of the tile's row sums per thread");
-  __shared__ float ln_rows[PRE == PRE_LN ? MT * ROWS * 16 : 1];   // this tile's rows of ln_R (weights: they come from HBM / MALL)
+  static_assert(PRE != PRE_LN || ROWS * 4 == NW * 64, "PRE_LN: one float4 of the tile's row sums per thread");
+  __shared__ float ln_rows[PRE == PRE_LN ? ROWS * 16 : 1];   // this tile's rows of ln_R (weights: they come from HBM / MALL)
   __shared__ float ln_cols[PRE == PRE_LN ? 64 * 17 : 1];          // per column of the tile: delta_g[16], rstd
   // The statistics are combined ONCE per workgroup, 4 threads per column (thread = column tid >> 2, groups 4q .. 4q+3): two
   // coalesced float4 loads per thread.  (Every lane loading its own two frames' 2 x 128 B -- 16 loads touching 64 different
@@ -672,7 +656,7 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
     // ---- bf16 operands: one K iteration = 16 channels of one tap = ONE v_mfma_f32_32x32x16_bf16 per accumulator block.
     // A: packed [m_tile][it][rb][lane] 16 B = 8 bf16 (k = 8*half .. +7 of row li); B: the lane's column, channel block
     // 2*cb16 + half, one 16-byte group.  Same register ring and saturating cursors as the fp32 loop below.
-    static_assert(PRE == PRE_NONE && MT == 1, "bf16 operands: plain contraction only");
+    static_assert(PRE == PRE_NONE, "bf16 operands: plain contraction only");
     if (active && it_begin < it_end) {
       struct StageB { bf16x8 a[RBX]; bf16x8 b[NB]; };
       const int n = it_end - it_begin;
@@ -737,8 +721,7 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
     // this wave's K range (the over-run re-reads the last iteration: L1 hits, values unused).
     const int n = it_end - it_begin;
     const int cb0 = it_begin / a.taps, tap0 = it_begin - cb0 * a.taps;
-    const char* Abase = reinterpret_cast<const char*>(a.Wp + ((long)mtg * MT * a.n_it + it_begin) * (RB * 64));
-    const unsigned mt_stride = (unsigned)a.n_it * (RB * 1024u);           // bytes between consecutive packed m-tiles
+    const char* Abase = reinterpret_cast<const char*>(a.Wp + ((long)mtg * a.n_it + it_begin) * (RB * 64));
     const char* Xbase = reinterpret_cast<const char*>(a.X + item * a.x_bstride + a.shift0 + t0);
     const unsigned rs = (unsigned)a.ldx * 4u;                  // bytes between channels
     const unsigned d_tap = (unsigned)a.dshift * 4u;            // next tap, same channel block
@@ -756,7 +739,7 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
     auto load = [&](Stage& s) {
 #pragma unroll
       for (int x = 0; x < RBX; ++x)
-        s.a[x] = *reinterpret_cast<const float4*>(Abase + (a_off + a_lane + (x / RB) * mt_stride + (x % RB) * 1024u));
+        s.a[x] = *reinterpret_cast<const float4*>(Abase + (a_off + a_lane + x * 1024u));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f2u v = *reinterpret_cast<const f2u*>(Xbase + (x_off + x_lane[j]));
@@ -815,13 +798,6 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
     for (int d = 0; d < D - 1; ++d) load(st[d]);
     __builtin_amdgcn_sched_barrier(0);
     int done = 0;
-    if constexpr ((VAR & VAR_LATE_EPI) != 0) {
-      if (D <= n) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
-        done = D;
-      }
-    }
     prefetch_epilogue();
     ln_prefetch();
     __builtin_amdgcn_sched_barrier(0);
@@ -867,10 +843,10 @@ __global__ __launch_bounds__(NW * 64, PRE == PRE_LN ? 2 : 1) void convgemm_kerne
       f4 sum[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int sidx = wave * NS + i, mtl = sidx >> 4, r = sidx & 15;
-        sum[i] = *reinterpret_cast<const f4*>(red + ridx(0, r) + 4 * mtl);
+        const int r = (wave * NS + i) & 15;
+        sum[i] = *reinterpret_cast<const f4*>(red + ridx(0, r));
 #pragma unroll
-        for (int w = 1; w < NW; ++w) sum[i] += *reinterpret_cast<const f4*>(red + ridx(w, r) + 4 * mtl);
+        for (int w = 1; w < NW; ++w) sum[i] += *reinterpret_cast<const f4*>(red + ridx(w, r));
       }
       if constexpr (OPK == OPK_BF16) {
         static_assert(NS == 4, "a wave's four sites = one channel quad");
@@ -961,7 +937,7 @@ struct ConvGeom {   // everything the launcher needs besides pointers
   int n_mtiles;     // row tiles of 32*RB logical rows (32 pairs for paired epilogues)
 };
 
-template <int RB, bool SPLITK, int PRE, class Epi, int NW = 4, int MT = 1, int OPK = OPK_F32, int VAR = 0>
+template <int RB, bool SPLITK, int PRE, class Epi, int OPK = OPK_F32>
 inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx,
                                   float in_slope, const Epi& epi, hipStream_t s, hipEvent_t ev_start = nullptr,
                                   hipEvent_t ev_stop = nullptr, const float* col_stats = nullptr, const float* ln_R = nullptr,
@@ -974,11 +950,10 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   a.tiles_per_item = (g.T + cols - 1) / cols;
   a.n_tiles_n = g.B * a.tiles_per_item;
   a.n_mtiles = g.n_mtiles;
-  a.xcd_rect = 0;                      // (this family keeps the row-run map; VAR_XCD_RECT is its own experiment)
+  a.xcd_rect = 0;                      // (this family keeps the row-run map)
   a.in_slope = in_slope;
   a.col_stats = col_stats; a.ln_R = ln_R; a.n_groups = n_groups; a.ln_eps = ln_eps;
-  if (g.n_mtiles % MT) return hipErrorInvalidValue;
-  const int grid = a.n_tiles_n * (a.n_mtiles / MT);
+  const int grid = a.n_tiles_n * a.n_mtiles;
   if (grid <= 0) return hipSuccess;
 #ifdef FDX_KTRACE
   a.trace = nullptr;
@@ -986,10 +961,10 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)   // profiling: the events receive this dispatch's own begin / end timestamps (what rocprofv3 reports)
-    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK, VAR>), dim3(grid), dim3(NW * 64), 0, s, ev_start, ev_stop, 0,
+    hipExtLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, OPK>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0,
                           FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, NW, MT, OPK, VAR>), dim3(grid), dim3(NW * 64), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipLaunchKernelGGL((convgemm_kernel<RB, SPLITK, PRE, Epi, OPK>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 

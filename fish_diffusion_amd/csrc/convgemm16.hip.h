@@ -53,47 +53,8 @@ struct EpiGate16 {  // wavenet.py:112-115
   }
 };
 
-struct EpiResSkip16 {  // wavenet.py:117-120 + the skip sum of :228
-  static constexpr bool kPaired = false;
-  float* X; float* Y; float* SK; long bs; int ld;
-  const float* bias;
-  const float* sb; int sb_ld, sb_bs;
-  int C, skip_mode;
-  float inv_div, r_inv_div;
-  struct Pre { f4 old; float bias, sb; };
-  __device__ __forceinline__ bool is_res(int row) const { return __builtin_amdgcn_readfirstlane(row) < C; }
-  __device__ __forceinline__ Pre load(int b, int row, int t) const {
-    Pre p{f4{0.f, 0.f, 0.f, 0.f}, bias[row], 0.f};
-    if (is_res(row)) {
-      p.old = ld4(X + b * bs + (long)row * ld + t);
-      if (Y) p.sb = sb[(long)row * sb_ld + b * sb_bs];
-    } else if (skip_mode == 1 || skip_mode == 2) {
-      p.old = ld4(SK + b * bs + (long)(row - C) * ld + t);
-    }
-    return p;
-  }
-  __device__ __forceinline__ static f4 div4(f4 x, float c, float rc) {
-    return f4{div_const(x.x, c, rc), div_const(x.y, c, rc), div_const(x.z, c, rc), div_const(x.w, c, rc)};
-  }
-  __device__ __forceinline__ void store(int b, int row, int t, int nvalid, f4 v, const Pre& p) const {
-    v += p.bias;
-    if (is_res(row)) {
-      const long o = b * bs + (long)row * ld + t;
-      const f4 xn = div4(p.old + v, 1.41421356237309504880f, 0.70710678118654752440f);
-      st4p(X + o, xn, nvalid);
-      if (Y) st4p(Y + o, xn + p.sb, nvalid);
-    } else {
-      const long o = b * bs + (long)(row - C) * ld + t;
-      f4 s = v;
-      if (skip_mode == 1 || skip_mode == 2) s = p.old + v;
-      if (skip_mode >= 2) s = div4(s, inv_div, r_inv_div);
-      st4p(SK + o, s, nvalid);
-    }
-  }
-};
-
 // ------------------------------------------------------------------------------------------ kernel
-template <class Epi, int VAR = 0>
+template <class Epi>
 __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
   a.tiles_per_item = (a.T + 63) / 64;
@@ -196,13 +157,6 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
     for (int d = 0; d < D - 1; ++d) load(st[d]);
     __builtin_amdgcn_sched_barrier(0);
     int done = 0;
-    if constexpr ((VAR & VAR_LATE_EPI) != 0) {
-      if (D <= n) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) slot(st[(d + D - 1) % D], st[d]);
-        done = D;
-      }
-    }
     prefetch_epilogue();
     __builtin_amdgcn_sched_barrier(0);
     for (; done + D <= n; done += D) {
@@ -247,7 +201,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
   FDX_STAMP_RT1();
 }
 
-template <class Epi, int VAR = 0>
+template <class Epi>
 inline hipError_t launch_convgemm16(const ConvGeom& g, const float4* Wp, const float* X, long x_bstride, int ldx, const Epi& epi,
                                     hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   ConvArgs a;
@@ -268,9 +222,9 @@ inline hipError_t launch_convgemm16(const ConvGeom& g, const float4* Wp, const f
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)
-    hipExtLaunchKernelGGL((convgemm16_kernel<Epi, VAR>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipExtLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm16_kernel<Epi, VAR>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipLaunchKernelGGL((convgemm16_kernel<Epi>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 

@@ -18,18 +18,11 @@
 // the NR = 2 order (one float2 per lane) is derived from it on the device at attach time (`k_repack16_nr2`), so the packed
 // arena -- what the RCCL broadcast ships -- does not change.
 #pragma once
-#include <utility>
 #include "convgemm16.hip.h"
 
 namespace fdx {
 
 template <int N> struct VecN { float v[N]; };
-// two v_mfma_f32_16x16x4_f32 on two DIFFERENT accumulators (the two row blocks of one column set), pinned as one asm statement
-__device__ __forceinline__ void mfma16_pair_asm(f4& c0, f4& c1, float a0, float a1, float b) {
-  asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, %3, %4, %1" : "+a"(c0), "+a"(c1) : "v"(a0), "v"(a1), "v"(b));
-}
-template <int... I, class F>
-__device__ __forceinline__ void s64like_for_each(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
 
 // The same N adjacent floats kept as the VECTORS the loads produce (one dwordx4 + one tail load): the K loop's operand ring holds
@@ -177,16 +170,9 @@ template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum o
 // Packed A: NR = 4: [m64-tile][it][h][lane] float4 (pack_convgemm16);  NR = 2: [m32-tile][it][h][lane] float2 (k_repack16_nr2);
 // NR = 1 (out-projection only): [m16-tile][it][h][lane] float (k_repack16_from32<1>) -- 16 x (16 NM) tiles, twice the workgroups of NR = 2.
 // Paired epilogues: blocks 0 .. NR/2-1 hold the tile's gate rows (16 channels each), blocks NR/2 .. NR-1 the matching filter rows.
-// LTAPS > 0 selects the LDS-STAGED operand path (round 3) for a GEMM with exactly LTAPS taps (1 or 3), NR = 2:
-//   `global_load_dwordx4 -> VGPR` delivers ~18 B per clock per CU from the L2 on this chip, LDS-DMA (`global_load_lds_dwordx4`) 54-59
-//   (tools/ubench/l2bw.hip, profiles/r03_l2_to_cu_bandwidth.txt).  The register-direct K loop below asks for 16-21 B per clock per CU
-//   (the three taps re-read their rows through L1, which shares the return path) -- it is operand-delivery-bound, which is the 15-19 %
-//   its slots take over their MFMA issue and which no ring depth or load width moved.  Staged: every wave brings ITS OWN K range into its
-//   own LDS ring by DMA -- per 8-channel block the A fragments of the block's taps (1 KiB per tap, already in fragment order) and ONE
-//   8-row window of the activations (tile + 8 columns either side: the three taps read it at shifted columns, 4 KiB instead of 3 x 3.5) --
-//   waits on its own counted vmcnt (no barrier: nothing is shared between waves) and feeds the MFMAs from ds_reads issued one tap ahead.
-//   Same MFMAs in the same order on the same values: results are bit-identical to the register-direct path.
-template <class Epi, int NR, int NM, int LTAPS = 0>
+// (An LDS-staged operand path for this K loop -- per-wave LDS-DMA rings, asm-sequenced MFMA / ds_read stream -- was built and measured in
+// round 3: bit-identical, fewer cycles per wave, LONGER launches (26.6 vs 25.2 us); removed in round 4, see profiles/NOTES.md and commit 7078c9b.)
+template <class Epi, int NR, int NM>
 __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
   static_assert(NR == 2 || NR == 4 || (NR == 1 && !Epi::kPaired), "1 (unpaired epilogues only), 2 or 4 row blocks");
@@ -230,165 +216,7 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
 #pragma unroll
     for (int m = 0; m < NM; ++m) acc[x][m] = f4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- LDS-staged operands (see the kernel's header comment)
-  // staged window: tile + kPadL columns either side (>= the dilated taps' reach of 8).  16 rather than 8: the row pitch kW = 16 NM + 32
-  // floats is then 16 mod 32 banks for odd NM, which keeps the two k-rows a ds_read_b32 serves per cycle (lanes 0-31 = lk 0, 1) off each
-  // other's banks (pitch 128 = 0 mod 32: two-way conflicts on every B read, +1.1 us per conv launch)
-  constexpr int kPadL = 16, kW = 16 * NM + 2 * kPadL, kW16 = kW / 4;   // floats / 16-byte groups per channel row
-  constexpr int kBG = 8 * kW16, kNPB = (kBG + 63) / 64;                 // 16-byte groups / DMA pieces of B per 8-channel block
-  constexpr int kLT = LTAPS > 0 ? LTAPS : 1;
-  constexpr int kStage16 = kLT * 64 + kNPB * 64;                        // 16-byte groups per stage: A (1 KiB per tap), then the window
-  constexpr int kLD = LTAPS == 3 ? 3 : 4;                               // stages per wave (7.5 KB / 5.5 KB each at NM = 7).  Per-launch us, conv / out-
-  __shared__ uint4 ring[LTAPS > 0 ? NW * kLD * kStage16 : 1];           // projection: 2 / 3 stages 29.7 / 18.2;  3 / 4: 26.6 / 14.7;  4 / 6: 26.8 / 15.2
-  if constexpr (LTAPS > 0) {
-    static_assert(NR == 2, "LDS-staged path: one 1-KiB piece of A per K iteration");
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    prefetch_epilogue();                                                // oldest vector-memory ops of the wave: the first counted wait covers them
-    const int n_cb = (it_end - it_begin) / LTAPS;                       // host guarantees: whole channel blocks per wave, an even number
-    if (n_cb > 0) {
-      constexpr unsigned ASTEP = 2u * 64u * NR * 4u;                      // bytes of A per K iteration = one DMA piece
-      constexpr int P = LTAPS + kNPB;                                     // DMA instructions per stage per wave
-      constexpr unsigned STAGE_B = kStage16 * 16u;                        // bytes per ring slot
-      // uniform (SGPR) bases + constant per-lane byte offsets: every DMA is `global_load_lds_dwordx4 voffset, s[base]`
-      auto uniform_ptr = [](const char* p) {       // wave-uniform by construction: say so (the DMA's base operand must be an SGPR pair)
-        const unsigned long long v = (unsigned long long)p;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-      };
-      const char* a_base = uniform_ptr(reinterpret_cast<const char*>(a.Wp) + ((size_t)mt * a.n_it + it_begin) * ASTEP);
-      const unsigned rs = (unsigned)__builtin_amdgcn_readfirstlane(a.ldx) * 4u;
-      const char* x_base = uniform_ptr(reinterpret_cast<const char*>(a.X + item * a.x_bstride + (size_t)(it_begin / LTAPS) * 8 * a.ldx + t0 - kPadL));
-      // fetch cursors: 32-bit scalar offsets that saturate at the wave's last block (s_min_u32; 64-bit pointer compares would go through the VALU)
-      unsigned a_off = 0, x_off = 0;
-      const unsigned a_last = (unsigned)__builtin_amdgcn_readfirstlane(n_cb - 1) * (LTAPS * ASTEP), x_last = (unsigned)__builtin_amdgcn_readfirstlane(n_cb - 1) * 8u * rs;
-      const unsigned a_lane = lane * 16u;
-      unsigned boff[kNPB];
-      bool bval[kNPB];
-#pragma unroll
-      for (int p = 0; p < kNPB; ++p) {
-        const int e = p * 64 + lane, row = e / kW16, c16 = e - row * kW16;
-        bval[p] = row < 8;
-        boff[p] = (unsigned)min(row, 7) * rs + (unsigned)c16 * 16u;
-      }
-      const unsigned ring0 = (unsigned)(size_t)(lds_ptr_t)ring + (unsigned)wave * (kLD * STAGE_B);
-      auto glds16 = [&](unsigned voff, const char* sbase, unsigned dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
-      };
-      auto issue_piece = [&](int q, unsigned slot_b) {                    // piece q (0 .. P-1) of the block at the fetch cursors -> ring slot slot_b
-        const unsigned l = ring0 + slot_b;
-        if (q < LTAPS) glds16(a_lane, a_base + (a_off + q * ASTEP), l + q * 1024u);
-        else if (bval[q - LTAPS]) glds16(boff[q - LTAPS], x_base + x_off, l + (LTAPS * 64 + (q - LTAPS) * 64) * 16u);
-      };
-      auto advance = [&]() {
-        a_off = min(a_off + LTAPS * ASTEP, a_last);
-        x_off = min(x_off + 8u * rs, x_last);
-      };
-      auto issue = [&](unsigned slot_b) {
-#pragma unroll
-        for (int q = 0; q < P; ++q) issue_piece(q, slot_b);
-        advance();
-      };
-      // ---- the K loop proper is a sequence of small `asm volatile` statements (their relative order is the program's): one MFMA pair
-      // (the two row blocks of one column set: two different accumulators) followed by at most one ds_read / DMA piece.  hipcc's own
-      // schedule of the same C++ put the ds_reads in front of the MFMAs, paired MFMAs of one accumulator back to back and rotated the
-      // accumulator registers through copies at the loop edge (28.4-30.3 us per conv launch against 25.3 for the register-direct loop).
-      typedef float f2v __attribute__((ext_vector_type(2)));
-      constexpr int NBP = (NM + 1) / 2;                                   // B values per sub-step as read2 pairs (+ a single if NM is odd)
-      struct Frag { f2v a[2]; f2v b[2][NBP]; };
-      const unsigned ring_l = (unsigned)(size_t)(lds_ptr_t)ring + (unsigned)wave * (kLD * STAGE_B);
-      const unsigned rd_a = ring_l + lane * (NR * 4u);                                              // A: [tap][h][lane] float2
-      const unsigned rd_b = ring_l + LTAPS * 1024u + (unsigned)(lk * kW + kPadL + a.shift0 + NM * lj) * 4u;   // B: row lk, tap 0, sub-step 0
-      const unsigned tap_b = (unsigned)a.dshift * 4u;
-      constexpr unsigned H1 = 4u * kW * 4u;                                // sub-step 1 = rows lk + 4
-      // one read group g of fragment f at LDS byte addresses (va: A, vb: B of this tap): g = 0: A of h = 0; 1 .. NBP: B pairs of h = 0;
-      // NBP + 1: A of h = 1; NBP + 2 .. 2 NBP + 1: B pairs of h = 1
-      auto read_group = [&](Frag& f, unsigned va, unsigned vb, auto G_) {
-        constexpr int G = decltype(G_)::value, h = G / (NBP + 1), r = G % (NBP + 1);
-        if constexpr (r == 0) {
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(f.a[h]) : "v"(va), "n"(h * 512));
-        } else {
-          constexpr int m0 = 2 * (r - 1);
-          if constexpr (m0 + 1 < NM) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(f.b[h][r - 1]) : "v"(h ? vb + H1 : vb), "n"(m0), "n"(m0 + 1));
-          else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(f.b[h][r - 1].x) : "v"(h ? vb + H1 : vb), "n"(m0 * 4));
-        }
-      };
-      constexpr int NRG = 2 * (NBP + 1);                                   // read groups per fragment
-      auto read_all = [&](Frag& f, unsigned va, unsigned vb) {
-        s64like_for_each(std::make_integer_sequence<int, NRG>{}, [&](auto G_) { read_group(f, va, vb, G_); });
-      };
-      auto mfma_pair = [&](auto M_, const Frag& f, auto H_) {
-        constexpr int m = decltype(M_)::value, h = decltype(H_)::value;
-        mfma16_pair_asm(acc[0][m], acc[1][m], f.a[h].x, f.a[h].y, (m & 1) ? f.b[h][m >> 1].y : f.b[h][m >> 1].x);
-      };
-      FDX_STAMP(1);
-#pragma unroll
-      for (int d = 0; d < kLD - 1; ++d) issue(d * STAGE_B);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kLD - 2) * P) : "memory");   // block 0 landed
-      Frag fr[2];
-      read_all(fr[0], rd_a, rd_b);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // When may the DMA pieces of the block being fetched (block + kLD - 1, into the slot of block - 1) be issued, and what may stay in
-      // flight when the NEXT block's first fragments are read (at the block's last tap)?
-      //   LTAPS > 1: pieces ride the taps BEFORE the last one; at the last tap everything up to block + kLD - 1 is issued: keep kLD - 2 blocks.
-      //   LTAPS = 1: the one tap starts with the wait (issued so far: up to block + kLD - 2: keep kLD - 3 blocks), reads, then issues.
-      constexpr int KEEP = LTAPS > 1 ? (kLD - 2) * P : (kLD - 3) * P;
-      constexpr int PT = LTAPS > 1 ? LTAPS - 1 : 1;                         // taps that carry DMA pieces
-      constexpr int PPT = (P + PT - 1) / PT;                                // ... pieces each
-      constexpr int SLOTS = 2 * NM - 1 - NRG;                               // pairs of a tap behind which pieces can go (behind the read groups)
-      static_assert(SLOTS >= 1, "a tap's pairs: 1 (wait) + NRG (reads) + at least one for DMA pieces");
-      constexpr int PPS = (PPT + SLOTS - 1) / SLOTS;                        // pieces per such pair
-      unsigned slot_b = 0;                                                  // ring slot (byte offset) of the current block
-      auto block = [&](auto PAR_) {
-        constexpr int PAR = decltype(PAR_)::value;
-        const unsigned fetch_b = slot_b == 0 ? (kLD - 1) * STAGE_B : slot_b - STAGE_B;   // the slot of the previous block: all its fragments are consumed
-        const unsigned next_b = slot_b + STAGE_B == kLD * STAGE_B ? 0u : slot_b + STAGE_B;
-        s64like_for_each(std::make_integer_sequence<int, LTAPS>{}, [&](auto TP_) {
-          constexpr int tp = decltype(TP_)::value;
-          constexpr bool last_tap = tp + 1 == LTAPS;
-          Frag& cur = fr[(PAR + tp) & 1];
-          Frag& nxt = fr[(PAR + tp + 1) & 1];
-          const unsigned va = rd_a + (last_tap ? next_b : slot_b + (tp + 1) * 1024u);              // the NEXT tap's fragments
-          const unsigned vb = rd_b + (last_tap ? next_b : slot_b + (tp + 1) * tap_b);
-          // pair k of the tap's 2 * NM: sub-step h = k / NM, column set m = k % NM; behind it at most one read group or DMA piece
-          s64like_for_each(std::make_integer_sequence<int, 2 * NM>{}, [&](auto K_) {
-            constexpr int k = decltype(K_)::value;
-            mfma_pair(std::integral_constant<int, k % NM>{}, cur, std::integral_constant<int, k / NM>{});
-            if constexpr (LTAPS > 1) {
-              // reads behind pairs 1 .. NRG (the wait for the next block in front of them at the last tap), pieces behind the later pairs
-              if constexpr (k == 0 && last_tap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-              if constexpr (k >= 1 && k <= NRG) read_group(nxt, va, vb, std::integral_constant<int, k - 1>{});
-              if constexpr (!last_tap && k > NRG) {
-                s64like_for_each(std::make_integer_sequence<int, PPS>{}, [&](auto J_) {
-                  constexpr int w = (k - NRG - 1) * PPS + decltype(J_)::value, q = tp * PPT + w;
-                  if constexpr (w < PPT && q < P) issue_piece(q, fetch_b);
-                });
-              }
-            } else {
-              if constexpr (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-              if constexpr (k >= 1 && k <= NRG) read_group(nxt, va, vb, std::integral_constant<int, k - 1>{});
-              if constexpr (k > NRG) {
-                s64like_for_each(std::make_integer_sequence<int, PPS>{}, [&](auto J_) {
-                  constexpr int q = (k - NRG - 1) * PPS + decltype(J_)::value;
-                  if constexpr (q < P) issue_piece(q, fetch_b);
-                });
-              }
-            }
-          });
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the next tap's fragments have long landed: no copy of a pending register can follow
-        });
-        advance();
-        slot_b = next_b;
-      };
-      static_assert((LTAPS & 1) == 1, "odd tap counts (1 or 3): the parity scheme above");
-      for (int cbi = 0; cbi < n_cb; cbi += 2) {
-        block(std::integral_constant<int, 0>{});
-        block(std::integral_constant<int, 1>{});
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the trailing re-loads must not land in LDS after this workgroup left
-    }
-  } else if (it_begin < it_end) {
+  if (it_begin < it_end) {
     typedef float avec __attribute__((ext_vector_type(NR)));          // a lane's A values of one sub-step, as loaded (see RawN)
     struct Stage { avec a[2]; RawN<NM> b[2]; };                       // two K = 4 sub-steps = 8 channels
     const int n = it_end - it_begin;
@@ -519,29 +347,9 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
   FDX_STAMP_RT1();
 }
 
-// FDX_LDS_OPS=1: the LDS-staged operand path wherever it is instantiated (NR = 2, NM = 7) and the geometry allows.  OFF by default: it is
-// bit-identical and its waves need 16-22 % fewer cycles (tools/ktrace.py: conv K loop 76.3 k -> 61.3 k, out-projection 43.1 k -> 30.6 k),
-// but the launches take LONGER on the wall clock (batch 1 x 10 s: 26.6 vs 25.3 us, 14.7 vs 13.2 us).
-inline bool lds_ops_enabled() {
-  static const bool v = [] { const char* e = getenv("FDX_LDS_OPS"); return e && atoi(e) != 0; }();
-  return v;
-}
-
-// FDX_DYN_LDS=<bytes>: an UNUSED dynamic LDS allocation on top of the kernel's own (experiment: what does a workgroup's LDS footprint alone
-// cost a launch?  round 3: nothing measurable)
-inline unsigned dyn_lds_probe() {
-  static const unsigned v = [] { const char* e = getenv("FDX_DYN_LDS"); return e ? (unsigned)atol(e) : 0u; }();
-  return v;
-}
-
-template <class Epi, int NR, int NM, int LTAPS = 0>
+template <class Epi, int NR, int NM>
 inline hipError_t launch_convgemm16s(const ConvGeom& g, const void* Wp, const float* X, long x_bstride, int ldx, const Epi& epi,
                                      hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-  if constexpr (LTAPS > 0) {   // whole channel blocks per K-splitting wave, and the taps the instantiation was built for -- else register-direct
-    if (!lds_ops_enabled() || g.taps != LTAPS || (g.cin8 * g.taps) % (8 * LTAPS) != 0 || (LTAPS == 3 && (g.dshift > 16 || g.shift0 != -g.dshift)) ||
-        (LTAPS == 1 && g.shift0 != 0))
-      return launch_convgemm16s<Epi, NR, NM, 0>(g, Wp, X, x_bstride, ldx, epi, s, ev_start, ev_stop);
-  }
   ConvArgs a;
   a.Wp = static_cast<const float4*>(Wp); a.X = X; a.x_bstride = x_bstride; a.ldx = ldx;
   a.n_it = g.cin8 * g.taps; a.taps = g.taps; a.shift0 = g.shift0; a.dshift = g.dshift;
@@ -560,9 +368,9 @@ inline hipError_t launch_convgemm16s(const ConvGeom& g, const void* Wp, const fl
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)
-    hipExtLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM, LTAPS>), dim3(grid), dim3(256), dyn_lds_probe(), s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipExtLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM, LTAPS>), dim3(grid), dim3(256), dyn_lds_probe(), s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 

@@ -49,8 +49,6 @@ extern "C" int fdx_destroy(fdx_handle h) {
   if (h->td) fdx_td_free(h->td);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-  for (auto e : h->side_ev) (void)hipEventDestroy(e);
   for (auto e : h->prof.start) (void)hipEventDestroy(e);
   for (auto e : h->prof.stop) (void)hipEventDestroy(e);
   delete h;

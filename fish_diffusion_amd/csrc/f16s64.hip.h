@@ -33,7 +33,7 @@ __device__ __forceinline__ void s64_for_each_stage(std::integer_sequence<int, I.
 // NST: LDS stages (a stage is 34 KB for the conv, 18 KB for the one-tap out-projection).  The K loop is bound by LDS-DMA latency, not
 // by its MFMAs (tools/ktrace.py: 1340 cycles per 32-channel block of the conv against 576 cycles of MFMA issue with three stages, i.e.
 // one stage of look-ahead), so the stage count is how many blocks the DMA runs ahead: NST - 2 whole stages stay in flight across a barrier.
-template <class Epi, int NST = 3, int DBG = 0>
+template <class Epi, int NST = 3>
 __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
   constexpr int TAPS = Epi::kTaps, NW = kS64Waves;
   constexpr int PAD = TAPS == 3 ? 8 : 0;            // columns staged either side of the tile: the dilated taps reach 8; the one-tap GEMM none
@@ -127,27 +127,23 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
         for (int nb = 0; nb < 2; ++nb) fb[set][hl][nb] = lb[hl * 2 * WIN + shift + nb * 16];
       }
     };
-    if (!(DBG & 4)) frag(0, 0);
+    frag(0, 0);
 #pragma unroll
     for (int j = 0; j < TAPS; ++j) {
-      if (!(DBG & 4) && j + 1 < TAPS) frag(j + 1, (j + 1) & 1);
-      if (!(DBG & 1)) {
+      if (j + 1 < TAPS) frag(j + 1, (j + 1) & 1);
 #pragma unroll
-        for (int q = j * NP / TAPS; q < (j + 1) * NP / TAPS; ++q) piece(q, bk2, st2);
-      }
+      for (int q = j * NP / TAPS; q < (j + 1) * NP / TAPS; ++q) piece(q, bk2, st2);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(DBG & 4)) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+      for (int x = 0; x < 2; ++x)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, fa[j & 1][0][x]), al = __builtin_bit_cast(f16x8, fa[j & 1][1][x]);
-            const f16x8 bh = __builtin_bit_cast(f16x8, fb[j & 1][0][nb]), bl = __builtin_bit_cast(f16x8, fb[j & 1][1][nb]);
-            acc[x][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[x][nb], 0, 0, 0);
-            acc[x][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[x][nb], 0, 0, 0);
-            acc[x][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[x][nb], 0, 0, 0);
-          }
-      }
+        for (int nb = 0; nb < 2; ++nb) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, fa[j & 1][0][x]), al = __builtin_bit_cast(f16x8, fa[j & 1][1][x]);
+          const f16x8 bh = __builtin_bit_cast(f16x8, fb[j & 1][0][nb]), bl = __builtin_bit_cast(f16x8, fb[j & 1][1][nb]);
+          acc[x][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[x][nb], 0, 0, 0);
+          acc[x][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[x][nb], 0, 0, 0);
+          acc[x][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[x][nb], 0, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -155,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
   // ---- the epilogue's operands (conditioner slab | residual stream / skip sum, biases, keep mask), requested HERE, in front of the first
   // operand stage: their (cold) latency overlaps that stage's own and they land behind the K loop.  Unconditional loads: a column >= T
   // lies in the rows' right pad (readable, the value is not used).  They are older than every DMA piece, so the counted waits cover them.
-  // Round-3 measurements, batch 1 x 10 s, us per launch (conv + gate / out-projection; FDX_F16S_DBG builds): operands loaded after the K loop
+  // Round-3 measurements, batch 1 x 10 s, us per launch (conv + gate / out-projection; timing-only builds, removed since: commit 6735d87): operands loaded after the K loop
   // 15.2 / 12.1;  HERE as register loads 15.1 / 10.7 (9.3 with the pad-free window);  the same 64 x 64 fp32 tile by LDS-DMA in front of the
   // first stage 15.2 / 10.1, by LDS-DMA in the K loop's last two bodies 16.0 / 11.0 (two stages do not cover a cold fetch);  with neither
   // epilogue nor operands 9.1 / 6.2 -- the rest is the K loop's DMA (its MFMAs alone: 7.5 / 4.3).
@@ -205,12 +201,10 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
 
   // ---- K loop over the 32-channel blocks, NST stages with compile-time indices (see bf16lds_kernel)
   const int last = a.n_blk - 1;
-  if (!(DBG & 1)) {
 #pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
+  for (int st = 0; st < NST - 1; ++st)
 #pragma unroll
-      for (int q = 0; q < NP; ++q) piece(q, min(st, last), st);
-  }
+    for (int q = 0; q < NP; ++q) piece(q, min(st, last), st);
   wait_landed();
   FDX_STAMP(1);
   auto body = [&](auto S_, int blk) {
@@ -226,7 +220,6 @@ __global__ __launch_bounds__(256, 1) void f16s64_kernel(BfArgs a, Epi epi) {
   FDX_STAMP(2);
 
   // ---------------------------------------------------------------- epilogue: lane = column li of a 16-column block, rows 4 * kg .. + 3
-  if (DBG & 8) return;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int t = t0 + wc * 32 + nb * 16 + li;
@@ -288,27 +281,17 @@ inline hipError_t launch_f16s64(const uint4* Wp, const uint4* Xb, long x_bs, int
   // stage count: FDX_F16S_NST (conv: 3 | 4) / FDX_F16S_NST_O (out-projection: 3 | 4; 6 and 8 measured no better) override the defaults (A/B runs)
   static const int nst_c = [] { const char* e = getenv("FDX_F16S_NST"); const int k = e ? atoi(e) : 0; return (k == 3 || k == 4) ? k : kS64StagesConv; }();
   static const int nst_o = [] { const char* e = getenv("FDX_F16S_NST_O"); const int k = e ? atoi(e) : 0; return (k == 3 || k == 4) ? k : kS64StagesOutp; }();
-  // FDX_F16S_DBG=1 | 4 | 5 | 8: timing-only builds of the default instantiation WITHOUT its DMA / its MFMAs and fragment reads / both / its
-  // epilogue (results are garbage): which side bounds the kernel (tools/f16s_cross.py and bench.py do not look at the numbers)
-  static const int dbg = [] { const char* e = getenv("FDX_F16S_DBG"); return e ? atoi(e) : 0; }();
-#define FDX_S64_LAUNCH_D(N, D)                                                                                     \
+#define FDX_S64_LAUNCH(N)                                                                                        \
   do {                                                                                                             \
-    if (ev0) hipExtLaunchKernelGGL((f16s64_kernel<Epi, N, D>), dim3(grid), dim3(256), 0, s, ev0, ev1, 0, a, epi);  \
-    else hipLaunchKernelGGL((f16s64_kernel<Epi, N, D>), dim3(grid), dim3(256), 0, s, a, epi);                      \
+    if (ev0) hipExtLaunchKernelGGL((f16s64_kernel<Epi, N>), dim3(grid), dim3(256), 0, s, ev0, ev1, 0, a, epi);     \
+    else hipLaunchKernelGGL((f16s64_kernel<Epi, N>), dim3(grid), dim3(256), 0, s, a, epi);                         \
   } while (0)
-#define FDX_S64_LAUNCH(N) FDX_S64_LAUNCH_D(N, 0)
-  constexpr int NDEF = Epi::kTaps == 3 ? kS64StagesConv : kS64StagesOutp;
-  if (dbg == 1) FDX_S64_LAUNCH_D(NDEF, 1);
-  else if (dbg == 4) FDX_S64_LAUNCH_D(NDEF, 4);
-  else if (dbg == 8) FDX_S64_LAUNCH_D(NDEF, 8);
-  else if (dbg == 5) FDX_S64_LAUNCH_D(NDEF, 5);
-  else if constexpr (Epi::kTaps == 3) {
+  if constexpr (Epi::kTaps == 3) {
     if (nst_c == 4) FDX_S64_LAUNCH(4); else FDX_S64_LAUNCH(3);
   } else {
     if (nst_o == 3) FDX_S64_LAUNCH(3); else FDX_S64_LAUNCH(4);
   }
 #undef FDX_S64_LAUNCH
-#undef FDX_S64_LAUNCH_D
   return hipGetLastError();
 }
 

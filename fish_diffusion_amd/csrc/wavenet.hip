@@ -23,32 +23,16 @@
 
 using namespace fdx;
 
-// Which MFMA shape runs the two residual-block kernels.  Default: the dilated conv + gate on v_mfma_f32_16x16x4_f32
-// (convgemm16.hip.h: 4 x dwordx4 operand loads per 32 MFMAs, 16-byte epilogue quads; ~1 us faster per launch), the
-// out-projection on 32x32x2 (its short K loop -- 16 iterations per wave -- measured 3 % slower on 16x16x4).
-// FDX_RESBLOCK_MFMA=32 / 16 forces one family for both.  The families want different weight fragment orders, so the
-// switch is read wherever weights are packed AND where they are used: it must be the same on every rank of a job.
-static int resblock_mode() {   // bit 0: dilated conv + gate on 16x16x4, bit 1: out-projection on 16x16x4
-  static const int v = [] {
-    const char* e = getenv("FDX_RESBLOCK_MFMA");
-    if (!e) return 1;
-    if (atoi(e) == 32) return 0;
-    if (atoi(e) == 16) return 3;
-    return 1;
-  }();
-  return v;
-}
-static bool conv16() { return resblock_mode() & 1; }
-static bool outp16() { return resblock_mode() & 2; }
-
-static long kMinTilesMT2 = 1L << 60;   // disabled; FDX_MT2_MIN_TILES overrides (read in fdx_wavenet_attach)
-// Shape-adaptive tiles for the dilated conv + gate (convgemm16s.hip.h).  FDX_CONV_SHAPE=0 disables (always the 64 x 64 tile),
-// FDX_CONV_SHAPE=<NR><NM> (e.g. 27) forces one shape for A/B runs.
+// Both residual-block GEMMs run on v_mfma_f32_16x16x4_f32 (convgemm16s.hip.h).  The arena holds the dilated conv's weights in the 16x16x4
+// NR = 4 fragment order (pack_convgemm16) and the out-projection's in the generic 32x32x2 order (pack_convgemm), from which its 16x16x4
+// orders are derived on the device at attach time.  (Round 1-3 also carried a 32x32x2 residual-block family behind FDX_RESBLOCK_MFMA and
+// 128-row MT = 2 tiles behind FDX_MT2_MIN_TILES: measured slower, removed in round 4 -- profiles/NOTES.md.)
+// Shape-adaptive tiles for the dilated conv + gate (convgemm16s.hip.h).  FDX_CONV_SHAPE=<NR><NM> (e.g. 27; 44 = the round-1 64 x 64 tile) forces
+// one shape: the tile-shape bit-identity test runs every shape in its own process.
 static int conv_shape_env() {
   static const int v = [] { const char* e = getenv("FDX_CONV_SHAPE"); return e ? atoi(e) : -1; }();
   return v;
 }
-static bool shapes_enabled() { return conv_shape_env() != 0; }
 // bf16 storage mode: LDS-tiled kernels (bf16lds.hip.h) when a launch has at least this many 128 x 128 tiles; FDX_BF16_LDS=0 disables,
 // FDX_BF16_LDS=<n> sets the threshold
 static long bf16_lds_min_tiles() {
@@ -65,7 +49,7 @@ static long f16s_min_tiles() {
   return v;
 }
 constexpr size_t kBfTileSlack = 8192;   // bytes behind the blocked 16-bit operand buffers (see wn_alloc)
-static int outp_shape_env() {   // FDX_OUTP_SHAPE=0: always the 32x32x2 kernel; =<NR><NM>: force a 16x16x4 shape
+static int outp_shape_env() {   // FDX_OUTP_SHAPE=<NR><NM>: force one out-projection tile shape (NR = 1, 2, 4)
   static const int v = [] { const char* e = getenv("FDX_OUTP_SHAPE"); return e ? atoi(e) : -1; }();
   return v;
 }
@@ -167,32 +151,15 @@ extern "C" int fdx_wavenet_pack(const fdx_wavenet_desc* d, const float* const* w
     const float* op_w = w[k]; const float* op_b = w[k + 1]; k += 2;
     // dilated conv, gate/filter paired: tile mt holds gate rows 32mt.. (rb 0) and filter rows C+32mt.. (rb 1)
     const PackedW& pc = l.conv[i];
-    if (conv16()) {   // rbk 0,1: gate rows 32mt + 16rbk + r;  rbk 2,3: the matching filter rows
-      pack_convgemm16(A + pc.w_off, pc.n_mtiles, pc.cin8, 3, [&](int mt, int rbk, int r, int c, int tap) -> float {
-        const int ch = mt * 32 + (rbk & 1) * 16 + r;
-        if (ch >= C || c >= C) return 0.f;
-        return conv_w[((size_t)((rbk >> 1) * C + ch) * C + c) * 3 + tap];
-      });
-    } else {
-      pack_convgemm(A + pc.w_off, pc.n_mtiles, 2, pc.cin8, 3, [&](int mt, int rb, int r, int c, int tap) -> float {
-        const int ch = mt * 32 + r;
-        if (ch >= C || c >= C) return 0.f;
-        return conv_w[((size_t)(rb * C + ch) * C + c) * 3 + tap];
-      });
-    }
+    // 16x16x4 NR = 4 order: rbk 0,1: gate rows 32mt + 16rbk + r;  rbk 2,3: the matching filter rows
+    pack_convgemm16(A + pc.w_off, pc.n_mtiles, pc.cin8, 3, [&](int mt, int rbk, int r, int c, int tap) -> float {
+      const int ch = mt * 32 + (rbk & 1) * 16 + r;
+      if (ch >= C || c >= C) return 0.f;
+      return conv_w[((size_t)((rbk >> 1) * C + ch) * C + c) * 3 + tap];
+    });
     // the hoisted conditioner slab also absorbs the conv bias: y = (conv + b_conv) + (cond + b_cond), wavenet.py:112
     for (int r = 0; r < 2 * C; ++r) A[l.cond.b_off + (size_t)i * 2 * C + r] = cp_b[r] + conv_b[r];
-    if (outp16()) {
-      const PackedW& po = l.outp[i];
-      pack_convgemm16(A + po.w_off, po.n_mtiles, po.cin8, 1, [&](int mt, int rbk, int r, int c, int) -> float {
-        const int row = mt * 64 + rbk * 16 + r;
-        if (row >= 2 * C || c >= C) return 0.f;
-        return op_w[(size_t)row * C + c];
-      });
-      for (int r = 0; r < 2 * C; ++r) A[po.b_off + r] = op_b[r];
-    } else {
-      pack_plain(A, l.outp[i], op_w, 2 * C, C, op_b);
-    }
+    pack_plain(A, l.outp[i], op_w, 2 * C, C, op_b);
   }
   {  // diffusion projections of all layers = one [L*C x C] GEMM; conditioner projections = one [L*2C x E] GEMM
     const PackedW& p = l.dproj;
@@ -226,7 +193,6 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
   WavenetLayout l;
   wn_layout(*d, l);
   if (!dev || bytes != l.total_floats * sizeof(float)) return fail(h, FDX_E_ARG, "packed arena size mismatch");
-  if (const char* e = getenv("FDX_MT2_MIN_TILES")) kMinTilesMT2 = atol(e);
   h->wd = *d;
   h->wl = l;
   h->wn_arena = static_cast<const float*>(dev);
@@ -235,8 +201,7 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
   ++h->alloc_gen;   // recorded graphs bake the arena (and the derived buffer below) in
   // Shape-adaptive tiles (convgemm16s.hip.h): the dilated conv's weights once more in the NR = 2 fragment order, derived on the
   // device from the packed (NR = 4) arena.  One-off at model load: default stream, synchronous.
-  h->wn_nr2_ok = false;
-  if (conv16() && shapes_enabled()) {
+  {
     FDX_HIP(h, hipSetDevice(h->device));
     size_t total = 0;
     for (const auto& p : l.conv) total += packed_floats(p.n_mtiles, 2, p.cin8, p.taps);
@@ -250,8 +215,8 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
                          reinterpret_cast<const float4*>(h->wn_arena + p.w_off), n_src, p.cin8 * p.taps, 1);
       cur += n_src * 4;
     }
-    // the out-projection (packed for 32x32x2) in both 16x16x4 orders
-    if (!outp16()) {
+    // the out-projection (packed in the generic 32x32x2 order) in the three 16x16x4 orders
+    {
       size_t tot = 0;
       for (const auto& p : l.outp) tot += 3 * packed_floats(p.n_mtiles, 2, p.cin8, 1);
       FDX_HIP(h, h->wn_outp16.ensure(tot * sizeof(float), false, nullptr));
@@ -269,46 +234,9 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
                            p.n_mtiles, p.cin8);
         c2 += 3 * nf;
       }
-      // Deferred skip sum (experiment, FDX_DEFER_SKIP=<layers per group>): per group, the skip rows' weights of its layers side by side
-      // along K in the chosen tile order ([m-tile][layer][it]), and the sum of their biases.
-      h->defer_group = 0;
-      const int Gd = [] { const char* e = getenv("FDX_DEFER_SKIP"); return e ? atoi(e) : 0; }();
-      if (Gd > 0 && !l.outp.empty()) {
-        const int shp = [] { const char* e = getenv("FDX_DEFER_SHAPE"); return e ? atoi(e) : 27; }();
-        const int rshp = [] { const char* e = getenv("FDX_DEFER_RES_SHAPE"); return e ? atoi(e) : 0; }();
-        const int NRd = shp / 10, NMd = shp % 10;
-        if ((NRd != 1 && NRd != 2 && NRd != 4) || NMd < 4 || NMd > 8) return fail(h, FDX_E_ARG, "FDX_DEFER_SHAPE=%d: NR in {1,2,4}, NM in 4..8", shp);
-        if (rshp && (((rshp / 10) != 1 && (rshp / 10) != 2 && (rshp / 10) != 4) || rshp % 10 < 4 || rshp % 10 > 8))
-          return fail(h, FDX_E_ARG, "FDX_DEFER_RES_SHAPE=%d: NR in {1,2,4}, NM in 4..8", rshp);
-        const int Ld = (int)l.outp.size(), Cd = d->residual_channels, n_it = l.outp[0].cin8;
-        const int n_groups = (Ld + Gd - 1) / Gd;
-        const size_t nf = packed_floats(l.outp[0].n_mtiles, 2, l.outp[0].cin8, 1);   // one layer's [2C x C] matrix
-        FDX_HIP(h, h->wn_skipcat.ensure((size_t)Ld * (nf / 2) * sizeof(float), false, nullptr));
-        FDX_HIP(h, h->wn_skipbias.ensure((size_t)n_groups * Cd * sizeof(float), true, nullptr));
-        const auto& offs = NRd == 4 ? h->wn_outp16_off4 : NRd == 2 ? h->wn_outp16_off2 : h->wn_outp16_off1;
-        const int n_mtp = Cd / (16 * NRd);                     // m-tiles of the skip half
-        const size_t row_f = (size_t)n_it * 128 * NRd;          // floats of one m-tile of one layer
-        h->wn_skipcat_off.clear();
-        size_t cur = 0;
-        for (int g = 0; g < n_groups; ++g) {
-          const int a = g * Gd, lg = std::min(Gd, Ld - a);
-          h->wn_skipcat_off.push_back(cur);
-          for (int j = 0; j < lg; ++j) {
-            FDX_HIP(h, hipMemcpy2DAsync(h->wn_skipcat.f() + cur + (size_t)j * row_f, (size_t)lg * row_f * sizeof(float),
-                                        h->wn_outp16.f() + offs[a + j] + (size_t)n_mtp * row_f, row_f * sizeof(float), row_f * sizeof(float),
-                                        n_mtp, hipMemcpyDeviceToDevice, nullptr));
-            hipLaunchKernelGGL(k_acc_vec, dim3((Cd + 255) / 256), dim3(256), 0, nullptr, h->wn_skipbias.f() + (size_t)g * Cd,
-                               h->wn_arena + l.outp[a + j].b_off + Cd, Cd);
-          }
-          cur += (size_t)lg * (nf / 2);
-        }
-        h->defer_group = Gd; h->defer_nr = NRd; h->defer_nm = NMd; h->defer_res_nr = rshp / 10; h->defer_res_nm = rshp % 10;
-        h->defer_side = [] { const char* e = getenv("FDX_DEFER_SIDE"); return e && atoi(e) != 0; }();
-      }
     }
     FDX_HIP(h, hipGetLastError());
     FDX_HIP(h, hipStreamSynchronize(nullptr));
-    h->wn_nr2_ok = true;
   }
   return FDX_OK;
 }
@@ -464,8 +392,7 @@ extern "C" int fdx_wavenet_bf16_from_arena(fdx_handle h, void* dev_out, size_t b
   FDX_HIP(h, hipStreamSynchronize(s));   // `lay` dies at return (one-off set-up call)
   const size_t groups = (size_t)L * ((size_t)bl.conv_mt * bl.conv_it + (size_t)bl.outp_mt * bl.outp_it) * 128;
   hipLaunchKernelGGL(k_bf16_from_arena, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, static_cast<__bf16*>(dev_out), h->wn_arena,
-                     static_cast<const Bf16Derive*>(h->scratch_b.p), L, C, bl.conv_mt, bl.conv_it, bl.outp_mt, bl.outp_it, conv16() ? 1 : 0,
-                     outp16() ? 1 : 0);
+                     static_cast<const Bf16Derive*>(h->scratch_b.p), L, C, bl.conv_mt, bl.conv_it, bl.outp_mt, bl.outp_it, 1, 0);   // arena orders: conv 16x16x4, out-projection 32x32x2
   FDX_HIP(h, hipGetLastError());
   return FDX_OK;
 }
@@ -487,7 +414,9 @@ extern "C" int fdx_wavenet_bf16_attach(fdx_handle h, const void* dev, size_t byt
   ++h->alloc_gen;         // recorded sampler graphs bake the kernel choice in
   // the LDS-tiled kernels' A order (bf16lds.hip.h), a permutation of the same 16-byte groups: one-off, default stream, synchronous
   h->wn_bf16_lds_ok = false;
-  if (dev && h->wd.residual_channels % 64 == 0 && bf16_lds_enabled()) {
+  bool dil_ok = true;       // the LDS-tiled kernels stage tile +/- 8 columns: layers dilated by more than 8 need the register-direct kernels
+  for (int dl : h->wl.dil) dil_ok = dil_ok && dl <= 8;
+  if (dev && h->wd.residual_channels % 64 == 0 && bf16_lds_enabled() && dil_ok) {
     FDX_HIP(h, hipSetDevice(h->device));
     WnBf16Layout bl;
     wn_bf16_layout(h->wd, bl);
@@ -618,6 +547,10 @@ extern "C" int fdx_wavenet_f16s_enable(fdx_handle h, int on) {
   if (h->wn_arena_bf16) return fail(h, FDX_E_STATE, "fdx_wavenet_f16s_enable: the bf16 storage mode is attached (detach it first)");
   const int C = h->wd.residual_channels, L = h->wd.residual_layers;
   if (C % 64) return FDX_OK;   // no LDS tiling for this width: the fp32 kernels serve every launch (same fp32-class contract)
+  // both fp16-split kernel families stage the conv's window as tile +/- 8 columns (f16s64.hip.h PAD, bf16lds.hip.h): a dilation above 8
+  // would read outside the staged window
+  for (int dl : h->wl.dil)
+    if (dl > 8) return fail(h, FDX_E_NOIMPL, "fdx_wavenet_f16s_enable: dilation %d exceeds the 8-column window pad of the fp16-split kernels (dilation_cycle <= 4)", dl);
   FDX_HIP(h, hipSetDevice(h->device));
   const size_t groups = (size_t)L * (f16s_conv_groups(C) + f16s_outp_groups(C));
   FDX_HIP(h, h->wn_f16s.ensure(groups * 16, false, nullptr));
@@ -626,14 +559,14 @@ extern "C" int fdx_wavenet_f16s_enable(fdx_handle h, int on) {
   FDX_HIP(h, h->scratch_b.ensure(L * sizeof(F16sDerive), false, nullptr));
   FDX_HIP(h, hipMemcpy(h->scratch_b.p, lay.data(), L * sizeof(F16sDerive), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_f16s_from_arena, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, static_cast<_Float16*>(h->wn_f16s.p), h->wn_arena,
-                     static_cast<const F16sDerive*>(h->scratch_b.p), L, C, conv16() ? 1 : 0, outp16() ? 1 : 0, kF16sWScale);
+                     static_cast<const F16sDerive*>(h->scratch_b.p), L, C, 1, 0, kF16sWScale);
   FDX_HIP(h, hipGetLastError());
   h->wn_f16s64_ok = false;
   if (f16s_small_min_tiles() > 0) {
     const size_t g64 = (size_t)L * (f16s64_conv_groups(C) + f16s64_outp_groups(C));
     FDX_HIP(h, h->wn_f16s64.ensure(g64 * 16, false, nullptr));
     hipLaunchKernelGGL(k_f16s64_from_arena, dim3((unsigned)((g64 + 255) / 256)), dim3(256), 0, nullptr, static_cast<_Float16*>(h->wn_f16s64.p), h->wn_arena,
-                       static_cast<const F16sDerive*>(h->scratch_b.p), L, C, conv16() ? 1 : 0, outp16() ? 1 : 0, kF16sWScale);
+                       static_cast<const F16sDerive*>(h->scratch_b.p), L, C, 1, 0, kF16sWScale);
     FDX_HIP(h, hipGetLastError());
     h->wn_f16s64_ok = true;
   }
@@ -680,16 +613,8 @@ static hipError_t run_gemm(const float* arena, const PackedW& p, int B, int T, c
                            hipEvent_t ev1 = nullptr) {
   ConvGeom g{B, T, p.cin8, p.taps, shift0, dshift, p.n_mtiles};
   const float4* Wp = reinterpret_cast<const float4*>(arena + p.w_off);
-  // Optional 128-row tiles (two packed m-tiles per workgroup, convgemm_kernel<..., MT = 2>): 1/3 fewer operand loads and
-  // 1/4 fewer operand bytes per MFMA -- but 128 KB of LDS per workgroup, i.e. ONE workgroup per CU instead of two.
-  // Measured on MI355X (100-step UniPC, 10 s utterances): batch 2: 171.6 vs 173.9 ms (+1 %), batch 8: 632.5 vs 571.8 ms
-  // (-10 %): two co-resident 64-row workgroups hide each other's epilogues and operand waits better than one big one.
-  // Off by default (FDX_MT2_MIN_TILES=<n> enables it for launches with at least n 128-row tiles).
   if constexpr (!Epi::kPaired)
     if (p.RB == 1) return launch_convgemm<1, SPLITK, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s, ev0, ev1);
-  const long tiles2 = (long)B * ((T + 63) / 64) * (p.n_mtiles / 2);
-  if (SPLITK && p.n_mtiles % 2 == 0 && tiles2 >= kMinTilesMT2)
-    return launch_convgemm<2, SPLITK, LRELU, Epi, 4, SPLITK ? 2 : 1>(g, Wp, X, x_bs, ldx, slope, e, s, ev0, ev1);
   return launch_convgemm<2, SPLITK, LRELU, Epi>(g, Wp, X, x_bs, ldx, slope, e, s, ev0, ev1);
 }
 
@@ -712,20 +637,18 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
     const int rows16 = 2 * C / 16, n_per_wave = (C / 8 * 3 + 3) / 4;
     Shape16 sh{4, 4};
     const long wg44 = (long)(rows16 / 4) * B * ((T + 63) / 64);
-    if (h->wn_nr2_ok && wg44 < 2 * 256) sh = pick_shape16(rows16, B, T, 12000.0 / (32.0 * n_per_wave));
+    if (wg44 < 2 * 256) sh = pick_shape16(rows16, B, T, 12000.0 / (32.0 * n_per_wave));
     const int forced = conv_shape_env();
     if (forced > 0) sh = Shape16{forced / 10, forced % 10};
-    if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8 || (sh.NR == 2 && !h->wn_nr2_ok)) sh = Shape16{4, 4};
+    if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8) sh = Shape16{4, 4};
     h->conv_shape_nr = sh.NR; h->conv_shape_nm = sh.NM;
     // the out-projection (rows = 2C, K = C: 16 iterations per K-splitting wave) runs on the same 16x16x4 family for EVERY geometry,
-    // so that an item's result does not depend on the batch it rode in (the 32x32x2 kernel groups the k-steps differently:
-    // last-bit differences).  FDX_OUTP_SHAPE=0 restores the 32x32x2 kernel.
-    Shape16 so{0, 0};
-    const int forced_o = outp_shape_env();
-    if (h->wn_nr2_ok && !outp16() && forced_o != 0) {
+    // so that an item's result does not depend on the batch it rode in
+    Shape16 so{4, 4};
+    {
+      const int forced_o = outp_shape_env();
       const int n_o = (C / 8 + 3) / 4;
       const long wgo = (long)(rows16 / 4) * B * ((T + 63) / 64);
-      so = Shape16{4, 4};
       if (forced_o > 0) so = Shape16{forced_o / 10, forced_o % 10};
       else if (wgo < 2 * 256) so = pick_shape16(rows16, B, T, 12000.0 / (32.0 * n_o));
       if ((so.NR != 1 && so.NR != 2 && so.NR != 4) || so.NM < 4 || so.NM > 8) so = Shape16{4, 4};
@@ -738,15 +661,6 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
   FDX_HIP(h, h->X.ensure(sz(C), geom, s));
   FDX_HIP(h, h->Y.ensure(sz(C), geom, s));
   FDX_HIP(h, h->Z.ensure(sz(C), geom, s));
-  if (h->defer_group) {   // deferred skip sum: every layer's gated output; side stream + events made here, never inside a stream capture
-    FDX_HIP(h, h->Zs.ensure(sz(L * C), geom, s));
-    if (h->defer_side && !h->side_stream) FDX_HIP(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-    while (h->defer_side && (int)h->side_ev.size() < (L + h->defer_group - 1) / h->defer_group + 1) {
-      hipEvent_t e;
-      FDX_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      h->side_ev.push_back(e);
-    }
-  }
   FDX_HIP(h, h->SK.ensure(sz(C), geom, s));
   FDX_HIP(h, h->H.ensure(sz(C), geom, s));
   FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
@@ -845,8 +759,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   float* SK = h->SK.f() + kHalo; float* H = h->H.f() + kHalo;
   const float* S = h->S.f() + kHalo + col0;
   const float* keep = h->ragged_keep;   // exact-mask mode (fdx_sampler_run_ragged), else null
-  if (keep && (h->wn_arena_bf16 || !h->outp_shape_nr))
-    return fail(h, FDX_E_NOIMPL, "exact-mask runs need the fp32 shape-adaptive kernels (not bf16 storage / FDX_RESBLOCK_MFMA / FDX_*_SHAPE=0)");
+  if (keep && h->wn_arena_bf16) return fail(h, FDX_E_NOIMPL, "exact-mask runs are built for the fp32 / fp16-split kernels (not bf16 storage)");
 
   {  // input projection + ReLU + mask; Y = X + s_0
     EpiBias e = epi_bias(X, bsC, ld, A + l.in_proj.b_off, C, ACT_RELU);
@@ -879,40 +792,20 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       h->prof.note(PROF_WN_CONVGATE, "bf16lds_kernel<BfEpiGate, %d, %d> (%s; 128 x %d workgroup tile, operands into LDS by DMA)", wn, (int)f16s_big, mf, 64 * wn);
       h->prof.note(PROF_WN_OUTPROJ, "bf16lds_kernel<BfEpiResSkip, %d, %d> (%s; 128 x %d workgroup tile)", wn, (int)f16s_big, mf, 64 * wn);
     } else if (h->wn_arena_bf16) {
-      h->prof.note(PROF_WN_CONVGATE, "convgemm_kernel<2, true, 0, EpiGateB, 4, 1, OPK_BF16> (v_mfma_f32_32x32x16_bf16; 64 x 64 split-K workgroup tile, register-direct operands)");
-      h->prof.note(PROF_WN_OUTPROJ, "convgemm_kernel<2, true, 0, EpiResSkipB, 4, 1, OPK_BF16> (v_mfma_f32_32x32x16_bf16; 64 x 64 split-K workgroup tile)");
+      h->prof.note(PROF_WN_CONVGATE, "convgemm_kernel<2, true, 0, EpiGateB, OPK_BF16> (v_mfma_f32_32x32x16_bf16; 64 x 64 split-K workgroup tile, register-direct operands)");
+      h->prof.note(PROF_WN_OUTPROJ, "convgemm_kernel<2, true, 0, EpiResSkipB, OPK_BF16> (v_mfma_f32_32x32x16_bf16; 64 x 64 split-K workgroup tile)");
     } else {
-      if (!conv16())
-        h->prof.note(PROF_WN_CONVGATE, "convgemm_kernel<2, true, 0, EpiGate> (v_mfma_f32_32x32x2_f32; 64 x 64 split-K workgroup tile)");
-      else if (h->conv_shape_nr == 4 && h->conv_shape_nm == 4)
+      if (h->conv_shape_nr == 4 && h->conv_shape_nm == 4)
         h->prof.note(PROF_WN_CONVGATE, "convgemm16_kernel<EpiGate16> (v_mfma_f32_16x16x4_f32; 64 x 64 split-K workgroup tile)");
       else
         h->prof.note(PROF_WN_CONVGATE, "convgemm16s_kernel<EpiGate16S<%d>, %d, %d> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, %ld workgroups)",
                      h->conv_shape_nm, h->conv_shape_nr, h->conv_shape_nm, 16 * h->conv_shape_nr, 16 * h->conv_shape_nm,
                      (long)B * ((T + 16 * h->conv_shape_nm - 1) / (16 * h->conv_shape_nm)) * (2 * C / (16 * h->conv_shape_nr)));
-      if (h->outp_shape_nr)
-        h->prof.note(PROF_WN_OUTPROJ, "convgemm16s_kernel<EpiResSkip16S<%d>, %d, %d> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, %ld workgroups)",
-                     h->outp_shape_nm, h->outp_shape_nr, h->outp_shape_nm, 16 * h->outp_shape_nr, 16 * h->outp_shape_nm,
-                     (long)B * ((T + 16 * h->outp_shape_nm - 1) / (16 * h->outp_shape_nm)) * (2 * C / (16 * h->outp_shape_nr)));
-      else if (outp16())
-        h->prof.note(PROF_WN_OUTPROJ, "convgemm16_kernel<EpiResSkip16> (v_mfma_f32_16x16x4_f32; 64 x 64 split-K workgroup tile)");
-      else
-        h->prof.note(PROF_WN_OUTPROJ, "convgemm_kernel<2, true, 0, EpiResSkip> (v_mfma_f32_32x32x2_f32; 64 x 64 split-K workgroup tile)");
+      h->prof.note(PROF_WN_OUTPROJ, "convgemm16s_kernel<EpiResSkip16S<%d>, %d, %d> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, %ld workgroups)",
+                   h->outp_shape_nm, h->outp_shape_nr, h->outp_shape_nm, 16 * h->outp_shape_nr, 16 * h->outp_shape_nm,
+                   (long)B * ((T + 16 * h->outp_shape_nm - 1) / (16 * h->outp_shape_nm)) * (2 * C / (16 * h->outp_shape_nr)));
     }
   }
-  // Deferred skip sum (FDX_DEFER_SKIP): fp32 shape-adaptive path only
-  const int Gd = (h->defer_group && !f16s && !h->wn_arena_bf16 && conv16() && h->outp_shape_nr &&
-                  !(h->conv_shape_nr == 4 && h->conv_shape_nm == 4)) ? h->defer_group : 0;
-  float* Zs = Gd ? h->Zs.f() + kHalo : nullptr;
-  const long bsZ = Gd ? (long)L * C * ld : bsC;
-  hipStream_t sg = s;                       // the stream the group GEMMs go to
-  int side_used = 0;
-  auto side_event = [&](hipEvent_t& ev) -> hipError_t {
-    if (side_used >= (int)h->side_ev.size()) return hipErrorInvalidValue;   // (made in prepare)
-    ev = h->side_ev[side_used++];
-    return hipSuccess;
-  };
-  if (Gd && h->defer_side && h->side_stream) sg = h->side_stream;
   for (int i = 0; i < L; ++i) {
     const int dil = l.dil[i];
     hipEvent_t ev0 = nullptr, ev1 = nullptr, eo0 = nullptr, eo1 = nullptr;   // fdx_prof_*: one of the two kernels, sampled
@@ -961,7 +854,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       g.out = Z; g.o_bs = bsC; g.ldo = ld; g.P = Pl; g.p_bs = p_bs; g.ldp = ld; g.C = C;
       g.outb = Zb; g.ob_bs = bsB;
       const ConvGeom gc{B, T, C / 16, 3, -dil, dil, bl.conv_mt};
-      FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiGateB, 4, 1, OPK_BF16>(gc, WB + bl.conv[i], reinterpret_cast<const float*>(Yb),
+      FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiGateB, OPK_BF16>(gc, WB + bl.conv[i], reinterpret_cast<const float*>(Yb),
                                                                               bsB / 2, ld, 1.f, g, s, ev0, ev1)));
       EpiResSkipB r{};
       r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
@@ -969,43 +862,35 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       r.skip_mode = skip_mode; r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
       r.Yb = (i + 1 < L) ? Yb : nullptr; r.yb_bs = bsB;
       const ConvGeom go{B, T, C / 16, 1, 0, 0, bl.outp_mt};
-      FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkipB, 4, 1, OPK_BF16>(go, WB + bl.outp[i], reinterpret_cast<const float*>(Zb),
+      FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkipB, OPK_BF16>(go, WB + bl.outp[i], reinterpret_cast<const float*>(Zb),
                                                                                  bsB / 2, ld, 1.f, r, s, eo0, eo1)));
       continue;
     }
-    if (conv16()) {
-      const ConvGeom gc{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles};
-      EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
+    {  // dilated conv k = 3 + gate (wavenet.py:107-115): 64 x 64 round-1 tile, or the shape picked for this geometry
+      const ConvGeom g4{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles}, g2{B, T, l.conv[i].cin8, 3, -dil, dil, 2 * l.conv[i].n_mtiles};
       const int NRs = h->conv_shape_nr, NMs = h->conv_shape_nm;
       if (NRs == 4 && NMs == 4) {
-        FDX_HIP(h, launch_convgemm16(gc, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
+        EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
+        FDX_HIP(h, launch_convgemm16(g4, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
       } else {
         const void* W4 = A + l.conv[i].w_off;
-        const void* W2 = h->wn_nr2_ok ? h->wn_nr2.f() + h->wn_nr2_off[i] : nullptr;
-        const ConvGeom g4{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles}, g2{B, T, l.conv[i].cin8, 3, -dil, dil, 2 * l.conv[i].n_mtiles};
+        const void* W2 = h->wn_nr2.f() + h->wn_nr2_off[i];
         hipError_t e = hipErrorInvalidValue;
 #define FDX_GATE_SHAPE(NR_, NM_)                                                                                              \
   if (NRs == NR_ && NMs == NM_) {                                                                                             \
-    const EpiGate16S<NM_> gs{Gd ? Zs + (size_t)i * C * ld : Z, bsZ, ld, Pl, p_bs, ld, C};                                     \
-    e = launch_convgemm16s<EpiGate16S<NM_>, NR_, NM_, (NR_ == 2 && NM_ == 7) ? 3 : 0>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Y, bsC, ld, gs, s, ev0, ev1); \
+    const EpiGate16S<NM_> gs{Z, bsC, ld, Pl, p_bs, ld, C};                                                                    \
+    e = launch_convgemm16s<EpiGate16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, Y, bsC, ld, gs, s, ev0, ev1);   \
   }
         FDX_GATE_SHAPE(4, 5) FDX_GATE_SHAPE(4, 6) FDX_GATE_SHAPE(4, 7) FDX_GATE_SHAPE(4, 8)
         FDX_GATE_SHAPE(2, 4) FDX_GATE_SHAPE(2, 5) FDX_GATE_SHAPE(2, 6) FDX_GATE_SHAPE(2, 7) FDX_GATE_SHAPE(2, 8)
 #undef FDX_GATE_SHAPE
         FDX_HIP(h, e);
       }
-    } else {
-      EpiGate g{};
-      g.out = Z; g.o_bs = bsC; g.ldo = ld;
-      g.P = Pl; g.p_bs = p_bs; g.ldp = ld; g.C = C;
-      FDX_HIP(h, (run_gemm<true, false>(A, l.conv[i], B, T, Y, bsC, ld, -dil, dil, 1.f, g, s, ev0, ev1)));
     }
-    if (h->outp_shape_nr) {   // shape-adaptive 16x16x4 tiles (weights re-ordered at attach)
-      const int NRo = (Gd && h->defer_res_nr) ? h->defer_res_nr : h->outp_shape_nr, NMo = (Gd && h->defer_res_nr) ? h->defer_res_nm : h->outp_shape_nm;
-      const int hv = Gd ? 2 : 1;      // deferred skip sum: the residual rows only (the first half of the m-tiles)
-      const float* Zin = Gd ? Zs + (size_t)i * C * ld : Z;
-      const ConvGeom g4{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles / hv}, g2{B, T, l.outp[i].cin8, 1, 0, 0, 2 * l.outp[i].n_mtiles / hv},
-          g1{B, T, l.outp[i].cin8, 1, 0, 0, 4 * l.outp[i].n_mtiles / hv};
+    {  // out-projection + residual / skip (wavenet.py:117-120, 228): shape-adaptive 16x16x4 tiles (weights re-ordered at attach)
+      const int NRo = h->outp_shape_nr, NMo = h->outp_shape_nm;
+      const ConvGeom g4{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles}, g2{B, T, l.outp[i].cin8, 1, 0, 0, 2 * l.outp[i].n_mtiles},
+          g1{B, T, l.outp[i].cin8, 1, 0, 0, 4 * l.outp[i].n_mtiles};
       const void* W4 = h->wn_outp16.f() + h->wn_outp16_off4[i];
       const void* W2 = h->wn_outp16.f() + h->wn_outp16_off2[i];
       const void* W1 = h->wn_outp16.f() + h->wn_outp16_off1[i];
@@ -1014,67 +899,14 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   if (NRo == NR_ && NMo == NM_) {                                                                                                  \
     const EpiResSkip16S<NM_> rs{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL, \
                                 (float)(1.0 / (double)sqrtL), keep, (long)ld};                                                     \
-    e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_, (NR_ == 2 && NM_ == 7) ? 1 : 0>(NR_ == 4 ? g4 : NR_ == 2 ? g2 : g1,                 \
-                                                                                             NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, Zin, bsZ, ld, rs, s, eo0, eo1); \
+    e = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : NR_ == 2 ? g2 : g1, NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, Z, bsC, ld, rs, s, eo0, eo1); \
   }
       FDX_OUTP_SHAPE(4, 4) FDX_OUTP_SHAPE(4, 5) FDX_OUTP_SHAPE(4, 6) FDX_OUTP_SHAPE(4, 7) FDX_OUTP_SHAPE(4, 8)
       FDX_OUTP_SHAPE(2, 4) FDX_OUTP_SHAPE(2, 5) FDX_OUTP_SHAPE(2, 6) FDX_OUTP_SHAPE(2, 7) FDX_OUTP_SHAPE(2, 8)
       FDX_OUTP_SHAPE(1, 4) FDX_OUTP_SHAPE(1, 5) FDX_OUTP_SHAPE(1, 6) FDX_OUTP_SHAPE(1, 7) FDX_OUTP_SHAPE(1, 8)
 #undef FDX_OUTP_SHAPE
       FDX_HIP(h, e);
-      if (Gd && ((i + 1) % Gd == 0 || i + 1 == L)) {   // the skip rows of layers [a, i] as one GEMM with K = (i + 1 - a) C
-        const int g = i / Gd, a = g * Gd, lg = i + 1 - a, n_groups = (L + Gd - 1) / Gd;
-        const int gmode = n_groups == 1 ? 3 : (g == 0 ? 0 : (g + 1 == n_groups ? 2 : 1));
-        if (sg != s) {
-          hipEvent_t ev;
-          FDX_HIP(h, side_event(ev));
-          FDX_HIP(h, hipEventRecord(ev, s));
-          FDX_HIP(h, hipStreamWaitEvent(sg, ev, 0));
-        }
-        const int NRd = h->defer_nr, NMd = h->defer_nm;
-        const ConvGeom gg{B, T, lg * (C / 8), 1, 0, 0, C / (16 * NRd)};
-        const void* Wg = h->wn_skipcat.f() + h->wn_skipcat_off[g];
-        hipError_t eg = hipErrorInvalidValue;
-#define FDX_DEFER_SHAPE(NR_, NM_)                                                                                                       \
-  if (NRd == NR_ && NMd == NM_) {                                                                                                       \
-    const EpiResSkip16S<NM_> rs{X, nullptr, SK, bsC, ld, h->wn_skipbias.f() + (size_t)g * C, sbn, ldn, sb_bs, 0, gmode, sqrtL,          \
-                                (float)(1.0 / (double)sqrtL), nullptr, (long)ld};                                                       \
-    eg = launch_convgemm16s<EpiResSkip16S<NM_>, NR_, NM_, 0>(gg, Wg, Zs + (size_t)a * C * ld, bsZ, ld, rs, sg);                          \
-  }
-        FDX_DEFER_SHAPE(4, 4) FDX_DEFER_SHAPE(4, 7) FDX_DEFER_SHAPE(4, 8)
-        FDX_DEFER_SHAPE(2, 4) FDX_DEFER_SHAPE(2, 5) FDX_DEFER_SHAPE(2, 6) FDX_DEFER_SHAPE(2, 7) FDX_DEFER_SHAPE(2, 8)
-        FDX_DEFER_SHAPE(1, 4) FDX_DEFER_SHAPE(1, 7) FDX_DEFER_SHAPE(1, 8)
-#undef FDX_DEFER_SHAPE
-        FDX_HIP(h, eg);
-      }
-    } else if (outp16()) {
-      const ConvGeom go{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles};
-      EpiResSkip16 r{X, (i + 1 < L) ? Y : nullptr, SK, bsC, ld, A + l.outp[i].b_off, sbn, ldn, sb_bs, C, skip_mode, sqrtL,
-                     (float)(1.0 / (double)sqrtL)};
-      FDX_HIP(h, launch_convgemm16(go, reinterpret_cast<const float4*>(A + l.outp[i].w_off), Z, bsC, ld, r, s, eo0, eo1));
-    } else {
-      EpiResSkip r{};
-      r.X = X; r.SK = SK; r.bs = bsC; r.ld = ld; r.bias = A + l.outp[i].b_off; r.C = C;
-      r.Y = (i + 1 < L) ? Y : nullptr;
-      r.sb = sbn; r.sb_ld = ldn; r.sb_bs = sb_bs;
-      r.skip_mode = skip_mode;
-      r.inv_div = sqrtL; r.r_inv_div = (float)(1.0 / (double)sqrtL);
-      static const int outp_var = [] { const char* e = getenv("FDX_OUTP_VAR"); return e ? atoi(e) : 0; }();   // tuning experiments
-      const ConvGeom go{B, T, l.outp[i].cin8, 1, 0, 0, l.outp[i].n_mtiles};
-      const float4* Wo = reinterpret_cast<const float4*>(A + l.outp[i].w_off);
-      switch (outp_var) {
-        case 1: FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkip, 4, 1, OPK_F32, 1>(go, Wo, Z, bsC, ld, 1.f, r, s, eo0, eo1))); break;
-        case 2: FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkip, 4, 1, OPK_F32, 2>(go, Wo, Z, bsC, ld, 1.f, r, s, eo0, eo1))); break;
-        case 3: FDX_HIP(h, (launch_convgemm<2, true, PRE_NONE, EpiResSkip, 4, 1, OPK_F32, 3>(go, Wo, Z, bsC, ld, 1.f, r, s, eo0, eo1))); break;
-        default: FDX_HIP(h, (run_gemm<true, false>(A, l.outp[i], B, T, Z, bsC, ld, 0, 0, 1.f, r, s, eo0, eo1)));
-      }
     }
-  }
-  if (Gd && sg != s) {   // join: skip_projection reads the group GEMMs' sum
-    hipEvent_t ev;
-    FDX_HIP(h, side_event(ev));
-    FDX_HIP(h, hipEventRecord(ev, sg));
-    FDX_HIP(h, hipStreamWaitEvent(s, ev, 0));
   }
   {
     EpiBias e = epi_bias(H, bsC, ld, A + l.skip_proj.b_off, C, ACT_RELU);

@@ -232,10 +232,15 @@ class WaveNet(HipDenoiser):
         if mode not in STORAGE_MODES:
             raise ValueError(f"storage must be one of {STORAGE_MODES}, got {mode!r}")
         if mode != self._storage:
-            self._storage = mode
+            prev, self._storage = self._storage, mode
             self._prep_sig = None
             if self._handle is not None and self._arena is not None:
-                self._after_attach()
+                try:
+                    self._after_attach()
+                except Exception:       # e.g. fp16x3 on a net with a dilation beyond the kernels' LDS window: stay in the previous mode
+                    self._storage = prev
+                    self._after_attach()
+                    raise
 
     def _after_attach(self):
         l = _lib.lib()
