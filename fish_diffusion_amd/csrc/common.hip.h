@@ -69,6 +69,10 @@ struct NsfStage {
   size_t nc_w = 0, nc_b = 0; int nc_k = 1, nc_stride = 1, nc_pad = 0;   // noise conv (VALU kernel), raw layout
   int cin = 0, cout = 0, stride = 1, ksize = 1;
   std::vector<PackedW> c1, c2;   // [n_resblock_kernels * n_dil]; c2 empty for ResBlock2
+  // small-channel stages (C = 16 / 32, ResBlock1 with three dilations): the same weights once more in the fused kernel's order
+  // (resblock_fused.hip.h): per ResBlock 6 convs x KS*C*C floats at fw[j], 6 x C biases at fb[j]
+  bool fused = false;
+  std::vector<size_t> fw, fb;
 };
 struct NsfLayout {
   size_t src_w = 0, src_b = 0;        // m_source.l_linear

@@ -13,6 +13,7 @@
 #include "elementwise.hip.h"
 #include "nsf_kernels.hip.h"
 #include "convplan.hip.h"
+#include "resblock_fused.hip.h"
 
 using namespace fdx;
 
@@ -94,6 +95,18 @@ static void nsf_layout(const fdx_nsf_desc& d, NsfLayout& l) {
   l.post_c = l.stages.back().cout;
   l.post_w = cur; cur += round_up(l.post_c * 7, 64);
   l.post_b = cur; cur += 64;
+  // fused ResBlock1 weights of the small-channel stages (behind everything else: the offsets above do not move)
+  for (int i = 0; i < d.n_stages; ++i) {
+    NsfStage& st = l.stages[i];
+    st.fused = d.resblock_type == 1 && d.n_dilations == kRbPairs;
+    for (int j = 0; j < d.n_resblock_kernels; ++j) st.fused = st.fused && rb_fused_supported(st.cout, d.resblock_kernel_sizes[j]);
+    st.fw.clear(); st.fb.clear();
+    if (!st.fused) continue;
+    for (int j = 0; j < d.n_resblock_kernels; ++j) {
+      st.fw.push_back(cur); cur += round_up((int)(2 * kRbPairs * rb_fused_floats(st.cout, d.resblock_kernel_sizes[j])), 64);
+      st.fb.push_back(cur); cur += round_up(2 * kRbPairs * st.cout, 64);
+    }
+  }
   l.total_floats = cur;
 }
 
@@ -151,6 +164,13 @@ extern "C" int fdx_nsf_pack(const fdx_nsf_desc* d, const float* const* w, int n,
     size_t idx = 0;
     for (int j = 0; j < d->n_resblock_kernels; ++j)
       for (int q = 0; q < d->n_dilations; ++q, ++idx) {
+        const int ks = d->resblock_kernel_sizes[j];
+        if (st.fused) {     // conv 2q = c1_q, conv 2q + 1 = c2_q
+          rb_fused_pack(A + st.fw[j] + (size_t)(2 * q) * rb_fused_floats(st.cout, ks), w[k], st.cout, ks);
+          memcpy(A + st.fb[j] + (size_t)(2 * q) * st.cout, w[k + 1], (size_t)st.cout * sizeof(float));
+          rb_fused_pack(A + st.fw[j] + (size_t)(2 * q + 1) * rb_fused_floats(st.cout, ks), w[k + 2], st.cout, ks);
+          memcpy(A + st.fb[j] + (size_t)(2 * q + 1) * st.cout, w[k + 3], (size_t)st.cout * sizeof(float));
+        }
         pack_conv1d(A, st.c1[idx], w[k], st.cout, st.cout, w[k + 1]); k += 2;
         if (d->resblock_type == 1) { pack_conv1d(A, st.c2[idx], w[k], st.cout, st.cout, w[k + 1]); k += 2; }
       }
@@ -170,6 +190,12 @@ extern "C" int fdx_nsf_attach(fdx_handle h, const fdx_nsf_desc* d, const void* d
   h->nd = *d; h->nl = l; h->nsf_arena = static_cast<const float*>(dev); h->nsf_ok = true;
   h->vB = h->vT = 0;
   return FDX_OK;
+}
+
+// FDX_NSF_FUSED=0: the small-channel stages conv by conv (the path the fused ResBlock1 kernel is tested against)
+static bool nsf_fused_enabled() {
+  static const bool v = [] { const char* e = getenv("FDX_NSF_FUSED"); return !e || atoi(e) != 0; }();
+  return v;
 }
 
 // ================================================================================================ noise convs
@@ -342,6 +368,16 @@ extern "C" int fdx_nsf_forward(fdx_handle h, const float* mel, const float* f0, 
     launch_noise_conv(U, bs, g.ld, har, (long)ldL, A + st.nc_w, A + st.nc_b, st.cout, g.L, st.nc_k, st.nc_stride, st.nc_pad, B, s);
     for (int j = 0; j < nk; ++j) {
       const int k = d.resblock_kernel_sizes[j];
+      if (st.fused && nsf_fused_enabled()) {   // small-channel stage: the whole ResBlock1 (six convs) out of LDS in one launch
+        RbFusedArgs fa{};
+        fa.X = U; fa.x_bs = bs; fa.ldx = g.ld; fa.out = XS; fa.o_bs = bs; fa.ldo = g.ld;
+        fa.W = A + st.fw[j]; fa.bias = A + st.fb[j]; fa.L = g.L;
+        for (int q = 0; q < kRbPairs; ++q) { fa.d1[q] = d.resblock_dilations[j][q]; fa.d2[q] = 1; }
+        fa.slope = 0.1f;
+        fa.mode = (j == 0) ? 0 : (j + 1 == nk ? 2 : 1); fa.div = (float)nk;
+        FDX_HIP(h, launch_resblock1_fused(st.cout, k, fa, B, s));
+        continue;
+      }
       const float* cur = U;   // running x of this resblock
       for (int q = 0; q < nd; ++q) {
         const int dil = d.resblock_dilations[j][q];

@@ -1,0 +1,239 @@
+// resblock_fused.hip.h -- one launch per ResBlock1 for the vocoders' SMALL-CHANNEL stages (C = 16 / 32 at 2-4 x 10^5 samples).
+//
+// Reference: fish_diffusion/modules/vocoders/nsf_hifigan/models.py:44-110 (ResBlock1: three pairs  xt = c1_j(lrelu(x)); xt = c2_j(lrelu(xt));
+// x = xt + x, c1 dilated by d_j, c2 by 1) and :426-432 (the MRF mean over the three kernel sizes); RefineGAN's ResBlock
+// (refinegan/generator.py:63-75: both convs of a pair dilated by d_j, slope 0.2).
+//
+// Why: run conv by conv, these stages are not MFMA-bound but traffic-bound -- each of the 18 convs of a stage reads 28 MB, writes 28 MB and
+// the residual adds another read (2.9-3.5 TB/s measured at C = 16, profiles/r03_vocoder_launch_sequence.txt: 27 % / 47 % of the fp32 MFMA
+// roof).  Here a workgroup owns N output columns of ALL C channels, stages the window x[C][N + 2H] (H = the six convs' receptive field:
+// 12 / 36 / 60 columns per side for k = 3 / 7 / 11) ONCE into LDS and runs the six convs out of LDS -- the intermediate of each pair in a
+// second LDS buffer, the running x updated in place -- so a ResBlock reads its input once and writes its output once.  The halo columns are
+// recomputed per tile (N = 1024 at C = 16: +6 % MFMA work on average; N = 448 at C = 32: +13 %), a trade the roofs make easy.
+//
+//   v_mfma_f32_16x16x4_f32:  A = weights [16 rows][4 channels] of one tap (lane l: row l & 15, channel l >> 4) -- a conv's whole weight set
+//   lives in registers (12 ... 176 per lane), loaded once per conv per tile; B = activations [4 channels][16 columns] read from LDS with
+//   ds_read2_b32 (lane l: channel l >> 4, column l & 15; row pitch = 16 mod 32 banks -> conflict-free); D = exactly C rows: no row padding.
+//   A wave owns 32-column units (2 x C/16 independent accumulators) dealt round-robin; one barrier per conv.
+//
+// Zero padding of the reference's convs applies to EVERY conv's input separately: every intermediate is written as 0 outside [0, L).
+// Summation order differs from the per-conv kernels (tap-major over 4-channel groups instead of 8-channel blocks): fp32-rounding-level
+// differences, inside the 1e-4 waveform bar with a margin of 30 (tests/test_gpu_round4.py compares the two paths directly).
+#pragma once
+#include <type_traits>
+
+#include "common.hip.h"
+
+namespace fdx {
+
+constexpr int kRbPairs = 3;   // (c1, c2) pairs per ResBlock1: the shipped configs' [1, 3, 5]
+
+struct RbFusedArgs {
+  const float* X; long x_bs; int ldx;     // input rows [B][C][ldx], pointer at column 0
+  float* out; long o_bs; int ldo;         // output rows
+  const float* W;                         // this ResBlock's fused weights: 6 convs x [tap][rb][q][lane] float4 (rb_fused_pack)
+  const float* bias;                      // 6 x C
+  int L, N, tiles_per_item;               // valid columns, owned columns per tile (multiple of 32)
+  int d1[kRbPairs], d2[kRbPairs];         // dilations of c1_j / c2_j
+  float slope;
+  int mode; float div;                    // output: 0: out = v   1: out += v   2: out = (out + v) / div   (EpiResblock's modes)
+};
+
+template <int C> struct RbGeom {
+  static constexpr int P = C == 16 ? 1168 : 592;     // LDS row pitch in floats: 16 mod 32, two buffers of C x P fit 160 KB
+};
+inline int rb_halo(int ks, const int* d1, const int* d2) {
+  int h = 0;
+  for (int j = 0; j < kRbPairs; ++j) h += (ks - 1) / 2 * (d1[j] + d2[j]);
+  return h;
+}
+// owned columns per tile: the widest window the LDS rows hold, then shrunk so that the tiles fill whole rounds of `n_cu` workgroups
+// (the chip runs ceil(tiles / n_cu) rounds of one workgroup per CU; each costs ~ N + 2H columns of work)
+inline int rb_pick_n(int C, int H4, long L, int B, int n_cu = 256) {
+  const int P = C == 16 ? RbGeom<16>::P : RbGeom<32>::P;
+  const int n_max = (P - 32 - 2 * H4) / 32 * 32;
+  if (n_max < 64) return 0;
+  int best = n_max;
+  double best_cost = 1e300;
+  for (int n = n_max; n >= 64 && n >= n_max / 2; n -= 32) {
+    const long tiles = (long)B * ((L + n - 1) / n);
+    const double cost = (double)((tiles + n_cu - 1) / n_cu) * (n + 2.0 * H4);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = n; }
+  }
+  return best;
+}
+
+// host: Conv1d weight w[C][C][KS] -> [tap][rb][q][lane][e]: row rb*16 + (lane & 15), channel (4*q + e)*4 + (lane >> 4)
+inline void rb_fused_pack(float* dst, const float* w, int C, int KS) {
+  const int RB = C / 16, Q = C / 16;
+  for (int tap = 0; tap < KS; ++tap)
+    for (int rb = 0; rb < RB; ++rb)
+      for (int q = 0; q < Q; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int row = rb * 16 + (lane & 15), ch = (4 * q + e) * 4 + (lane >> 4);
+            dst[((((size_t)tap * RB + rb) * Q + q) * 64 + lane) * 4 + e] = w[((size_t)row * C + ch) * KS + tap];
+          }
+}
+inline size_t rb_fused_floats(int C, int KS) { return (size_t)KS * C * C; }
+
+template <int C, int KS>
+__global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int RB = C / 16, Q = C / 16, CG = C / 4, P = RbGeom<C>::P, KH = (KS - 1) / 2, NA4 = KS * Q;
+  // a wave holds the weights of ONE 16-row block (C = 32: waves 0, 2 the rows 0-15, waves 1, 3 the rows 16-31; a unit is then computed by a pair
+  // of waves, each reading the same B values) -- both row blocks of k = 11 would be 176 registers per lane and spill
+  constexpr int UW = 4 / RB;                       // waves that share a row block = unit stride
+  constexpr bool PREF = NA4 * 4 <= 64;           // small weight sets: the NEXT conv's weights are requested while this conv computes
+  __shared__ float sx[C * P + 128];              // running x (raw)
+  __shared__ float st[C * P + 128];              // the pair's intermediate, stored leaky-relu'd (only c2 reads it)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, lk = lane >> 4;
+  const int rb = RB == 1 ? 0 : (wave & (RB - 1)), uw = wave / RB;      // this wave's row block; its first unit
+  const int item = blockIdx.x / a.tiles_per_item, t0 = (blockIdx.x - item * a.tiles_per_item) * a.N;
+  // (scalars, not the argument struct's arrays: indexing those -- even with unrolled constants -- made hipcc keep the struct in scratch memory)
+  const int d1_[kRbPairs] = {a.d1[0], a.d1[1], a.d1[2]}, d2_[kRbPairs] = {a.d2[0], a.d2[1], a.d2[2]};
+  const int H = KH * (d1_[0] + d1_[1] + d1_[2] + d2_[0] + d2_[1] + d2_[2]);
+  const int H4 = (H + 3) & ~3, N = a.N, W = N + 2 * H4, g0 = t0 - H4;     // local column u <-> global column g0 + u
+  const float slope = a.slope;
+
+  // ---- weights of a conv: NA4 float4 per lane, fragment order
+  auto load_w = [&](f4 (&A)[NA4], int conv) __attribute__((always_inline)) {
+    const f4* src = reinterpret_cast<const f4*>(a.W) + (size_t)conv * (KS * RB * Q * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) A[i] = src[(size_t)(((i / Q) * RB + rb) * Q + (i % Q)) * 64];   // i = tap * Q + q
+  };
+  f4 A0[NA4], A1[PREF ? NA4 : 1];
+  load_w(A0, 0);
+
+  // ---- the window: x[C][W] -> LDS, zero outside [0, L)
+  {
+    const int w4 = W >> 2;
+    const float* Xb = a.X + item * a.x_bs;
+    for (int idx = tid; idx < C * w4; idx += 256) {
+      const int c = idx / w4, g = idx - c * w4, gt = g0 + 4 * g;
+      f4 v{0.f, 0.f, 0.f, 0.f};
+      const float* p = Xb + (long)c * a.ldx + gt;
+      if (gt >= 0 && gt + 3 < a.L) v = *reinterpret_cast<const f4*>(p);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gt + e >= 0 && gt + e < a.L) v[e] = p[e];
+      }
+      *reinterpret_cast<f4*>(sx + c * P + 4 * g) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- one conv over local columns [lo, hi): src -> (epilogue)
+  //   IS_C2 = false: st = lrelu(conv(lrelu(sx)) + b)            IS_C2 = true, !LAST: sx = conv(st) + b + sx
+  //   LAST: out (global) = conv(st) + b + sx under a.mode, owned columns only
+  // (always_inline: called three times per instantiation; out of line, the weight array it takes by reference would live in scratch memory)
+  auto conv_pass = [&](auto IS_C2_, auto LAST_, const f4 (&A)[NA4], int conv, int dil, int lo, int hi) __attribute__((always_inline)) {
+    constexpr bool IS_C2 = decltype(IS_C2_)::value, LAST = decltype(LAST_)::value;
+    const float* src = IS_C2 ? st : sx;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = a.bias[conv * C + rb * 16 + 4 * lk + r];
+    const int n_units = (hi - lo + 31) >> 5;
+    for (int unit = uw; unit < n_units; unit += UW) {
+      const int u0 = lo + 32 * unit;
+      f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      // K loop, tap-major: the B values of tap + 1 (CG x 2 LDS reads) are requested before the MFMAs of tap issue -- left to itself hipcc put
+      // every ds_read directly in front of its MFMA behind an lgkmcnt(0), i.e. one exposed LDS round trip per MFMA pair
+      const float* bp = src + lk * P + u0 + lj - KH * dil;
+      float bq[2][CG][2];
+      auto rd = [&](int buf, const float* p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { bq[buf][cg][0] = p[cg * 4 * P]; bq[buf][cg][1] = p[cg * 4 * P + 16]; }
+      };
+      rd(0, bp);
+#pragma unroll
+      for (int tap = 0; tap < KS; ++tap) {
+        if (tap + 1 < KS) rd((tap + 1) & 1, bp + (tap + 1) * dil);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+          float b0 = bq[tap & 1][cg][0], b1 = bq[tap & 1][cg][1];
+          if constexpr (!IS_C2) {      // leaky-relu on the operand: max(x, slope x) == the per-conv kernels' select for slope < 1
+            b0 = __builtin_fmaxf(b0, b0 * slope);
+            b1 = __builtin_fmaxf(b1, b1 * slope);
+          }
+          const float av = A[tap * Q + (cg >> 2)][cg & 3];
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // epilogue: lane holds rows rb*16 + 4*lk + r of column u0 + 16*m + lj
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int u = u0 + 16 * m + lj, gt = g0 + u;
+        const bool inside = gt >= 0 && gt < a.L;
+        if (u >= hi) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = rb * 16 + 4 * lk + r;
+            float v = acc[m][r] + bias[r];
+            if constexpr (!IS_C2) {
+              v = v > 0.f ? v : v * slope;
+              st[row * P + u] = inside ? v : 0.f;
+            } else if constexpr (!LAST) {
+              v = v + sx[row * P + u];
+              sx[row * P + u] = inside ? v : 0.f;
+            } else {
+              if (inside) {
+                v = v + sx[row * P + u];
+                float* o = a.out + item * a.o_bs + (long)row * a.ldo + gt;
+                if (a.mode == 1) v = *o + v;
+                else if (a.mode == 2) v = (*o + v) / a.div;
+                __builtin_nontemporal_store(v, o);
+              }
+            }
+          }
+      }
+    }
+  };
+
+  int rem = H;
+  auto run_pair = [&](auto J_) __attribute__((always_inline)) {
+    constexpr int j = decltype(J_)::value;
+    // c1_j
+    rem -= KH * d1_[j];
+    if constexpr (PREF) load_w(A1, 2 * j + 1);
+    conv_pass(std::false_type{}, std::false_type{}, A0, 2 * j, d1_[j], H4 - rem, H4 + N + rem);
+    if constexpr (!PREF) load_w(A0, 2 * j + 1);
+    __syncthreads();
+    // c2_j
+    rem -= KH * d2_[j];
+    if constexpr (PREF) {
+      if constexpr (j + 1 < kRbPairs) load_w(A0, 2 * j + 2);
+      conv_pass(std::true_type{}, std::integral_constant<bool, j + 1 == kRbPairs>{}, A1, 2 * j + 1, d2_[j], H4 - rem, H4 + N + rem);
+    } else {
+      conv_pass(std::true_type{}, std::integral_constant<bool, j + 1 == kRbPairs>{}, A0, 2 * j + 1, d2_[j], H4 - rem, H4 + N + rem);
+      if constexpr (j + 1 < kRbPairs) load_w(A0, 2 * j + 2);
+    }
+    if constexpr (j + 1 < kRbPairs) __syncthreads();
+  };
+  run_pair(std::integral_constant<int, 0>{});
+  run_pair(std::integral_constant<int, 1>{});
+  run_pair(std::integral_constant<int, 2>{});
+}
+
+// true if a fused instantiation exists for (C, KS) and the geometry fits
+inline bool rb_fused_supported(int C, int KS) { return (C == 16 || C == 32) && (KS == 3 || KS == 7 || KS == 11); }
+
+inline hipError_t launch_resblock1_fused(int C, int KS, RbFusedArgs a, int B, hipStream_t s) {
+  const int H = rb_halo(KS, a.d1, a.d2), H4 = (H + 3) & ~3;
+  a.N = rb_pick_n(C, H4, a.L, B);
+  if (a.N <= 0) return hipErrorInvalidValue;
+  a.tiles_per_item = (a.L + a.N - 1) / a.N;
+  const dim3 grid((unsigned)(B * a.tiles_per_item)), blk(256);
+#define FDX_RB(C_, K_) if (C == C_ && KS == K_) { hipLaunchKernelGGL((k_resblock1_fused<C_, K_>), grid, blk, 0, s, a); return hipGetLastError(); }
+  FDX_RB(16, 3) FDX_RB(16, 7) FDX_RB(16, 11) FDX_RB(32, 3) FDX_RB(32, 7) FDX_RB(32, 11)
+#undef FDX_RB
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fdx

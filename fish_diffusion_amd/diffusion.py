@@ -76,6 +76,7 @@ class GaussianDiffusion(nn.Module):
         # "philox": drawn on the device inside the loop by the library's own Philox -- perf mode.
         self.step_rng = "torch"
         self.naive_noise_chunk_bytes = 128 << 20
+        self._table_cache = {}
 
     # ------------------------------------------------------------------ small reference helpers
     def norm_spec(self, x):
@@ -178,6 +179,37 @@ class GaussianDiffusion(nn.Module):
     p_losses = train_step
 
     # ------------------------------------------------------------------ sampling
+    _NAIVE_BUFFERS = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+                      "posterior_log_variance_clipped", "clip_min", "clip_max")
+
+    def _sampler_table(self, noise_predictor: str, interval: int, skip_steps: int):
+        """(kind, rows) of the update rule.  The DDPM / PLMS coefficients come from the predictor modules' BUFFERS -- in the reference they
+        are `register_buffer`s (noise_predictor.py:29-71,115), so a checkpoint whose buffers differ from what its config would compute
+        samples with the checkpoint's values; UniPC's NoiseScheduleVP is a plain object built from the constructor's betas
+        (noise_predictor.py:151-158), hence from `self._sched`.  Cached per (buffer identity, version)."""
+        if noise_predictor == "unipc":
+            kind, table = schedule.sampler_table(noise_predictor, interval=interval, skip_steps=skip_steps, **self._sched)
+            return kind, np.ascontiguousarray(table, dtype=np.float32)
+        mod = self.naive_noise_predictor if noise_predictor == "naive" else self.plms_noise_predictor
+        names = self._NAIVE_BUFFERS if noise_predictor == "naive" else ("alphas_cumprod",)
+        bufs = {n: getattr(mod, n) for n in names}
+        key = (noise_predictor, int(interval), int(skip_steps), tuple((b.data_ptr(), b._version, b.device) for b in bufs.values()))
+        hit = self._table_cache.get(key)
+        if hit is None:
+            cpu = {n: b.detach().to("cpu", torch.float32) for n, b in bufs.items()}
+            n_t = int(next(iter(cpu.values())).shape[0]) if noise_predictor == "plms" else int(cpu["posterior_mean_coef1"].shape[0])
+            if n_t != self.num_timesteps:
+                raise ValueError(f"{noise_predictor} predictor buffers hold {n_t} timesteps, the diffusion was built with {self.num_timesteps}")
+            chunks = schedule.timestep_chunks(self.num_timesteps, skip_steps, interval)
+            if noise_predictor == "naive":
+                table = schedule.naive_table_from_buffers(cpu, chunks)
+            else:
+                table = schedule.plms_table_from_buffers(cpu["alphas_cumprod"], chunks, interval)
+            if len(self._table_cache) > 32:
+                self._table_cache.clear()
+            hit = self._table_cache[key] = np.ascontiguousarray(table, dtype=np.float32)
+        return schedule.KINDS[noise_predictor], hit
+
     @torch.no_grad()
     def forward(self, features, sampler_interval=None, progress: bool = False, skip_steps: int = 0,
                 original_mel: Optional[torch.Tensor] = None, noise_predictor: Optional[str] = None,
@@ -224,14 +256,8 @@ class GaussianDiffusion(nn.Module):
         if (B, M, T) != (cond.shape[0], self.mel_bins, cond.shape[2]):
             raise ValueError(f"x_T {tuple(x.shape)} does not match features {tuple(features.shape)} / mel_channels {self.mel_bins}")
 
-        kind, table = schedule.sampler_table(noise_predictor, interval=sampler_interval, skip_steps=skip_steps,
-                                             **self._sched)
+        kind, table = self._sampler_table(noise_predictor, sampler_interval, skip_steps)
         n_rows = table.shape[0]
-        table = np.ascontiguousarray(table, dtype=np.float32)
-        if kind == _lib.SAMPLER_NAIVE:   # the clamp bounds are loadable buffers in the reference (noise_predictor.py:30-31,90)
-            table = table.copy()
-            table[:, 6] = float(self.naive_noise_predictor.clip_min)
-            table[:, 7] = float(self.naive_noise_predictor.clip_max)
         if step_noise is not None:
             step_noise = step_noise.to(torch.float32).contiguous()
             if kind == _lib.SAMPLER_NAIVE and tuple(step_noise.shape) != (n_rows, B, M, T):

@@ -41,26 +41,40 @@ def timestep_chunks(timesteps: int, skip_steps: int, interval: int):
 
 
 # ------------------------------------------------------------------ naive (DDPM ancestral)
-def naive_table(betas: np.ndarray, chunks) -> np.ndarray:
+def naive_buffers(betas: np.ndarray) -> dict:
+    """The fp32 buffers NaiveNoisePredictor registers (noise_predictor.py:29-71), from float64 numpy like the reference."""
     alphas = 1.0 - betas
     acp = np.cumprod(alphas, axis=0)
     acp_prev = np.append(1.0, acp[:-1])
-    sr, srm1 = _f32(np.sqrt(1.0 / acp)), _f32(np.sqrt(1.0 / acp - 1))
     var = betas * (1.0 - acp_prev) / (1.0 - acp)
-    logvar = _f32(np.log(np.maximum(var, 1e-20)))
-    c1 = _f32(betas * np.sqrt(acp_prev) / (1.0 - acp))
-    c2 = _f32((1.0 - acp_prev) * np.sqrt(alphas) / (1.0 - acp))
+    return dict(sqrt_recip_alphas_cumprod=_f32(np.sqrt(1.0 / acp)), sqrt_recipm1_alphas_cumprod=_f32(np.sqrt(1.0 / acp - 1)),
+                posterior_log_variance_clipped=_f32(np.log(np.maximum(var, 1e-20))),
+                posterior_mean_coef1=_f32(betas * np.sqrt(acp_prev) / (1.0 - acp)),
+                posterior_mean_coef2=_f32((1.0 - acp_prev) * np.sqrt(alphas) / (1.0 - acp)), clip_min=_f32(-1.0), clip_max=_f32(1.0))
+
+
+def naive_table_from_buffers(buf: dict, chunks) -> np.ndarray:
+    """Rows of the DDPM update rule from the predictor's BUFFERS -- in the reference they are `register_buffer`s, i.e. whatever the
+    checkpoint holds is what sampling uses (noise_predictor.py:73-104): x0 = sr[t] x - srm1[t] eps, clamp(clip_min, clip_max),
+    mean = c1[t] x0 + c2[t] x, + (t > 0) exp(0.5 logvar[t]) noise.  One-element fp32 tensor ops, as the reference evaluates them."""
+    sr, srm1 = buf["sqrt_recip_alphas_cumprod"], buf["sqrt_recipm1_alphas_cumprod"]
+    c1, c2, logvar = buf["posterior_mean_coef1"], buf["posterior_mean_coef2"], buf["posterior_log_variance_clipped"]
+    lo, hi = float(buf["clip_min"]), float(buf["clip_max"])
     tab = np.zeros((len(chunks), FDX_ROW), np.float32)
     for r, t in enumerate(chunks):
         nonzero = torch.tensor(1.0 if t > 0 else 0.0)
         scale = nonzero * (0.5 * logvar[t]).exp()  # noise_predictor.py:102-104
-        tab[r, :8] = [float(v) for v in (t, sr[t], srm1[t], c1[t], c2[t], scale, -1.0, 1.0)]   # [6:8] = clip_min / clip_max (:30-31)
+        tab[r, :8] = [float(v) for v in (t, sr[t], srm1[t], c1[t], c2[t], scale, lo, hi)]
     return tab
 
 
+def naive_table(betas: np.ndarray, chunks) -> np.ndarray:
+    return naive_table_from_buffers(naive_buffers(betas), chunks)
+
+
 # ------------------------------------------------------------------ PLMS
-def plms_table(betas: np.ndarray, chunks, interval: int) -> np.ndarray:
-    acp = _f32(np.cumprod(1.0 - betas, axis=0))
+def plms_table_from_buffers(acp: torch.Tensor, chunks, interval: int) -> np.ndarray:
+    """noise_predictor.py:118-131 from the predictor's `alphas_cumprod` BUFFER (fp32)."""
     tab = np.zeros((len(chunks), FDX_ROW), np.float32)
     for r, t in enumerate(chunks):
         tp = max(t - interval, 0)  # diffusion.py:280-281
@@ -71,6 +85,10 @@ def plms_table(betas: np.ndarray, chunks, interval: int) -> np.ndarray:
         Q = 1 / (a_t_sq * (((1 - a_prev) * a_t).sqrt() + ((1 - a_t) * a_prev).sqrt()))
         tab[r, :5] = [float(v) for v in (t, tp, A, P, Q)]
     return tab
+
+
+def plms_table(betas: np.ndarray, chunks, interval: int) -> np.ndarray:
+    return plms_table_from_buffers(_f32(np.cumprod(1.0 - betas, axis=0)), chunks, interval)
 
 
 # ------------------------------------------------------------------ UniPC (bh2, order 2, multistep, time_uniform)

@@ -53,7 +53,7 @@ def save(name, **arrays):
 # which make_golden section writes which fixture (prefix match), for tests/golden/MANIFEST.json
 FIXTURE_SECTIONS = (("convnext_cross", "convnext_cross"), ("convnext", "convnext"), ("frontend_expand", "frontend_expand"), ("frontend_svs", "frontend_svs"),
                     ("tfdec", "tfdec"), ("refinegan_sine", "refinegan_sine"), ("nsf_v1_256_full", "round2"), ("chain_c1", "round2"), ("chain_c2", "round2"),
-                    ("chain_", "round3"), ("ddpm1000_", "round3"))
+                    ("chain_", "round3"), ("ddpm1000_", "round3"), ("sampler_buffers", "round4"), ("svc_caller", "round4"))
 
 
 def write_manifest():
@@ -663,6 +663,159 @@ def golden_round3(R):
 
 
 @torch.no_grad()
+@torch.no_grad()
+def golden_round4(R):
+    """Round-4 fixtures.
+    (a) sampler_buffers: in the reference the DDPM / PLMS coefficients are `register_buffer`s of the predictor modules
+        (noise_predictor.py:29-71,115) -- what a checkpoint holds is what sampling uses.  A real `GaussianDiffusion` whose predictor
+        buffers were overwritten (as `load_state_dict` would) runs the naive and PLMS samplers; the fixture holds the buffers and the
+        reference's mels.  The oracle takes the same buffers (`naive_buffers=`, `plms_alphas_cumprod=`) and must equal the reference.
+    (b) svc_caller: the reference's own caller, `SVCInference.forward` (tools/diffusion/inference.py:86-162), run HERE over the reference's
+        own modules with stub extractors: reference front end (`DiffSinger.forward_features`), `GaussianDiffusion` + `WaveNet`, the NSF-HiFiGAN
+        `Generator` behind `spec2wav`'s three scalar lines (nsf_hifigan.py:72-85), an `ema_model` whose weights differ from `model`'s.  The
+        fixture holds the stub extractors' outputs and the waveform; `tests/golden/svc_inference_forward.json` holds the SOURCE TEXT of
+        that one method (with the file's SHA-256 and line range) so that the GPU box -- which has no reference tree -- can run the same
+        body over the installed MI355X modules.  Test infrastructure only: nothing in the product reads it.
+    """
+    import ast
+    import hashlib as _hl
+    from typing import Optional as _Optional
+    print("round 4: sampler coefficient buffers as a checkpoint holds them")
+    cfg = WN_SMALL
+    sd = wavenet_ref.seeded_wavenet_state(77, **{k: v for k, v in cfg.items() if k != "dilation_cycle"})
+    diff = build_ref_diffusion(R, cfg, sd)
+    nb = diff.naive_noise_predictor
+    nb.posterior_mean_coef1.mul_(1.03)
+    nb.sqrt_recipm1_alphas_cumprod.mul_(0.98)
+    nb.posterior_log_variance_clipped.add_(0.2)
+    nb.clip_min.fill_(-0.9)
+    nb.clip_max.fill_(0.8)
+    diff.plms_noise_predictor.alphas_cumprod.pow_(1.05)
+    den = oracle_denoiser(sd, cfg)
+    B, T, interval = 2, 60, 50
+    feats = torch.randn(B, T, 256, generator=torch.Generator().manual_seed(771))
+    torch.manual_seed(772)
+    mel_naive = diff(feats, sampler_interval=interval, noise_predictor="naive")
+    x_naive, step_noise = sampler_ref.ddpm_noise(772, B, 128, T, 1000 // interval)
+    nbuf = {k: v.clone() for k, v in nb.state_dict().items()}
+    mine = sampler_ref.diffusion_sample(den, feats, x_init=x_naive, sampler_interval=interval, predictor="naive", step_noise=step_noise, naive_buffers=nbuf)
+    assert torch.equal(mine, mel_naive), "oracle naive sampler with loaded buffers != reference"
+    plain = sampler_ref.diffusion_sample(den, feats, x_init=x_naive, sampler_interval=interval, predictor="naive", step_noise=step_noise)
+    assert not torch.equal(plain, mel_naive), "the perturbed buffers must change the result"
+    torch.manual_seed(773)
+    mel_plms = diff(feats, sampler_interval=interval, noise_predictor="plms")
+    torch.manual_seed(773)
+    x_plms = torch.randn(B, 128, T)
+    acp = diff.plms_noise_predictor.alphas_cumprod.clone()
+    mine = sampler_ref.diffusion_sample(den, feats, x_init=x_plms, sampler_interval=interval, predictor="plms", plms_alphas_cumprod=acp)
+    assert torch.equal(mine, mel_plms), "oracle PLMS sampler with a loaded alphas_cumprod != reference"
+    print(f"  perturbed vs schedule-derived coefficients: naive mel differs by {float((plain - mel_naive).abs().max()):.3f}")
+    save("sampler_buffers", features=feats, x_naive=x_naive, step_noise=step_noise, x_plms=x_plms, mel_naive=mel_naive, mel_plms=mel_plms,
+         interval=np.int64(interval), weights_seed=np.int64(77), weights_sha1=np.array(state_sha1(sd)), plms_alphas_cumprod=acp,
+         **{"naive:" + k: v for k, v in nbuf.items()})
+
+    print("round 4: SVCInference.forward (the reference's caller) over the reference's modules")
+    path = os.path.join(_ref_import.REFERENCE_ROOT, "tools/diffusion/inference.py")
+    with open(path) as f:
+        text = f.read()
+    tree = ast.parse(text)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "SVCInference")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward")
+    first = min([fn.lineno] + [d.lineno for d in fn.decorator_list])
+    lines = text.splitlines()[first - 1:fn.end_lineno]
+    indent = len(lines[0]) - len(lines[0].lstrip())
+    source = "\n".join(ln[indent:] for ln in lines) + "\n"
+    with open(os.path.join(GOLD, "svc_inference_forward.json"), "w") as f:
+        json.dump({"what": "source text of ONE method of the reference, `SVCInference.forward`, extracted by oracle/make_golden.py round4 so that the GPU box "
+                           "(no reference tree) can run the reference's own caller body over the installed MI355X modules; test infrastructure only",
+                   "reference_file": "tools/diffusion/inference.py", "lines": [first, fn.end_lineno],
+                   "file_sha256": _hl.sha256(text.encode()).hexdigest(), "source": source}, f, indent=1)
+    ns = {"torch": torch, "np": np, "Optional": _Optional, "repeat_expand": R["repeat_expand"]}
+    exec(compile(source, path, "exec"), ns)
+    fwd = ns["forward"]
+
+    wcfg = WN_SMALL
+    fe_model, fe_ema = features_ref.seeded_frontend_state(81), features_ref.seeded_frontend_state(82)
+    wn_model = wavenet_ref.seeded_wavenet_state(83, **{k: v for k, v in wcfg.items() if k != "dilation_cycle"})
+    wn_ema = wavenet_ref.seeded_wavenet_state(84, **{k: v for k, v in wcfg.items() if k != "dilation_cycle"})
+    hv = nsf_hifigan_ref.CONFIG_V1
+    vsd = nsf_hifigan_ref.seeded_generator_state(85, hv)
+    gen = R["Generator"](R["AttrDict"](hv))
+    gen.remove_weight_norm()
+    gen.eval()
+    gen.load_state_dict(vsd, strict=True)
+
+    def ref_diffsinger(fe_sd, wn_sd):
+        m = _ref_frontend(R, fe_sd)
+        m.diffusion = build_ref_diffusion(R, wcfg, wn_sd)
+        return m.eval()
+
+    class RefVocoder:                       # nsf_hifigan.py:72-85 around the real Generator (the wrapper class itself imports lightning)
+        use_natural_log = False
+
+        def spec2wav(self, mel, f0, key_shift=0):
+            c = mel[None]
+            if key_shift is not None and key_shift != 0:
+                f0 *= 2 ** (key_shift / 12)
+            if self.use_natural_log is False:
+                c = 2.30259 * c
+            f0 = f0[None].to(c.dtype)
+            return gen(c, f0).view(-1)
+
+    class Lightning:                        # what load_checkpoint returns there: .model, .ema_model, .vocoder
+        pass
+
+    class ModelCfg(dict):
+        pass
+
+    class Holder(torch.nn.Module):          # the attributes SVCInference.forward touches
+        forward = fwd
+
+        def __init__(self, text_features, pitches):
+            super().__init__()
+            self.anchor = torch.nn.Parameter(torch.zeros(1))      # `self.device` = next(self.parameters()).device
+            self.config = type("Cfg", (), {"model": ModelCfg()})()
+            self.model = Lightning()
+            self.model.model = ref_diffsinger(fe_model, wn_model)
+            self.model.ema_model = ref_diffsinger(fe_ema, wn_ema)
+            self.model.vocoder = RefVocoder()
+            self.text_features_extractor = lambda audio, sr: text_features.clone()
+            self.pitch_extractor = lambda audio, sr, pad_to=None: pitches[:pad_to].clone()
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    T, S = 70, 112
+    g = torch.Generator().manual_seed(86)
+    text_features = torch.randn(1, 256, S, generator=g)           # an extractor at ~50 frames/s; forward() nearest-expands it to mel_len
+    pitches = synth_f0(T)
+    audio = torch.zeros(1, T * 512 + 100)                          # only its length is read by the caller (mel_len = n // 512)
+    holder = Holder(text_features, pitches).eval()
+    torch.manual_seed(87)
+    wav = holder(audio, 44100, pitch_adjust=2, speakers=torch.tensor([3]), sampler_interval=50)
+    wav = torch.from_numpy(np.asarray(wav))
+    torch.manual_seed(87)
+    wav_again = torch.from_numpy(np.asarray(holder(audio, 44100, pitch_adjust=2, speakers=torch.tensor([3]), sampler_interval=50)))
+    assert torch.equal(wav, wav_again) and wav.shape == (T * 512,)
+    # the same chain through the oracle: front end (EMA weights) -> 20-step UniPC -> vocoder, draws regenerated in the reference's order
+    torch.manual_seed(87)
+    x_T = torch.randn(1, 128, T)
+    rand_ini = torch.rand(1, 9)
+    rand_ini[:, 0] = 0
+    src_noise = torch.randn(1, T * 512, 9)
+    f0 = pitches * 2 ** (2 / 12)
+    contents = features_ref.repeat_expand(text_features[0], T).T[None]
+    feats = features_ref.forward_features(fe_ema, contents, speakers=torch.tensor([3]), pitches=f0[None], mel_lens=torch.tensor([T]))["features"]
+    mel = sampler_ref.diffusion_sample(oracle_denoiser(wn_ema, wcfg), feats, x_init=x_T, sampler_interval=50)
+    mine = nsf_hifigan_ref.generator_forward(vsd, hv, 2.30259 * mel[0].T[None], f0[None], rand_ini, src_noise).view(-1)
+    assert torch.equal(mine, wav), f"oracle chain != SVCInference.forward over the reference modules ({float((mine - wav).abs().max()):.3e})"
+    save("svc_caller", text_features=text_features, pitches=pitches, n_audio=np.int64(audio.shape[-1]), speaker=np.int64(3), pitch_adjust=np.int64(2),
+         sampler_interval=np.int64(50), noise_seed=np.int64(87), wav=wav, mel=mel,
+         seeds=np.array([81, 82, 83, 84, 85], dtype=np.int64),
+         sha1=np.array([state_sha1(fe_model), state_sha1(fe_ema), state_sha1(wn_model), state_sha1(wn_ema), state_sha1(vsd)]))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     R = _ref_import.load()
@@ -967,6 +1120,7 @@ def main():
     golden_refinegan_sine(R)
     golden_frontend_svs(R)
     golden_round3(R)
+    golden_round4(R)
 
     write_manifest()
     print("done")
@@ -974,7 +1128,7 @@ def main():
 
 if __name__ == "__main__":
     SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2, "convnext_cross": golden_convnext_cross, "refinegan_sine": golden_refinegan_sine,
-                "frontend_svs": golden_frontend_svs, "round3": golden_round3}
+                "frontend_svs": golden_frontend_svs, "round3": golden_round3, "round4": golden_round4}
     if len(sys.argv) == 2 and sys.argv[1] == "manifest":   # re-index the fixtures on disk (no reference needed)
         write_manifest()
     elif len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only

@@ -43,7 +43,8 @@ def f32(a) -> torch.Tensor:
 
 # ------------------------------------------------------------------ naive (DDPM ancestral)
 class NaiveTables:
-    """noise_predictor.py:29-71 -- float64 numpy, cast to fp32 tensors."""
+    """noise_predictor.py:29-71 -- float64 numpy, cast to fp32 tensors.  In the reference these are `register_buffer`s: `from_buffers`
+    takes them as a (loaded) state dict of NaiveNoisePredictor instead of recomputing them from the betas."""
 
     def __init__(self, betas: np.ndarray):
         alphas = 1.0 - betas
@@ -55,12 +56,22 @@ class NaiveTables:
         self.logvar = f32(np.log(np.maximum(var, 1e-20)))
         self.coef1 = f32(betas * np.sqrt(ac_prev) / (1.0 - ac))
         self.coef2 = f32((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac))
+        self.clip_min, self.clip_max = -1.0, 1.0
+
+    @classmethod
+    def from_buffers(cls, sd: dict) -> "NaiveTables":
+        self = cls.__new__(cls)
+        self.sqrt_recip, self.sqrt_recipm1 = sd["sqrt_recip_alphas_cumprod"].float(), sd["sqrt_recipm1_alphas_cumprod"].float()
+        self.logvar = sd["posterior_log_variance_clipped"].float()
+        self.coef1, self.coef2 = sd["posterior_mean_coef1"].float(), sd["posterior_mean_coef2"].float()
+        self.clip_min, self.clip_max = float(sd["clip_min"]), float(sd["clip_max"])
+        return self
 
 
 def naive_step(tb: NaiveTables, x, t: int, eps, noise):
     """noise_predictor.py:73-104."""
     x0 = tb.sqrt_recip[t] * x - tb.sqrt_recipm1[t] * eps
-    x0 = torch.clamp(x0, min=-1.0, max=1.0)
+    x0 = torch.clamp(x0, min=tb.clip_min, max=tb.clip_max)
     mean = tb.coef1[t] * x0 + tb.coef2[t] * x
     nonzero = 1.0 if t > 0 else 0.0
     return mean + nonzero * (0.5 * tb.logvar[t]).exp() * noise
@@ -201,12 +212,15 @@ def diffusion_sample(denoise: Callable, features: torch.Tensor, *, x_init: torch
                      sampler_interval=10, predictor: Optional[str] = None, step_noise: Optional[torch.Tensor] = None,
                      noise_schedule="linear", timesteps=1000, max_beta=0.01, s=0.008,
                      spec_min=(-5.0,), spec_max=(0.0,), skip_steps=0,
-                     x_masks=None, cond_masks=None, trace: Optional[list] = None) -> torch.Tensor:
+                     x_masks=None, cond_masks=None, trace: Optional[list] = None,
+                     naive_buffers: Optional[dict] = None, plms_alphas_cumprod: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GaussianDiffusion.forward (diffusion.py:196-313).
 
     features [B,T,E]; x_init [B,M,T] is the tensor the reference would hold right before the loop
     (randn at :222, or q_sample(norm_spec(original_mel)) at :223-232 -- build it with ``q_sample``);
     step_noise [n_steps,B,M,T] for the naive predictor.  Returns mel [B,T,M].
+    `naive_buffers` / `plms_alphas_cumprod`: the predictor modules' buffers as a checkpoint holds them (noise_predictor.py:29-71,115);
+    default: computed from the schedule, as the constructors do.
     """
     betas = beta_schedule(noise_schedule, timesteps, max_beta, s)
     if predictor is None:
@@ -227,7 +241,7 @@ def diffusion_sample(denoise: Callable, features: torch.Tensor, *, x_init: torch
         return eps
 
     if predictor == "naive":
-        tb = NaiveTables(betas)
+        tb = NaiveTables(betas) if naive_buffers is None else NaiveTables.from_buffers(naive_buffers)
         for i, t in enumerate(chunks):
             eps = call(x, t)
             x = naive_step(tb, x, t, eps, step_noise[i])
@@ -235,7 +249,7 @@ def diffusion_sample(denoise: Callable, features: torch.Tensor, *, x_init: torch
         steps = timesteps // sampler_interval  # noise_predictor.py:187 (total_N, NOT timesteps-skip_steps)
         x = unipc_sample(lambda xx, t: denoise(xx, t, cond, x_masks, cond_masks), x, betas, steps, trace)
     elif predictor == "plms":
-        ac = f32(np.cumprod(1.0 - betas, axis=0))
+        ac = f32(np.cumprod(1.0 - betas, axis=0)) if plms_alphas_cumprod is None else plms_alphas_cumprod.float()
         hist: List[torch.Tensor] = []
         for t in chunks:
             eps = call(x, t)
