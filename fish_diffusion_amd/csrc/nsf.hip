@@ -98,7 +98,7 @@ static void nsf_layout(const fdx_nsf_desc& d, NsfLayout& l) {
   // fused ResBlock1 weights of the small-channel stages (behind everything else: the offsets above do not move)
   for (int i = 0; i < d.n_stages; ++i) {
     NsfStage& st = l.stages[i];
-    st.fused = d.resblock_type == 1 && d.n_dilations == kRbPairs;
+    st.fused = d.resblock_type == 1 && d.n_dilations == kRbPairs && rb_fused_wins(st.cout);
     for (int j = 0; j < d.n_resblock_kernels; ++j) st.fused = st.fused && rb_fused_supported(st.cout, d.resblock_kernel_sizes[j]);
     st.fw.clear(); st.fb.clear();
     if (!st.fused) continue;

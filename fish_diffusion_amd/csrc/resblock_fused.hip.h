@@ -24,6 +24,10 @@
 
 #include "common.hip.h"
 
+#ifndef FDX_RB_EXP
+#define FDX_RB_EXP 0     // timing experiments of tools/ubench/rbfused.hip (results wrong): 1 no leaky-relu, 2 no epilogue, 4 no LDS reads in the K loop
+#endif
+
 namespace fdx {
 
 constexpr int kRbPairs = 3;   // (c1, c2) pairs per ResBlock1: the shipped configs' [1, 3, 5]
@@ -37,6 +41,7 @@ struct RbFusedArgs {
   int d1[kRbPairs], d2[kRbPairs];         // dilations of c1_j / c2_j
   float slope;
   int mode; float div;                    // output: 0: out = v   1: out += v   2: out = (out + v) / div   (EpiResblock's modes)
+  unsigned long long* trace;              // FDX_RB_TRACE builds (tools/ubench/rbfused.hip): 9 shader-clock stamps per wave, else unused
 };
 
 template <int C> struct RbGeom {
@@ -77,13 +82,15 @@ inline void rb_fused_pack(float* dst, const float* w, int C, int KS) {
 }
 inline size_t rb_fused_floats(int C, int KS) { return (size_t)KS * C * C; }
 
+constexpr int kRbWaves = 8;   // waves per workgroup: two per SIMD -- with one, nothing hides a wave's LDS reads / epilogue / address arithmetic (measured additive)
+
 template <int C, int KS>
-__global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
+__global__ __launch_bounds__(kRbWaves * 64) void k_resblock1_fused(RbFusedArgs a) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   constexpr int RB = C / 16, Q = C / 16, CG = C / 4, P = RbGeom<C>::P, KH = (KS - 1) / 2, NA4 = KS * Q;
   // a wave holds the weights of ONE 16-row block (C = 32: waves 0, 2 the rows 0-15, waves 1, 3 the rows 16-31; a unit is then computed by a pair
   // of waves, each reading the same B values) -- both row blocks of k = 11 would be 176 registers per lane and spill
-  constexpr int UW = 4 / RB;                       // waves that share a row block = unit stride
+  constexpr int UW = kRbWaves / RB, NT = kRbWaves * 64;   // waves that share a row block = unit stride; threads
   constexpr bool PREF = NA4 * 4 <= 64;           // small weight sets: the NEXT conv's weights are requested while this conv computes
   __shared__ float sx[C * P + 128];              // running x (raw)
   __shared__ float st[C * P + 128];              // the pair's intermediate, stored leaky-relu'd (only c2 reads it)
@@ -97,6 +104,14 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
   const int H = KH * (d1_[0] + d1_[1] + d1_[2] + d2_[0] + d2_[1] + d2_[2]);
   const int H4 = (H + 3) & ~3, N = a.N, W = N + 2 * H4, g0 = t0 - H4;     // local column u <-> global column g0 + u
   const float slope = a.slope;
+#ifdef FDX_RB_TRACE
+  unsigned long long stamps[9];
+  int n_st = 0;
+#define RB_STAMP() stamps[n_st++] = __builtin_amdgcn_s_memtime()
+#else
+#define RB_STAMP() do { } while (0)
+#endif
+  RB_STAMP();
 
   // ---- weights of a conv: NA4 float4 per lane, fragment order
   auto load_w = [&](f4 (&A)[NA4], int conv) __attribute__((always_inline)) {
@@ -107,24 +122,32 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
   f4 A0[NA4], A1[PREF ? NA4 : 1];
   load_w(A0, 0);
 
-  // ---- the window: x[C][W] -> LDS, zero outside [0, L)
+  // ---- the window: x[C][W] -> LDS, zero outside [0, L).  Batches of independent, unconditional 16-byte loads (a group outside the signal reads
+  // column 0 of its row instead and is zeroed by a select): with the bounds test around the load hipcc waited for every load before issuing
+  // the next -- 18 exposed HBM round trips per tile.  L and the window origin are multiples of 4: a group is wholly inside or wholly outside.
   {
-    const int w4 = W >> 2;
+    const int w4 = W >> 2, total = C * w4;
     const float* Xb = a.X + item * a.x_bs;
-    for (int idx = tid; idx < C * w4; idx += 256) {
-      const int c = idx / w4, g = idx - c * w4, gt = g0 + 4 * g;
-      f4 v{0.f, 0.f, 0.f, 0.f};
-      const float* p = Xb + (long)c * a.ldx + gt;
-      if (gt >= 0 && gt + 3 < a.L) v = *reinterpret_cast<const f4*>(p);
-      else {
+    constexpr int BATCH = 3;
+    for (int base = tid; base < total; base += NT * BATCH) {
+      f4 v[BATCH];
+      int dst[BATCH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gt + e >= 0 && gt + e < a.L) v[e] = p[e];
+      for (int k = 0; k < BATCH; ++k) {
+        const int idx = min(base + NT * k, total - 1);
+        const int c = idx / w4, g = idx - c * w4, gt = g0 + 4 * g;
+        const bool in = gt >= 0 && gt < a.L;
+        v[k] = *reinterpret_cast<const f4*>(Xb + (long)c * a.ldx + (in ? gt : 0));
+        if (!in) v[k] = f4{0.f, 0.f, 0.f, 0.f};
+        dst[k] = c * P + 4 * g;
       }
-      *reinterpret_cast<f4*>(sx + c * P + 4 * g) = v;
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k)
+        if (base + NT * k < total) *reinterpret_cast<f4*>(sx + dst[k]) = v[k];
     }
   }
   __syncthreads();
+  RB_STAMP();
 
   // ---- one conv over local columns [lo, hi): src -> (epilogue)
   //   IS_C2 = false: st = lrelu(conv(lrelu(sx)) + b)            IS_C2 = true, !LAST: sx = conv(st) + b + sx
@@ -140,13 +163,27 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
     for (int unit = uw; unit < n_units; unit += UW) {
       const int u0 = lo + 32 * unit;
       f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      float old[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      if constexpr (LAST) {            // the MRF sum's running value: requested here, used behind the K loop (unconditional loads, clamped column)
+        if (a.mode != 0) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int gt = min(max(g0 + u0 + 16 * m + lj, 0), a.L - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[m][r] = a.out[item * a.o_bs + (long)(rb * 16 + 4 * lk + r) * a.ldo + gt];
+          }
+        }
+      }
       // K loop, tap-major: the B values of tap + 1 (CG x 2 LDS reads) are requested before the MFMAs of tap issue -- left to itself hipcc put
       // every ds_read directly in front of its MFMA behind an lgkmcnt(0), i.e. one exposed LDS round trip per MFMA pair
       const float* bp = src + lk * P + u0 + lj - KH * dil;
       float bq[2][CG][2];
       auto rd = [&](int buf, const float* p) __attribute__((always_inline)) {
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) { bq[buf][cg][0] = p[cg * 4 * P]; bq[buf][cg][1] = p[cg * 4 * P + 16]; }
+        for (int cg = 0; cg < CG; ++cg) {
+          if constexpr ((FDX_RB_EXP & 4) != 0) { bq[buf][cg][0] = slope + (float)cg; bq[buf][cg][1] = slope - (float)cg; }
+          else { bq[buf][cg][0] = p[cg * 4 * P]; bq[buf][cg][1] = p[cg * 4 * P + 16]; }
+        }
       };
       rd(0, bp);
 #pragma unroll
@@ -156,9 +193,11 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
           float b0 = bq[tap & 1][cg][0], b1 = bq[tap & 1][cg][1];
-          if constexpr (!IS_C2) {      // leaky-relu on the operand: max(x, slope x) == the per-conv kernels' select for slope < 1
-            b0 = __builtin_fmaxf(b0, b0 * slope);
-            b1 = __builtin_fmaxf(b1, b1 * slope);
+          if constexpr (!IS_C2 && (FDX_RB_EXP & 1) == 0) {      // leaky-relu on the operand: max(x, slope x) == the per-conv kernels' select for slope < 1
+            // (v_mul + v_max as asm: __builtin_fmaxf adds a canonicalising v_max per operand, and every VALU op here costs MFMA time)
+            float t0_ = b0 * slope, t1_ = b1 * slope;
+            asm("v_max_f32 %0, %1, %2" : "=v"(b0) : "v"(b0), "v"(t0_));
+            asm("v_max_f32 %0, %1, %2" : "=v"(b1) : "v"(b1), "v"(t1_));
           }
           const float av = A[tap * Q + (cg >> 2)][cg & 3];
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
@@ -167,6 +206,7 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       // epilogue: lane holds rows rb*16 + 4*lk + r of column u0 + 16*m + lj
+      if constexpr ((FDX_RB_EXP & 2) != 0) { if (acc[0][0] + acc[1][1] == 1.2345f) st[lane] = acc[0][2]; continue; }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int u = u0 + 16 * m + lj, gt = g0 + u;
@@ -186,8 +226,8 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
               if (inside) {
                 v = v + sx[row * P + u];
                 float* o = a.out + item * a.o_bs + (long)row * a.ldo + gt;
-                if (a.mode == 1) v = *o + v;
-                else if (a.mode == 2) v = (*o + v) / a.div;
+                if (a.mode == 1) v = old[m][r] + v;
+                else if (a.mode == 2) v = (old[m][r] + v) / a.div;
                 __builtin_nontemporal_store(v, o);
               }
             }
@@ -205,6 +245,7 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
     conv_pass(std::false_type{}, std::false_type{}, A0, 2 * j, d1_[j], H4 - rem, H4 + N + rem);
     if constexpr (!PREF) load_w(A0, 2 * j + 1);
     __syncthreads();
+    RB_STAMP();
     // c2_j
     rem -= KH * d2_[j];
     if constexpr (PREF) {
@@ -215,21 +256,34 @@ __global__ __launch_bounds__(256) void k_resblock1_fused(RbFusedArgs a) {
       if constexpr (j + 1 < kRbPairs) load_w(A0, 2 * j + 2);
     }
     if constexpr (j + 1 < kRbPairs) __syncthreads();
+    RB_STAMP();
   };
   run_pair(std::integral_constant<int, 0>{});
   run_pair(std::integral_constant<int, 1>{});
   run_pair(std::integral_constant<int, 2>{});
+#ifdef FDX_RB_TRACE
+  if (a.trace && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.trace[((size_t)blockIdx.x * kRbWaves + wave) * 8 + i] = stamps[i];
+  }
+#endif
+#undef RB_STAMP
 }
 
 // true if a fused instantiation exists for (C, KS) and the geometry fits
+// Instantiated for C = 16 and 32; TAKEN for C = 16 only (rb_fused_wins).  Measured on MI355X (tools/ubench/rbfused.hip, profiles/r04_resblock_fused_ubench.txt),
+// one ResBlock1 at batch 1, us, fused | conv by conv:  C = 16 (L = 440 832): k = 3 / 7 / 11: 77 / 142 / 207 = 426 | 660;  C = 32 (L = 220 416): 134 / 265 / 441 = 839 | 765.
+// At C = 32 two LDS buffers leave N = 288 ... 448 owned columns per tile: the recomputed halo (+21 ... +40 % MFMA work) and the one-row-block-per-wave
+// split (every B value feeds ONE 32-cycle MFMA: the leaky-relu VALU ops and the LDS reads cost as much per MFMA as at C = 16) eat the traffic saved.
 inline bool rb_fused_supported(int C, int KS) { return (C == 16 || C == 32) && (KS == 3 || KS == 7 || KS == 11); }
+inline bool rb_fused_wins(int C) { return C == 16; }
 
 inline hipError_t launch_resblock1_fused(int C, int KS, RbFusedArgs a, int B, hipStream_t s) {
   const int H = rb_halo(KS, a.d1, a.d2), H4 = (H + 3) & ~3;
   a.N = rb_pick_n(C, H4, a.L, B);
   if (a.N <= 0) return hipErrorInvalidValue;
   a.tiles_per_item = (a.L + a.N - 1) / a.N;
-  const dim3 grid((unsigned)(B * a.tiles_per_item)), blk(256);
+  const dim3 grid((unsigned)(B * a.tiles_per_item)), blk(kRbWaves * 64);
 #define FDX_RB(C_, K_) if (C == C_ && KS == K_) { hipLaunchKernelGGL((k_resblock1_fused<C_, K_>), grid, blk, 0, s, a); return hipGetLastError(); }
   FDX_RB(16, 3) FDX_RB(16, 7) FDX_RB(16, 11) FDX_RB(32, 3) FDX_RB(32, 7) FDX_RB(32, 11)
 #undef FDX_RB
