@@ -417,6 +417,64 @@ struct EpiResSkipB : EpiResSkip {  // as EpiResSkip; the next conv's input Y = X
   }
 };
 
+// The denoiser's last projection (wavenet.py:231-234: eps = output_projection(h) + bias, masked) with the UniPC corrector -- and the NEXT step's
+// predictor -- applied to eps in the epilogue instead of by a separate elementwise launch (k_unipc_post / k_unipc_post_pre, elementwise.hip.h):
+//   model_t = (x_t - sigma eps) / alpha;  x = x_base - aB (rho0 D1 + rho1 (model_t - m0))                      uni_pc.py:673-680
+//   [next]  x_base' = c_x' x - c_m' model_t;  x_t' = x_base' - aB' (0.5 (m0 - model_t) / rk')                  uni_pc.py:664-671, 797-804
+// Same expressions in the same order as those kernels (every product / quotient / sum its own rounding: -ffp-contract=off), on the value
+// the EpiBias epilogue would have stored -- the sampler's state is bit-identical to the unfused sequence.  eps itself is not stored.
+struct EpiUniPC {
+  static constexpr bool kPaired = false;
+  float* x; float* mt; float* xbase; float* xt; const float* m0; const float* m1; long bs; int ld;   // sampler state, padded [B][M][ld]
+  const float* bias; int M;
+  const uint8_t* mask; int mask_ld;
+  float sigma, alpha, aB, rk, rho0, rho1; int order;
+  float n_cx, n_cm, n_aB, n_rk; int n_order;     // n_order = 0: last step, no predictor behind the corrector
+  struct Pre { f2 xt, xb, m0, m1; float bias; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p;
+    const int r = min(row, M - 1);
+    const long o = b * bs + (long)r * ld + t;
+    p.xt = ld2(xt + o, two); p.xb = ld2(xbase + o, two); p.m0 = ld2(m0 + o, two); p.m1 = ld2(m1 + o, two);
+    p.bias = bias[r];
+    return p;
+  }
+  __device__ __forceinline__ void one(float eps, float xtv, float xbv, float m0v, float m1v, float& xn, float& mtv, float& xb2, float& xt2) const {
+    mtv = (xtv - sigma * eps) / alpha;
+    const float D1t = mtv - m0v;
+    float corr;
+    if (order == 2) {
+      const float D1 = (m1v - m0v) / rk;
+      corr = rho0 * D1 + rho1 * D1t;
+    } else {
+      corr = rho1 * D1t;
+    }
+    xn = xbv - aB * corr;
+    xb2 = n_cx * xn - n_cm * mtv;
+    xt2 = xb2;
+    if (n_order == 2) {
+      const float D1n = (m0v - mtv) / n_rk;
+      xt2 = xb2 - n_aB * (0.5f * D1n);
+    }
+  }
+  __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
+    if (row >= M) return;
+    v += p.bias;
+    if (mask) {
+      if (mask[(long)b * mask_ld + t] != 0) v.x = 0.f;
+      if (two && mask[(long)b * mask_ld + t + 1] != 0) v.y = 0.f;
+    }
+    float r0[4], r1[4];
+    one(v.x, p.xt.x, p.xb.x, p.m0.x, p.m1.x, r0[0], r0[1], r0[2], r0[3]);
+    one(v.y, p.xt.y, p.xb.y, p.m0.y, p.m1.y, r1[0], r1[1], r1[2], r1[3]);
+    const f2 xn{r0[0], r1[0]}, mtv{r0[1], r1[1]}, xb2{r0[2], r1[2]}, xt2{r0[3], r1[3]};
+    const long o = b * bs + (long)row * ld + t;
+    st2(mt + o, mtv, two);
+    st2(x + o, xn, two);
+    if (n_order != 0) { st2(xbase + o, xb2, two); st2(xt + o, xt2, two); }
+  }
+};
+
 struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) + bias); masked_fill(x_masks)
   static constexpr bool kPaired = false;
   float* X; long bs; int ld;                 // residual in, result out (in place), padded rows

@@ -82,7 +82,10 @@ inline void rb_fused_pack(float* dst, const float* w, int C, int KS) {
 }
 inline size_t rb_fused_floats(int C, int KS) { return (size_t)KS * C * C; }
 
-constexpr int kRbWaves = 8;   // waves per workgroup: two per SIMD -- with one, nothing hides a wave's LDS reads / epilogue / address arithmetic (measured additive)
+#ifndef FDX_RB_WAVES
+#define FDX_RB_WAVES 8
+#endif
+constexpr int kRbWaves = FDX_RB_WAVES;   // waves per workgroup: two per SIMD -- with one, nothing hides a wave's LDS reads / epilogue / address arithmetic (measured additive)
 
 template <int C, int KS>
 __global__ __launch_bounds__(kRbWaves * 64) void k_resblock1_fused(RbFusedArgs a) {
@@ -194,10 +197,13 @@ __global__ __launch_bounds__(kRbWaves * 64) void k_resblock1_fused(RbFusedArgs a
         for (int cg = 0; cg < CG; ++cg) {
           float b0 = bq[tap & 1][cg][0], b1 = bq[tap & 1][cg][1];
           if constexpr (!IS_C2 && (FDX_RB_EXP & 1) == 0) {      // leaky-relu on the operand: max(x, slope x) == the per-conv kernels' select for slope < 1
-            // (v_mul + v_max as asm: __builtin_fmaxf adds a canonicalising v_max per operand, and every VALU op here costs MFMA time)
-            float t0_ = b0 * slope, t1_ = b1 * slope;
-            asm("v_max_f32 %0, %1, %2" : "=v"(b0) : "v"(b0), "v"(t0_));
-            asm("v_max_f32 %0, %1, %2" : "=v"(b1) : "v"(b1), "v"(t1_));
+            // max(x, slope x) as v_mul + v_max: __builtin_fmaxf (and fmed3 with +inf, which folds to it) adds a canonicalising v_max per operand, and
+            // every VALU op here costs MFMA time.  Inline asm, so the VALU-write -> MFMA-read hazard is ours to cover: the hazard recogniser does
+            // not see inside an asm statement (without the s_nop the MFMA read the operand too early: wrong results, caught by the ubench's check).
+            const float t0_ = b0 * slope, t1_ = b1 * slope;
+            float r0_, r1_;
+            asm("v_max_f32 %0, %2, %4\n\tv_max_f32 %1, %3, %5\n\ts_nop 1" : "=&v"(r0_), "=&v"(r1_) : "v"(b0), "v"(b1), "v"(t0_), "v"(t1_));
+            b0 = r0_; b1 = r1_;
           }
           const float av = A[tap * Q + (cg >> 2)][cg & 3];
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kRbWaves * 64) void k_resblock1_fused(RbFusedArgs a
 
 // true if a fused instantiation exists for (C, KS) and the geometry fits
 // Instantiated for C = 16 and 32; TAKEN for C = 16 only (rb_fused_wins).  Measured on MI355X (tools/ubench/rbfused.hip, profiles/r04_resblock_fused_ubench.txt),
-// one ResBlock1 at batch 1, us, fused | conv by conv:  C = 16 (L = 440 832): k = 3 / 7 / 11: 77 / 142 / 207 = 426 | 660;  C = 32 (L = 220 416): 134 / 265 / 441 = 839 | 765.
+// one ResBlock1 at batch 1, us, fused | conv by conv:  C = 16 (L = 440 832): k = 3 / 7 / 11: 75 / 137 / 198 = 410 | 660;  C = 32 (L = 220 416): 133 / 254 / 418 = 805 | 765.
 // At C = 32 two LDS buffers leave N = 288 ... 448 owned columns per tile: the recomputed halo (+21 ... +40 % MFMA work) and the one-row-block-per-wave
 // split (every B value feeds ONE 32-cycle MFMA: the leaky-relu VALU ops and the LDS reads cost as much per MFMA as at C = 16) eat the traffic saved.
 inline bool rb_fused_supported(int C, int KS) { return (C == 16 || C == 32) && (KS == 3 || KS == 7 || KS == 11); }

@@ -747,8 +747,9 @@ static int wn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s) {
 // ================================================================================================ forward
 // xin: padded [B][M][ld] (valid data at +kHalo).  Step projections are read from column `col0 + b*sb_bs` of S.
 // eps_out: [B][M] rows with pitch ldo / item stride o_bs (padded EPS buffer or the caller's tensor).
+// `fuse` (UniPC sampler only): the last projection's epilogue applies the corrector (+ the next step's predictor) to eps instead of storing it
 static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out,
-                           long o_bs, int ldo, hipStream_t s, const float* Pslab = nullptr) {
+                           long o_bs, int ldo, hipStream_t s, const float* Pslab = nullptr, const EpiUniPC* fuse = nullptr) {
   const auto& d = h->wd;
   const auto& l = h->wl;
   const int C = d.residual_channels, L = d.residual_layers, M = d.mel_channels;
@@ -912,7 +913,11 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
     EpiBias e = epi_bias(H, bsC, ld, A + l.skip_proj.b_off, C, ACT_RELU);
     FDX_HIP(h, (run_gemm<true, false>(A, l.skip_proj, B, T, SK, bsC, ld, 0, 0, 1.f, e, s)));
   }
-  {
+  if (fuse) {
+    EpiUniPC e = *fuse;
+    e.bias = A + l.out_proj.b_off; e.M = M; e.mask = mask; e.mask_ld = T;
+    FDX_HIP(h, (run_gemm<true, false>(A, l.out_proj, B, T, H, bsC, ld, 0, 0, 1.f, e, s)));
+  } else {
     EpiBias e = epi_bias(eps_out, o_bs, ldo, A + l.out_proj.b_off, M, ACT_NONE);
     e.mask = mask; e.mask_ld = T;
     e.tight = ldo != ld;   // fdx_wavenet_forward writes straight into the caller's [B][M][T] tensor
@@ -962,13 +967,15 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
   const dim3 grid = ew_grid(T, B * M), blk(kEwBlock);
   float* sx = h->sx.f() + kHalo;
   float* eps = h->EPS.f() + kHalo;
-  auto model = [&](const float* xin, int col, bool masked) {
+  // WaveNet + UniPC: the corrector (and the next predictor) ride in the last projection's epilogue (EpiUniPC): one launch less per step
+  static const bool fuse_unipc = [] { const char* e = getenv("FDX_UNIPC_FUSED"); return !e || atoi(e) != 0; }();
+  auto model = [&](const float* xin, int col, bool masked, const EpiUniPC* fuse = nullptr) {
     // the one unmasked call of PLMS uses the conditioner slab of the UNMASKED conditioner (built in the set-up phase)
     if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked);
     if (h->den_kind == 2) return fdx_td_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked);
     const float* P = (!masked && h->cond_masked) ? h->P2.f() : nullptr;
     // (exact-mask mode: the mask marks frames that do not exist, for an item run alone as well -- PLMS's unmasked call keeps it)
-    return wn_forward_core(h, xin, col, 0, (masked || h->ragged_keep) ? x_mask : nullptr, eps, bs, ld, s, P);
+    return wn_forward_core(h, xin, col, 0, (masked || h->ragged_keep) ? x_mask : nullptr, eps, bs, ld, s, P, fuse);
   };
 
   if (kind == FDX_SAMPLER_UNIPC) {
@@ -984,7 +991,18 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
       if (!pre_done)
         hipLaunchKernelGGL(k_unipc_pre, grid, blk, 0, s, xb, xt, sx, m0, m1, bs, ld, M, T, c_x, c_m, aB, rk, order);
       pre_done = false;
-      if (corr) {
+      if (corr && fuse_unipc && h->den_kind == 0) {
+        EpiUniPC e{};
+        e.x = sx; e.mt = mt; e.xbase = xb; e.xt = xt; e.m0 = m0; e.m1 = m1; e.bs = bs; e.ld = ld;
+        e.sigma = sigma; e.alpha = alpha; e.aB = aB; e.rk = rk; e.rho0 = row[9]; e.rho1 = row[10]; e.order = order;
+        if (r + 1 < n_rows) {
+          const float* nx = row + FDX_ROW;
+          e.n_cx = nx[3]; e.n_cm = nx[4]; e.n_aB = nx[5]; e.n_rk = nx[6]; e.n_order = (int)nx[7];
+          pre_done = true;
+        }
+        if (int rc = model(xt, r, true, &e)) return rc;
+        float* tmp = m1; m1 = m0; m0 = mt; mt = tmp;   // history shift (uni_pc.py:797-804)
+      } else if (corr) {
         if (int rc = model(xt, r, true)) return rc;
         if (r + 1 < n_rows) {
           const float* nx = row + FDX_ROW;

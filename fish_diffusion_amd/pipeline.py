@@ -88,9 +88,10 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     `exact` (default: True for the WaveNet denoiser in fp32 or fp16x3 storage): padded batches run in the library's EXACT-RAGGED mode
     -- every utterance's result is what a batch-1 run of it alone gives (the reference's one-segment-at-a-time loop): bit for bit in
     fp32 storage, to fp32 rounding in the opt-in fp16x3 storage (a long row may run the hi+lo fp16 tiles where the short item alone
-    runs the fp32 MFMA kernels: both fp32-class, not bit-identical to each other) -- and padding costs no arithmetic.  If the library
-    cannot run exact-mask mode in its current configuration (tuning switches FDX_OUTP_SHAPE=0 / FDX_RESBLOCK_MFMA) a defaulted
-    `exact` falls back to masked batches; an explicit `exact=True` raises.  False: the reference's own padded-batch semantics with x_masks /
+    runs the 64 x 64 fp16-split tiles: both fp32-class, not bit-identical to each other) -- and padding costs no arithmetic.  Whether the
+    mode exists is a static property of (denoiser, storage): decided ONCE, before batching (bf16 storage and the ConvNext / transformer
+    denoisers have no exact-mask kernels: an explicit `exact=True` raises NotImplementedError from the library, the default picks the
+    reference's masked batches there).  False: the reference's own padded-batch semantics with x_masks /
     cond_masks (the masked tail stays alive inside the receptive field: the last ~75 frames of every padded item differ slightly
     from a run alone)."""
     if len(features) != len(f0s):
@@ -104,7 +105,6 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     if mel_scale is None:   # nsf_hifigan.py:79-80: a log10 mel is rescaled to natural log
         mel_scale = 2.30259 if getattr(vocoder, "use_natural_log", True) is False else 1.0
     dev = features[mine[0]].device
-    exact_defaulted = exact is None
     if exact is None:
         den = getattr(diffusion, "denoise_fn", None)
         exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")
@@ -130,15 +130,7 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
             kw["lengths"] = [lengths[i] for i in idx]
         elif ragged:
             kw["x_masks"] = kw["cond_masks"] = masks
-        try:
-            mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
-        except NotImplementedError:
-            if not (ragged and exact and exact_defaulted):
-                raise
-            exact = False          # the library's current tuning configuration has no exact-mask kernels: the reference's masked batches
-            kw.pop("lengths")
-            kw["x_masks"] = kw["cond_masks"] = masks
-            mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)
+        mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
         for b, i in enumerate(idx):
             n = lengths[i]
             vkw = {}

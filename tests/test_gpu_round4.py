@@ -219,3 +219,46 @@ def test_fused_resblock_kernel_agrees_with_the_per_conv_path_and_the_oracle(dev,
             err = abs_err(torch.from_numpy(fused[f"{tag}_{B}_{T}"]), ref)
             assert err < WAV_ABS, (tag, B, T, err)
     print(f"fused ResBlock1 vs per-conv path: max abs diff {worst:.3e}")
+
+
+# ------------------------------------------------------------------------------------------------ UniPC corrector in the last projection's epilogue
+_UNIPC_CODE = r'''
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from fish_diffusion_amd import GaussianDiffusion
+from tests.helpers import WN_SMALL, wavenet_sd
+dev = torch.device("cuda", 0)
+diff = GaussianDiffusion(dict(type="WaveNetDenoiser", **WN_SMALL), spec_min=[-5], spec_max=[0])
+diff.denoise_fn.load_state_dict(wavenet_sd(WN_SMALL, 101), strict=True)
+diff = diff.to(dev).eval()
+h = hashlib.sha1()
+g = torch.Generator().manual_seed(21)
+for B, T, iv in ((1, 37, 100), (2, 113, 50), (1, 430, 20), (3, 64, 500), (1, 861, 334)):
+    feats, x0 = torch.randn(B, T, 256, generator=g).to(dev), torch.randn(B, 128, T, generator=g).to(dev)
+    m = torch.zeros(B, T, dtype=torch.bool, device=dev)
+    m[-1, T - T // 4:] = True
+    for masks in (None, m):
+        mel = diff(feats, sampler_interval=iv, x_init=x0, x_masks=masks, cond_masks=masks)
+        assert torch.isfinite(mel).all()
+        h.update(mel.cpu().numpy().tobytes())
+    lens = [max(1, T - 7 * b) for b in range(B)]
+    mel = diff(feats, sampler_interval=iv, x_init=x0, lengths=lens)        # exact-ragged rows run the same fused epilogue
+    h.update(mel.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+'''
+
+
+def test_unipc_update_fused_into_the_last_projection_is_bit_identical(dev):
+    """VERDICT r3 item 3 (first half): the UniPC corrector + next predictor (uni_pc.py:664-680) run in the epilogue of the denoiser's last
+    projection (EpiUniPC) instead of a separate elementwise launch.  Same expressions, same order, -ffp-contract=off: the sampled mels must
+    be BIT-identical to the unfused sequence (FDX_UNIPC_FUSED=0: out-projection -> eps, then k_unipc_post_pre), for odd step counts (the
+    order-1 tail), masks, batches and exact-ragged rows."""
+    import subprocess
+    import sys
+    digests = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, FDX_UNIPC_FUSED=mode)
+        r = subprocess.run([sys.executable, "-c", _UNIPC_CODE % ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DIGEST" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        digests[mode] = r.stdout.split("DIGEST")[1].split()[0]
+    assert digests["1"] == digests["0"], digests
