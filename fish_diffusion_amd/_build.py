@@ -16,8 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libfishdx.so")
 SOURCES = ["core.hip", "wavenet.hip", "nsf.hip", "mel.hip", "features.hip", "refinegan.hip", "convnext.hip", "tfdec.hip"]
-HEADERS = ["common.hip.h", "convgemm.hip.h", "convgemm16.hip.h", "convgemm16s.hip.h", "bf16lds.hip.h", "f16s64.hip.h", "convplan.hip.h", "elementwise.hip.h", "nsf_kernels.hip.h",
-           "refinegan_kernels.hip.h", "gemmplan.hip.h", "declayer.hip.h", "../../include/fishdx.h"]
+# every header under csrc/ (+ the C ABI): a change to any of them rebuilds every object (a hand-kept list went stale once: a header-only fix
+# of the fused ResBlock kernel did not rebuild nsf.o)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/fishdx.h"]
 # -amdgpu-kernarg-preload-count: the first 14 scalar kernel-argument dwords arrive in SGPRs at wave launch (convgemm.hip.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-mllvm", "-amdgpu-kernarg-preload-count=14"]
