@@ -11,7 +11,8 @@ from .mel import PitchAdjustableMelSpectrogram  # noqa: F401
 from .diffsinger import ENCODERS, DiffSinger, NaiveProjectionEncoder, pitch_to_scale, repeat_expand  # noqa: F401
 from .refinegan import RefineGAN, RefineGANGenerator  # noqa: F401
 from .hifisinger import HiFiSinger  # noqa: F401
+from .inference import SVCModel, inference_model, load_checkpoint  # noqa: F401
 from . import segments  # noqa: F401
 
 __all__ = ["DENOISERS", "DIFFUSIONS", "VOCODERS", "install", "WaveNet", "ConvNext", "TransformerDecoderDenoiser", "GaussianDiffusion", "NsfHifiGAN", "Generator",
-           "PitchAdjustableMelSpectrogram", "ENCODERS", "DiffSinger", "NaiveProjectionEncoder", "pitch_to_scale", "repeat_expand", "RefineGAN", "RefineGANGenerator", "HiFiSinger"]
+           "PitchAdjustableMelSpectrogram", "ENCODERS", "DiffSinger", "NaiveProjectionEncoder", "pitch_to_scale", "repeat_expand", "RefineGAN", "RefineGANGenerator", "HiFiSinger", "SVCModel", "load_checkpoint", "inference_model"]

@@ -30,12 +30,14 @@ def main():
                  "sharded": {"config": "sharded", "batch": 8, "frames": 861}, "ddpm1000": {"config": "ddpm1000", "batch": 16, "frames": 861},
                  "ddpm1000_bf16": {"config": "ddpm1000_bf16", "batch": 16, "frames": 861},
                  "ddpm1000_fp16x3": {"config": "ddpm1000_fp16x3", "batch": 16, "frames": 861},
-                 "headline_fp16x3": {"config": "headline_fp16x3", "batch": 1, "frames": 861}}
+                 "headline_fp16x3": {"config": "headline_fp16x3", "batch": 1, "frames": 861},
+                 "hifisinger_v2": {"config": "hifisinger_v2", "batch": 16, "frames": 1722},
+                 "convnext": {"config": "convnext", "batch": 1, "frames": 861}, "tfdec": {"config": "tfdec", "batch": 1, "frames": 861}}
     out = {"source": {"fetch_db": sys.argv[1], "write_db": sys.argv[2]}, "workload": workloads[cfg],
            "note": "bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024",
            "kernels": {}}
     for k in fetch:
-        if "convgemm" not in k and "bf16lds" not in k and "f16s64" not in k:
+        if not any(t in k for t in ("convgemm", "bf16lds", "f16s64", "k_attn", "k_resblock1_fused", "k_dwconv_stats")):
             continue
         n, f = fetch[k]
         w = write.get(k, (0, 0.0))[1]
