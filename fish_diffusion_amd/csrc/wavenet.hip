@@ -784,7 +784,7 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
   const float sqrtL = (float)std::sqrt((double)L);
   if (h->prof.on) {   // fdx_prof_label: the instantiations this call's two residual-block launches are (rocprofv3's kernel names)
     if (f16s_small) {
-      h->prof.note(PROF_WN_CONVGATE, "f16s64_kernel<BfEpiGate> (3 x v_mfma_f32_16x16x32_f16 per product block; 64 x 64 workgroup tile, LDS-DMA, 3 stages; %ld workgroups)",
+      h->prof.note(PROF_WN_CONVGATE, "f16s64_kernel<BfEpiGate> (3 x v_mfma_f32_16x16x32_f16 per product block; 64 x 64 workgroup tile, LDS-DMA; %ld workgroups)",
                    (long)B * ((T + 63) / 64) * (2 * C / 64));
       h->prof.note(PROF_WN_OUTPROJ, "f16s64_kernel<BfEpiResSkip> (3 x v_mfma_f32_16x16x32_f16 per product block; 64 x 64 workgroup tile)");
     } else if (f16s_big || (h->wn_arena_bf16 && h->wn_bf16_lds_ok && (long)B * ((T + 127) / 128) * (C / 64) >= bf16_lds_min_tiles())) {

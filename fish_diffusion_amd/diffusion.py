@@ -220,8 +220,8 @@ class GaussianDiffusion(nn.Module):
         `lengths` (extension): per-item valid frame counts of a padded batch -> EXACT-RAGGED mode: every item's mel[:length] is what
         a batch-1 call on its unpadded features returns (the reference's inference loop, tools/diffusion/inference.py:336-376, runs
         one segment at a time) -- BIT FOR BIT in the default fp32 storage; in the opt-in `storage="fp16x3"` mode to fp32 rounding
-        only (a long ragged row and a short single item may run different fp32-class kernel families: hi+lo fp16 tiles vs fp32
-        MFMA, chosen by tile count); frames beyond an item's length come back as 0.  The
+        only (a long ragged row and a short single item may run different fp16-split kernel families: 128-wide LDS tiles vs 64 x 64
+        tiles, chosen by tile count); frames beyond an item's length come back as 0.  The
         batch is laid out as ONE row -- items separated by 16-frame holes, nothing padded to a common length -- and run through
         `fdx_sampler_run_ragged`, whose holes isolate the items exactly (include/fishdx.h).  Mutually exclusive with x_masks /
         cond_masks (the reference's own padded-batch semantics)."""

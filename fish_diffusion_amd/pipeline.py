@@ -87,7 +87,7 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     to a multiple of this many frames (0 / 1 = pad to the longest member only).
     `exact` (default: True for the WaveNet denoiser in fp32 or fp16x3 storage): padded batches run in the library's EXACT-RAGGED mode
     -- every utterance's result is what a batch-1 run of it alone gives (the reference's one-segment-at-a-time loop): bit for bit in
-    fp32 storage, to fp32 rounding in the opt-in fp16x3 storage (a long row may run the hi+lo fp16 tiles where the short item alone
+    fp32 storage, to fp32 rounding in the opt-in fp16x3 storage (a long row may run the 128-wide fp16-split tiles where the short item alone
     runs the 64 x 64 fp16-split tiles: both fp32-class, not bit-identical to each other) -- and padding costs no arithmetic.  Whether the
     mode exists is a static property of (denoiser, storage): decided ONCE, before batching (bf16 storage and the ConvNext / transformer
     denoisers have no exact-mask kernels: an explicit `exact=True` raises NotImplementedError from the library, the default picks the

@@ -223,8 +223,8 @@ class WaveNet(HipDenoiser):
         """"fp32" (default).
         "bf16": bf16 weights / activation operands, fp32 accumulate (BASELINE configs[4]).  Not parity-grade; DESIGN.md has its error.
         "fp16x3": every operand as an fp16 pair hi + lo, each product block hi.hi + hi.lo + lo.hi on the fp16 MFMA, fp32 accumulate:
-        fp32-class results (the tests hold it to the fp32 path's own bars), used where a launch has enough LDS tiles (batch >= 2 at
-        10 s) and the fp32 kernels otherwise."""
+        fp32-class results (the tests hold it to the fp32 path's own bars): 128-wide LDS tiles from 200 tiles per launch (batch >= 4 at
+        10 s), 64 x 64 tiles below.  Nets with a dilation above 8 (dilation_cycle = 5) are refused: the kernels stage tile +/- 8 columns."""
         return self._storage
 
     @storage.setter

@@ -193,9 +193,9 @@ int fdx_sampler_run(fdx_handle h, int kind, const float* host_table, int n_rows,
  * common length -- and get every item exactly as if it had been run alone (what tools/diffusion/inference.py:336-376 computes
  * one segment at a time); fish_diffusion_amd.GaussianDiffusion(..., lengths=) does that.  x at masked frames is left undefined.
  * WaveNet denoiser.  fp32 storage: "bit for bit" holds for every geometry.  Opt-in fp16-split storage (fdx_wavenet_f16s_enable): the
- * exact-mask epilogues exist for both kernel families, but a long ragged row may run the hi+lo fp16 tiles where a short item alone
- * runs the fp32 MFMA kernels (chosen by tile count), so an item agrees with its stand-alone run to fp32 rounding, not bit for bit.
- * Not available in bf16 storage or with the tuning switches FDX_OUTP_SHAPE=0 / FDX_RESBLOCK_MFMA (FDX_E_NOIMPL). */
+ * exact-mask epilogues exist for both of its kernel families, but a long ragged row may run the 128-wide LDS tiles (bf16lds.hip.h) where a
+ * short item alone runs the 64 x 64 tiles (f16s64.hip.h) -- chosen by tile count, different summation grouping -- so an item agrees with
+ * its stand-alone run to fp32 rounding, not bit for bit.  Not available in bf16 storage (FDX_E_NOIMPL). */
 int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* host_table, int n_rows, float* x, const float* step_noise,
                            uint64_t seed, const uint8_t* x_mask, fdx_stream s);
 /* The start of shallow diffusion, diffusion.py:223-232: out = q_sample(norm_spec(src), t, noise).
