@@ -10,6 +10,7 @@
 #include "gemmplan.hip.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace fdx {
 namespace {
@@ -128,13 +129,15 @@ struct AttnArgs {
 };
 
 // NQ = 32-query blocks per workgroup: 2 (64 queries) when that already fills the chip, 1 to double the workgroup count
+// Four waves (one per SIMD) split the key tiles.  (Eight waves = two per SIMD without the register prefetch: 41.5 us against 29.4, round 4.)
 template <int DH, int NQ>
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+  constexpr int NWV = 4;
   constexpr int KS = DH / 2;                 // MFMA k-steps of the score product
   constexpr int RBD = (DH + 31) / 32;        // 32-row blocks of O^T
   constexpr int VLD = 65;                    // padded row of the staged V tile
   constexpr int NBLK = RBD * NQ;
-  constexpr int LDS_F = (4 * DH * VLD > 4 * NBLK * 16 * 64 + 4 * 2 * NQ * 64) ? 4 * DH * VLD : 4 * NBLK * 16 * 64 + 4 * 2 * NQ * 64;
+  constexpr int LDS_F = (NWV * DH * VLD > NWV * NBLK * 16 * 64 + NWV * 2 * NQ * 64) ? NWV * DH * VLD : NWV * NBLK * 16 * 64 + NWV * 2 * NQ * 64;
   __shared__ float lds[LDS_F];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, n = lane & 31;
@@ -144,12 +147,13 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   const float* Vh = a.V + b * a.v_bs + (long)h * DH * a.ldv;
   const float NEG = -__builtin_inff();
 
-  // B operand of the score product: this lane's slice of Q, for the whole launch
+  // B operand of the score product: this lane's slice of Q, for the whole launch, pre-multiplied by 1/sqrt(DH) (as the reference's
+  // multi_head_attention_forward scales q before the product)
   float qreg[KS][NQ];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int nb = 0; nb < NQ; ++nb) qreg[ks][nb] = Qh[(long)(2 * ks + half) * a.ldq + min(q0 + nb * 32 + n, a.Tq - 1)];
+    for (int nb = 0; nb < NQ; ++nb) qreg[ks][nb] = Qh[(long)(2 * ks + half) * a.ldq + min(q0 + nb * 32 + n, a.Tq - 1)] * a.scale;
 
   f32x16 o[RBD][NQ];
 #pragma unroll
@@ -163,32 +167,51 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   for (int nb = 0; nb < NQ; ++nb) { m[nb] = NEG; l[nb] = 0.f; }
   float* vt = lds + wave * DH * VLD;
 
-  // The K and V operands of a tile are fetched into registers one tile ahead: right after the score MFMAs have consumed the
-  // current ones, so that their fabric latency runs behind the softmax and the second product instead of in front of the first.
+  // The K and V operands of a tile are fetched into registers one tile ahead, two K rows + two V rows behind each k-step of the score
+  // product (their issue slots hide under the MFMAs that have just consumed the registers; the fabric latency runs behind the softmax and
+  // the second product).  Every load is a wave-uniform row pointer + a 32-bit lane offset (no 64-bit vector address arithmetic).
+  // The key-padding mask of a tile is ONE byte per lane (key k0 + lane), fetched with the operands and turned into a 64-bit key set by a
+  // ballot: the softmax selects on bits of a scalar.  (Round 4: it was 32 conditional byte loads per tile, each behind its own vmcnt(0).)
   const int n_kt = (a.Tk + 63) / 64;
+  const bool has_mask = a.kmask != nullptr;
+  const uint8_t* mrow = has_mask ? a.kmask + (long)b * a.Tk : reinterpret_cast<const uint8_t*>(Kh);   // no mask: any readable bytes, ignored
   float kreg[KS][2], vreg[DH];
-  auto fetch = [&](int kt) {
-    const int k0 = kt * 64;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) kreg[ks][rb] = Kh[(long)(2 * ks + half) * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)];
-#pragma unroll
-    for (int d = 0; d < DH; ++d) vreg[d] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
+  unsigned mreg = 0;
+  // (buffer loads: one resource per operand, lane offset in a VGPR, row offset in an SGPR)
+  const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Kh), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vh), 0, -1, 0x00020000);
+  auto fetch_ks = [&](int k0, int ks) __attribute__((always_inline)) {   // the operands k-step `ks` consumes + two V rows
+    const int kc0 = 4 * (half * a.ldk + min(k0 + n, a.Tk - 1)), kc1 = 4 * (half * a.ldk + min(k0 + 32 + n, a.Tk - 1));
+    const int vc = 4 * min(k0 + lane, a.Tk - 1);
+    kreg[ks][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kres, kc0, 8 * ks * a.ldk, 0));
+    kreg[ks][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kres, kc1, 8 * ks * a.ldk, 0));
+    vreg[2 * ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vres, vc, 8 * ks * a.ldv, 0));
+    vreg[2 * ks + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vres, vc, (8 * ks + 4) * a.ldv, 0));
   };
+  auto fetch_mask = [&](int k0) __attribute__((always_inline)) { mreg = mrow[(unsigned)min(k0 + lane, a.Tk - 1)]; };
   // (not for 64-query x 64-channel workgroups: their accumulators leave no room for a second operand set in 512 VGPRs)
   constexpr bool PF = !(DH == 64 && NQ == 2);
-  if (PF && wave < n_kt) fetch(wave);
-  for (int kt = wave; kt < n_kt; kt += 4) {
+  static_assert(2 * KS == DH, "one V row pair per k-step");
+  if (PF && wave < n_kt) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fetch_ks(wave * 64, ks);
+    fetch_mask(wave * 64);
+  }
+  for (int kt = wave; kt < n_kt; kt += NWV) {
     const int k0 = kt * 64;
+    const bool more = kt + NWV < n_kt;         // wave-uniform
     // ---- stage this tile of V (coalesced rows) for the second product
     if constexpr (PF) {
 #pragma unroll
       for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = vreg[d];
     } else {
+      fetch_mask(k0);
 #pragma unroll 8
-      for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = Vh[(long)d * a.ldv + min(k0 + lane, a.Tk - 1)];
+      for (int d = 0; d < DH; ++d)
+        vt[d * VLD + lane] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vres, 4 * min(k0 + lane, a.Tk - 1), 4 * d * a.ldv, 0));
     }
+    // keys this tile must ignore (tile overhang + key padding), as a wave-uniform bit set
+    const unsigned long long badm = __ballot((k0 + lane >= a.Tk) || (has_mask && mreg != 0));
     // ---- S^T = K^T Q
     f32x16 s[2][NQ];
 #pragma unroll
@@ -197,19 +220,24 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
       for (int nb = 0; nb < NQ; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[rb][nb][r] = 0.f;
+    auto scores = [&](auto prefetch) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float ak[2];
+      for (int ks = 0; ks < KS; ++ks) {
+        float ak[2];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-        ak[rb] = PF ? kreg[ks][rb] : Kh[(long)(2 * ks + half) * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)];
+        for (int rb = 0; rb < 2; ++rb)
+          ak[rb] = PF ? kreg[ks][rb]
+                      : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kres, 4 * (half * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)), 8 * ks * a.ldk, 0));
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int nb = 0; nb < NQ; ++nb) s[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rb], qreg[ks][nb], s[rb][nb], 0, 0, 0);
-    }
-    if (PF && kt + 4 < n_kt) fetch(kt + 4);
-    // ---- scale, key mask (padding keys and the tile overhang), online softmax over the key axis
+          for (int nb = 0; nb < NQ; ++nb) s[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rb], qreg[ks][nb], s[rb][nb], 0, 0, 0);
+        if constexpr (decltype(prefetch)::value) fetch_ks(k0 + 64 * NWV, ks);
+      }
+    };
+    if (PF && more) { scores(std::true_type{}); fetch_mask(k0 + 64 * NWV); }
+    else scores(std::false_type{});
+    // ---- key mask, online softmax over the key axis
     float mx[NQ];
 #pragma unroll
     for (int nb = 0; nb < NQ; ++nb) mx[nb] = NEG;
@@ -217,11 +245,12 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = k0 + rb * 32 + acc_row(r, half);
-        const bool ok = key < a.Tk && !(a.kmask && a.kmask[(long)b * a.Tk + min(key, a.Tk - 1)]);
+        const int c = rb * 32 + acc_row(r, 0);          // this element's key bit in the low lane half; + 4 in the high half
+        const unsigned long long lanes = (((badm >> c) & 1) ? 0x00000000FFFFFFFFull : 0ull) | (((badm >> (c + 4)) & 1) ? 0xFFFFFFFF00000000ull : 0ull);
+        const bool bad = __builtin_amdgcn_inverse_ballot_w64(lanes);
 #pragma unroll
         for (int nb = 0; nb < NQ; ++nb) {
-          const float v = ok ? s[rb][nb][r] * a.scale : NEG;
+          const float v = bad ? NEG : s[rb][nb][r];
           s[rb][nb][r] = v;
           mx[nb] = fmaxf(mx[nb], v);
         }
@@ -265,10 +294,10 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
       }
   }
 
-  // ---- merge the 4 waves' (m, l, O) through LDS; wave w finishes accumulator rows r = 4w .. 4w+3 of every block
+  // ---- merge the NWV waves' (m, l, O) through LDS; wave w finishes accumulator rows r = RPW w .. RPW w + RPW - 1 of every block (RPW = 16 / NWV)
   __syncthreads();
   float* ob = lds;                                   // [wave][blk][r][lane]
-  float* ml = lds + 4 * NBLK * 16 * 64;              // [wave][{m,l}][nb][lane]
+  float* ml = lds + NWV * NBLK * 16 * 64;            // [wave][{m,l}][nb][lane]
 #pragma unroll
   for (int x = 0; x < RBD; ++x)
 #pragma unroll
@@ -283,24 +312,24 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   __syncthreads();
 #pragma unroll
   for (int nb = 0; nb < NQ; ++nb) {
-    float mw[4], M = NEG, L = 0.f, wg[4];
+    float mw[NWV], M = NEG, L = 0.f, wg[NWV];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { mw[w] = ml[((w * 2 + 0) * NQ + nb) * 64 + lane]; M = fmaxf(M, mw[w]); }
+    for (int w = 0; w < NWV; ++w) { mw[w] = ml[((w * 2 + 0) * NQ + nb) * 64 + lane]; M = fmaxf(M, mw[w]); }
     const float M_use = M == NEG ? 0.f : M;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { wg[w] = expf(mw[w] - M_use); L += ml[((w * 2 + 1) * NQ + nb) * 64 + lane] * wg[w]; }
+    for (int w = 0; w < NWV; ++w) { wg[w] = expf(mw[w] - M_use); L += ml[((w * 2 + 1) * NQ + nb) * 64 + lane] * wg[w]; }
     const int q = q0 + nb * 32 + n;
     if (q >= a.Tq) continue;
 #pragma unroll
     for (int x = 0; x < RBD; ++x)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave * 4 + rr;
+      for (int rr = 0; rr < 16 / NWV; ++rr) {
+        const int r = wave * (16 / NWV) + rr;
         const int d = x * 32 + acc_row(r, half);
         if (d >= DH) continue;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += ob[((w * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] * wg[w];
+        for (int w = 0; w < NWV; ++w) acc += ob[((w * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] * wg[w];
         a.O[b * a.o_bs + (long)(h * DH + d) * a.ldo + q] = acc / L;
       }
   }
