@@ -22,6 +22,7 @@
 //                      the vocoder regime (10^5 columns).
 //  * XCD-aware block order: consecutive logical tiles (same weight rows) land on the same XCD's L2.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -214,12 +215,37 @@ __device__ __forceinline__ f2 div_const(f2 x, float c, float rc) { return f2{div
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3 };
 
 // nn.GELU() (exact, erf form): 0.5 * x * (1 + erf(x / sqrt(2)))
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// GELU (erf form, F.gelu's default): erf as one branch-free rational x P(x^2) / Q(x^2) on [-4, 4] (the fp32 fit Eigen / XLA use; 4.4e-7
+// max abs error on erf, GELU within 1.4e-6 abs of an fp64 evaluation on [-6, 6] -- torch's own fp32 gelu sits at 1.2e-6).  The library
+// erff() is two divergent branches per element, ~2.5x the vector instructions, and fp32 VALU work is additive to the MFMAs around it.
+__device__ __forceinline__ float erf_f(float x) {
+  x = fminf(fmaxf(x, -4.f), 4.f);
+  const float x2 = x * x;
+  float p = -2.72614225801306e-10f, q = -1.45660718464996e-05f;
+  p = fmaf(p, x2, 2.77068142495902e-08f);   q = fmaf(q, x2, -2.13374055278905e-04f);
+  p = fmaf(p, x2, -2.10102402082508e-06f);  q = fmaf(q, x2, -1.68282697438203e-03f);
+  p = fmaf(p, x2, -5.69250639462346e-05f);  q = fmaf(q, x2, -7.37332916720468e-03f);
+  p = fmaf(p, x2, -7.34990630326855e-04f);  q = fmaf(q, x2, -1.42647390514189e-02f);
+  p = fmaf(p, x2, -2.95459980854025e-03f);
+  p = fmaf(p, x2, -1.60960333262415e-02f);
+  return x * p * __builtin_amdgcn_rcpf(q);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_f(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float mish_f(float x) {
   // x * tanh(softplus(x)); F.softplus: beta=1, threshold=20 (wavenet.py:8-10)
   float sp = x > 20.f ? x : log1pf(expf(x));
   return x * tanhf(sp);
+}
+
+// An epilogue may offer `load_late` beside `load`: the variant for kernels that read the epilogue operands at store time (the no-split path),
+// where wave-uniform `if (operand)` branches are cheaper than the branch-free form the split-K prefetch needs.
+template <class E, class = void> struct epi_has_load_late : std::false_type {};
+template <class E> struct epi_has_load_late<E, std::void_t<decltype(&E::load_late)>> : std::true_type {};
+template <class E>
+__device__ __forceinline__ typename E::Pre epi_load_late(const E& e, int b, int row, int t, bool two) {
+  if constexpr (epi_has_load_late<E>::value) return e.load_late(b, row, t, two);
+  else return e.load(b, row, t, two);
 }
 
 struct EpiBias {  // out = act(acc + bias[row]); masked columns -> 0; optional out2 = out + sb[row]
@@ -507,7 +533,20 @@ struct EpiResblock {  // models.py:103-110 conv2: x = xt + x; plus the MRF mean 
   int mode;     // 0: out = v    1: out += v    2: out = (out + v) / div
   float div;
   struct Pre { f2 res, old; float bias; };
+  // Branch-free (see EpiBias::load): rows past M are clamped, an absent operand reads a pair of the bias vector instead (cached, ignored
+  // by store()).  With `if (resid) .. if (mode != 0) ..` here hipcc put an s_waitcnt vmcnt(0) behind each conditional load: the split-K
+  // kernel's eight epilogue sites became eight serial round trips in front of the K loop on every launch that accumulates (mode != 0).
   __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p;
+    const int r = min(row, M - 1);
+    const long o = b * bs + (long)r * ld + t;
+    const float* dummy = bias + (r & ~1);
+    p.bias = bias[r];
+    p.res = ld2(resid ? resid + o : dummy, two);
+    p.old = ld2(mode != 0 ? out + o : dummy, two);
+    return p;
+  }
+  __device__ __forceinline__ Pre load_late(int b, int row, int t, bool two) const {
     Pre p{f2{0.f, 0.f}, f2{0.f, 0.f}, 0.f};
     if (row >= M) return p;
     const long o = b * bs + (long)row * ld + t;
@@ -980,7 +1019,7 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
           const int row = row_base + rb * 32 + acc_row(r, half);
-          epi.store(item, row, tc, col_two, f2{acc[rb][0][r], acc[rb][1][r]}, epi.load(item, row, tc, col_two));
+          epi.store(item, row, tc, col_two, f2{acc[rb][0][r], acc[rb][1][r]}, epi_load_late(epi, item, row, tc, col_two));
         }
       }
     }
