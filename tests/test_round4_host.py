@@ -194,3 +194,34 @@ def test_reference_caller_fixture_provenance():
     assert "\n".join(ln[indent:] for ln in lines) + "\n" == fx["source"]
     g = load("svc_caller")
     assert g["wav"].shape == (70 * 512,) and int(g["n_audio"]) // 512 == 70
+
+
+def test_branch_free_gelu_rational_is_fp32_class():
+    """`erf_f` / `gelu_f` in csrc/convgemm.hip.h (the GELU epilogue of ConvNext's pwconv1 and the transformer's linear1): the coefficients are
+    read from the header itself, evaluated in float32 the way the kernel does (Horner, fma order aside), and held to the accuracy the comment
+    there states -- erf within 5e-7 abs, GELU within 1.5e-6 abs of an fp64 evaluation on [-6, 6] (torch's own fp32 gelu: 1.2e-6)."""
+    import re
+    from scipy.special import erf
+    src = open(os.path.join(os.path.dirname(__file__), "..", "fish_diffusion_amd", "csrc", "convgemm.hip.h")).read()
+    body = src[src.index("float erf_f(float x) {"):src.index("float gelu_f(float x)")]
+    p0, q0 = (float(v) for v in re.search(r"float p = (\S+?)f, q = (\S+?)f;", body).groups())
+    ps = [p0] + [float(v) for v in re.findall(r"p = fmaf\(p, x2, (\S+?)f\);", body)]
+    qs = [q0] + [float(v) for v in re.findall(r"q = fmaf\(q, x2, (\S+?)f\);", body)]
+    assert len(ps) == 7 and len(qs) == 5
+
+    def erf32(x):
+        x = np.clip(x, -4, 4).astype(np.float32)
+        x2 = (x * x).astype(np.float32)
+        p = np.float32(ps[0]); q = np.float32(qs[0])
+        for c in ps[1:]:
+            p = (p * x2 + np.float32(c)).astype(np.float32)
+        for c in qs[1:]:
+            q = (q * x2 + np.float32(c)).astype(np.float32)
+        return (x * p / q).astype(np.float32)
+
+    x = np.linspace(-6, 6, 400001).astype(np.float32)
+    assert np.abs(erf32(x) - erf(x.astype(np.float64))).max() < 5e-7
+    g64 = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    g32 = (np.float32(0.5) * x * (1 + erf32((x * np.float32(0.70710678118654752440)).astype(np.float32)))).astype(np.float32)
+    assert np.abs(g32 - g64).max() < 1.5e-6
+    assert np.abs(torch.nn.functional.gelu(torch.from_numpy(x)).numpy() - g64).max() > 1.0e-6   # the bar is the reference's own fp32 class
