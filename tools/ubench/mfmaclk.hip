@@ -123,10 +123,49 @@ static void run(const f4* src, size_t region_bytes, float* sink, Stamp* stamps_d
   CHECK(hipEventDestroy(a)); CHECK(hipEventDestroy(b));
 }
 
+// Short launches in a chain (what the sampler's hipGraph is: 25 us kernels back to back): N launches on one stream, no host sync between
+// them; the effective clock of the waves of EVERY launch (d memtime / d memrealtime per wave, one stamp slot per launch) and the launch period.
+template <int MODE>
+static void run_chain(const f4* src, size_t region_bytes, float* sink, Stamp* stamps_d, int iters, int n_launch, const char* what) {
+  const int wgs = 256;
+  size_t groups = 1;
+  while (groups * 2 * 16 <= region_bytes) groups *= 2;
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  float ms = 0;
+  for (int it = 0; it < 2; ++it) {
+    CHECK(hipEventRecord(a));
+    for (int l = 0; l < n_launch; ++l)
+      hipLaunchKernelGGL((k_mfma<MODE>), dim3(wgs), dim3(256), 0, 0, src, groups, iters, sink, stamps_d + (size_t)l * wgs * 4);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    CHECK(hipEventElapsedTime(&ms, a, b));
+  }
+  std::vector<Stamp> st((size_t)n_launch * wgs * 4);
+  CHECK(hipMemcpy(st.data(), stamps_d, st.size() * sizeof(Stamp), hipMemcpyDeviceToHost));
+  double ghz = 0, ns = 0, ghz_first = 0, ghz_last = 0;
+  for (size_t i = 0; i < st.size(); ++i) {
+    const double g = double(st[i].c1 - st[i].c0) / double(st[i].r1 - st[i].r0) * 0.1;
+    ghz += g; ns += double(st[i].r1 - st[i].r0) * 10.0;
+    if (i < (size_t)wgs * 4) ghz_first += g;
+    if (i >= st.size() - (size_t)wgs * 4) ghz_last += g;
+  }
+  // span of one launch: first wave start -> last wave end (realtime), averaged over the launches; gap = period - span
+  double span = 0;
+  for (int l = 0; l < n_launch; ++l) {
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int w = 0; w < wgs * 4; ++w) { const Stamp& q = st[(size_t)l * wgs * 4 + w]; lo = q.r0 < lo ? q.r0 : lo; hi = q.r1 > hi ? q.r1 : hi; }
+    span += double(hi - lo) * 10.0;
+  }
+  printf("chain mode %d %-40s %4d launches  period %6.2f us  span %6.2f us  wave lifetime %6.2f us  clock %.3f GHz (first launch %.3f, last %.3f)\n", MODE, what,
+         n_launch, ms * 1e3 / n_launch, span / n_launch * 1e-3, ns / st.size() * 1e-3, ghz / st.size(), ghz_first / (wgs * 4), ghz_last / (wgs * 4));
+  CHECK(hipEventDestroy(a)); CHECK(hipEventDestroy(b));
+}
+
 int main(int argc, char** argv) {
   const size_t total = (size_t)64 << 20;
   f4* src; float* sink; Stamp* stamps;
-  CHECK(hipMalloc(&src, total)); CHECK(hipMalloc(&sink, 64)); CHECK(hipMalloc(&stamps, sizeof(Stamp) * 256 * 8 * 4));
+  CHECK(hipMalloc(&src, total)); CHECK(hipMalloc(&sink, 64)); CHECK(hipMalloc(&stamps, sizeof(Stamp) * 256 * 4 * 512));
   std::vector<float> h(total / 4);
   unsigned s = 12345;
   for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }   // random data: DVFS sees realistic toggling
@@ -138,6 +177,15 @@ int main(int argc, char** argv) {
     run<1>(src, 2 << 20, sink, stamps, w, 60000 * scale / w, "16x16x4 + 6 dwordx4 loads / 16 MFMA (L2, 2 MB)");
     run<2>(src, 2 << 20, sink, stamps, w, 60000 * scale / w, "same, 3 of 6 loads re-read a line (L1 hits)");
     run<1>(src, 48 << 20, sink, stamps, w, 60000 * scale / w, "same as mode 1, 48 MB region (MALL / HBM)");
+  }
+  // short launches back to back (the regime of the sampler's kernels: ~12 / ~25 us per launch)
+  if (argc > 2) {
+    run_chain<0>(src, 1 << 20, sink, stamps, 117, 400, "16x16x4 only, ~25 us launches");
+    run_chain<0>(src, 1 << 20, sink, stamps, 56, 400, "16x16x4 only, ~12 us launches");
+    run_chain<1>(src, 2 << 20, sink, stamps, 29, 400, "K-loop load mix (L2), ~25 us launches");
+    run_chain<1>(src, 48 << 20, sink, stamps, 29, 400, "K-loop load mix (48 MB), ~25 us launches");
+    run_chain<0>(src, 1 << 20, sink, stamps, 4680, 100, "16x16x4 only, ~1 ms launches");
+    return 0;
   }
   // the same MFMA-only loop on zero operands (the guide's DVFS note: zero data clocks higher)
   CHECK(hipMemset(src, 0, total));
