@@ -225,3 +225,28 @@ def test_branch_free_gelu_rational_is_fp32_class():
     g32 = (np.float32(0.5) * x * (1 + erf32((x * np.float32(0.70710678118654752440)).astype(np.float32)))).astype(np.float32)
     assert np.abs(g32 - g64).max() < 1.5e-6
     assert np.abs(torch.nn.functional.gelu(torch.from_numpy(x)).numpy() - g64).max() > 1.0e-6   # the bar is the reference's own fp32 class
+
+
+def test_ragged_noise_scatter_matches_the_per_item_copies():
+    """`GaussianDiffusion._ragged_scatter` (one gather + one index_copy per chunk) against the per-step, per-item copies it replaced."""
+    from fish_diffusion_amd.diffusion import GaussianDiffusion
+    g = torch.Generator().manual_seed(3)
+    lens, T, M, c, gap = [70, 33, 64, 1], 70, 5, 4, 16
+    offs, cur = [], 0
+    for n in lens:
+        offs.append(cur)
+        cur += n + gap
+    Tc = cur
+    src = torch.randn(c, len(lens), M, T, generator=g)
+    want = torch.zeros(c, M, Tc)
+    for i in range(c):
+        for b, (o, n) in enumerate(zip(offs, lens)):
+            want[i, :, o:o + n] = src[i, b, :, :n]
+    cols, flat = GaussianDiffusion._ragged_index(offs, lens, T, torch.device("cpu"))
+    got = torch.zeros(c, 1, M, Tc)
+    GaussianDiffusion._ragged_scatter(got[:, 0], src, cols, flat)
+    assert torch.equal(got[:, 0], want)
+    one = torch.zeros(c, 1, M, Tc)
+    for i in range(c):
+        GaussianDiffusion._ragged_scatter(one[i:i + 1, 0], src[i][None], cols, flat)
+    assert torch.equal(one, got)
