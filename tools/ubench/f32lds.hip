@@ -92,6 +92,11 @@ __global__ __launch_bounds__(128 * NKQ, (NKQ * NST <= 6) ? 2 : 1) void k_f32lds(
       float av[16], bv[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) { av[ks] = la[ks * 64]; bv[ks] = lb[ks * 128]; }
+#ifndef F32LDS_NO_SCHED_BARRIER
+      // all 16 fragment reads are in flight before the first MFMA: left alone, hipcc sinks each B read next to its use and waits lgkmcnt(0) in
+      // front of every MFMA pair (one exposed LDS latency per 128 MFMA cycles -- what the first three cuts measured)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int ks = 0; ks < 16; ks += 2) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc, 0, 0, 0);
