@@ -532,6 +532,9 @@ struct EpiResblock {  // models.py:103-110 conv2: x = xt + x; plus the MRF mean 
   const float* bias; int M;
   int mode;     // 0: out = v    1: out += v    2: out = (out + v) / div
   float div;
+  // leaky-relu slope applied to the residual as it is added (1 = the plain `xt + x` of ResBlock1).  ResBlock2's `F.leaky_relu(x, .., inplace=True)`
+  // (models.py:152) rewrites x before `xt + x` (:154): its residual is the ACTIVATED x.  x * 1.f is exact, so one code path serves both.
+  float rslope = 1.f;
   struct Pre { f2 res, old; float bias; };
   // Branch-free (see EpiBias::load): rows past M are clamped, an absent operand reads a pair of the bias vector instead (cached, ignored
   // by store()).  With `if (resid) .. if (mode != 0) ..` here hipcc put an s_waitcnt vmcnt(0) behind each conditional load: the split-K
@@ -558,7 +561,7 @@ struct EpiResblock {  // models.py:103-110 conv2: x = xt + x; plus the MRF mean 
   __device__ __forceinline__ void store(int b, int row, int t, bool two, f2 v, const Pre& p) const {
     if (row >= M) return;
     v += p.bias;
-    if (resid) v += p.res;
+    if (resid) v += f2{p.res.x > 0.f ? p.res.x : p.res.x * rslope, p.res.y > 0.f ? p.res.y : p.res.y * rslope};
     if (mode == 1) v = p.old + v;
     else if (mode == 2) v = (p.old + v) / div;
     st2p(out + b * bs + (long)row * ld + t, v, two);

@@ -397,8 +397,13 @@ extern "C" int fdx_nsf_forward(fdx_handle h, const float* mel, const float* f0, 
           eo.resid = cur; eo.bias = A + st.c2[j * nd + q].b_off;
           FDX_HIP(h, (run_conv<true>(A, st.c2[j * nd + q], B, g.L, Tm, bs, g.ld, -(k - 1) / 2, 1, 0.1f, eo, s, &h->prof, PROF_NSF_RESBLOCK)));
         } else {
-          eo.resid = cur; eo.bias = A + st.c1[j * nd + q].b_off;
-          FDX_HIP(h, (run_conv<true>(A, st.c1[j * nd + q], B, g.L, cur, bs, g.ld, -(k - 1) / 2 * dil, dil, 0.1f, eo, s, &h->prof, PROF_NSF_RESBLOCK)));
+          // ResBlock2 (models.py:150-155) activates x IN PLACE (:152): the residual of `xt + x` is leaky_relu(x), and the first iteration
+          // rewrites the tensor Generator.forward hands to the next ResBlock2 of the stage (:426-431) -- block j starts from leaky_relu
+          // applied j times.  Same values without the extra pass over U: block j's first conv reads U through the slope 0.1^(j+1).
+          float slope = 0.1f;
+          if (q == 0) for (int r = 0; r < j; ++r) slope *= 0.1f;
+          eo.resid = cur; eo.rslope = slope; eo.bias = A + st.c1[j * nd + q].b_off;
+          FDX_HIP(h, (run_conv<true>(A, st.c1[j * nd + q], B, g.L, cur, bs, g.ld, -(k - 1) / 2 * dil, dil, slope, eo, s, &h->prof, PROF_NSF_RESBLOCK)));
         }
         cur = R;
       }

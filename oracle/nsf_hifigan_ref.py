@@ -119,9 +119,12 @@ def _resblock1(sd: SD, n: int, x, k: int, dils):
 
 
 def _resblock2(sd: SD, n: int, x, k: int, dils):
-    """models.py:150-155."""
+    """models.py:150-155.  The reference's ``F.leaky_relu(x, LRELU_SLOPE, inplace=True)`` (:152) rewrites ``x`` itself, so (a) the residual
+    ``xt + x`` (:154) adds the ACTIVATED x, and (b) the first iteration rewrites the CALLER's tensor: in ``Generator.forward`` (:426-431)
+    the same ``x`` is handed to the next ResBlock2 of the stage, which therefore starts from ``leaky_relu(x)``, the third from
+    ``leaky_relu(leaky_relu(x))``.  Restated with the same in-place op so the caller sees it too (pinned: make_golden round5)."""
     for j, d in enumerate(dils):
-        xt = F.leaky_relu(x, 0.1)
+        xt = F.leaky_relu(x, 0.1, inplace=True)          # xt IS x from here on
         xt = F.conv1d(xt, sd[f"resblocks.{n}.convs.{j}.weight"], sd[f"resblocks.{n}.convs.{j}.bias"],
                       dilation=d, padding=int((k * d - d) / 2))
         x = xt + x
