@@ -216,7 +216,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3 };
 
 // nn.GELU() (exact, erf form): 0.5 * x * (1 + erf(x / sqrt(2)))
 // GELU (erf form, F.gelu's default): erf as one branch-free rational x P(x^2) / Q(x^2) on [-4, 4] (the fp32 fit Eigen / XLA use; 4.4e-7
-// max abs error on erf, GELU within 1.4e-6 abs of an fp64 evaluation on [-6, 6] -- torch's own fp32 gelu sits at 1.2e-6).  The library
+// max abs error on erf, GELU within 1.4e-6 abs of an fp64 evaluation on [-6, 6] and exactly 0 / x beyond the clamp (tested to +-1e4) -- torch's own fp32 gelu sits at 1.2e-6).  The library
 // erff() is two divergent branches per element, ~2.5x the vector instructions, and fp32 VALU work is additive to the MFMAs around it.
 __device__ __forceinline__ float erf_f(float x) {
   x = fminf(fmaxf(x, -4.f), 4.f);
@@ -228,7 +228,10 @@ __device__ __forceinline__ float erf_f(float x) {
   p = fmaf(p, x2, -7.34990630326855e-04f);  q = fmaf(q, x2, -1.42647390514189e-02f);
   p = fmaf(p, x2, -2.95459980854025e-03f);
   p = fmaf(p, x2, -1.60960333262415e-02f);
-  return x * p * __builtin_amdgcn_rcpf(q);
+  // exactly +-1 at the clamp (erf(4) rounds to 1 in fp32): the approximate reciprocal can leave the rational 1e-7 off 1 there, and gelu's
+  // 0.5 x (1 + erf) would then grow like 1e-7 |x| in the negative tail instead of reaching 0
+  const float r = x * p * __builtin_amdgcn_rcpf(q);
+  return x2 >= 16.f ? copysignf(1.f, x) : r;
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_f(x * 0.70710678118654752440f)); }
 

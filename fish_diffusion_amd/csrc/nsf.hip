@@ -99,7 +99,13 @@ static void nsf_layout(const fdx_nsf_desc& d, NsfLayout& l) {
   for (int i = 0; i < d.n_stages; ++i) {
     NsfStage& st = l.stages[i];
     st.fused = d.resblock_type == 1 && d.n_dilations == kRbPairs && rb_fused_wins(st.cout);
-    for (int j = 0; j < d.n_resblock_kernels; ++j) st.fused = st.fused && rb_fused_supported(st.cout, d.resblock_kernel_sizes[j]);
+    for (int j = 0; j < d.n_resblock_kernels && st.fused; ++j) {
+      // with the CONFIGURED dilations: the six convs' halo has to leave at least 64 owned columns in the LDS window, otherwise conv by conv
+      int d1[kRbPairs], d2[kRbPairs];
+      for (int q = 0; q < kRbPairs; ++q) { d1[q] = d.resblock_dilations[j][q]; d2[q] = 1; }
+      const int H4 = (rb_halo(d.resblock_kernel_sizes[j], d1, d2) + 3) & ~3;
+      st.fused = rb_fused_supported(st.cout, d.resblock_kernel_sizes[j]) && rb_pick_n(st.cout, H4, 1L << 20, 1) > 0;
+    }
     st.fw.clear(); st.fb.clear();
     if (!st.fused) continue;
     for (int j = 0; j < d.n_resblock_kernels; ++j) {
@@ -368,7 +374,9 @@ extern "C" int fdx_nsf_forward(fdx_handle h, const float* mel, const float* f0, 
     launch_noise_conv(U, bs, g.ld, har, (long)ldL, A + st.nc_w, A + st.nc_b, st.cout, g.L, st.nc_k, st.nc_stride, st.nc_pad, B, s);
     for (int j = 0; j < nk; ++j) {
       const int k = d.resblock_kernel_sizes[j];
-      if (st.fused && nsf_fused_enabled()) {   // small-channel stage: the whole ResBlock1 (six convs) out of LDS in one launch
+      // small-channel stage: the whole ResBlock1 (six convs) out of LDS in one launch.  The kernel moves 16-byte groups (window origin, L and
+      // the row pitch multiples of 4): a geometry that is not (an odd product of upsample rates) takes the per-conv path, not an error.
+      if (st.fused && nsf_fused_enabled() && g.L % 4 == 0 && g.ld % 4 == 0) {
         RbFusedArgs fa{};
         fa.X = U; fa.x_bs = bs; fa.ldx = g.ld; fa.out = XS; fa.o_bs = bs; fa.ldo = g.ld;
         fa.W = A + st.fw[j]; fa.bias = A + st.fb[j]; fa.L = g.L;

@@ -250,7 +250,7 @@ class GaussianDiffusion(nn.Module):
         if noise_predictor not in schedule.KINDS:
             raise NotImplementedError(f"Unknown noise predictor: {noise_predictor}")
         if not isinstance(self.denoise_fn, HipDenoiser):
-            raise NotImplementedError("the MI355X sampler loop drives the HIP denoisers (WaveNetDenoiser, ConvNextDenoiser) only")
+            raise NotImplementedError("the MI355X sampler loop drives the HIP denoisers (WaveNetDenoiser, ConvNextDenoiser, TransformerDecoderDenoiser) only")
         _lib.require_gpu(features, "GaussianDiffusion features")
         device = features.device
         cond = features.transpose(1, 2)
@@ -276,7 +276,7 @@ class GaussianDiffusion(nn.Module):
         kind, table = self._sampler_table(noise_predictor, sampler_interval, skip_steps)
         n_rows = table.shape[0]
         if step_noise is not None:
-            step_noise = step_noise.to(torch.float32).contiguous()
+            step_noise = step_noise.to(device=device, dtype=torch.float32).contiguous()   # a host tensor is accepted (it crosses the ABI as a device pointer)
             if kind == _lib.SAMPLER_NAIVE and tuple(step_noise.shape) != (n_rows, B, M, T):
                 raise ValueError(f"step_noise must be {(n_rows, B, M, T)}, got {tuple(step_noise.shape)}")
         xm = None if x_masks is None else x_masks.to(torch.uint8).contiguous()

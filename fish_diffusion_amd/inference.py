@@ -7,8 +7,9 @@
 * `load_checkpoint(config, checkpoint, device, model_cls)` -- `fish_diffusion/utils/inference.py:6-32`: `torch.load`, unwrap the Lightning
   `"state_dict"`, drop `vocoder.*`, `load_state_dict(strict=False)`, `.to(device)`, `.eval()` -- PLUS the coverage assertion SURVEY
   section 7 asked for: the reference's `strict=False` lets a checkpoint with a missing `denoise_fn.*` / encoder key load silently onto
-  random initialisation.  Here every parameter and persistent buffer of `model.*` (and of `ema_model.*` when the config builds one) must
-  have come from the checkpoint, otherwise `KeyError` names what is missing (`allow_missing=True` restores the reference's behaviour).
+  random initialisation.  Here every parameter and every data-carrying buffer (`spec_min` / `spec_max`, `positional_embedding`) of `model.*`
+  (and of `ema_model.*` when the config builds one) must have come from the checkpoint, otherwise `KeyError` names what is missing
+  (`allow_missing=True` restores the reference's behaviour); schedule buffers the constructor derives from the config only warn.
 * `inference_model(m)` -- the `ema_model` preference of `SVCInference.forward` (tools/diffusion/inference.py:134-138).
 """
 from __future__ import annotations
@@ -66,15 +67,46 @@ def inference_model(m: nn.Module) -> nn.Module:
     return m.ema_model if hasattr(m, "ema_model") else m.model
 
 
+# Buffers `__init__` recomputes from the config alone (diffusion.py:81-90, noise_predictor.py:29-71,115): a reference checkpoint saved without
+# them loads and runs correctly under the reference's strict=False, so their absence is reported, not fatal.  Everything else -- every parameter,
+# and the buffers that carry data (`spec_min` / `spec_max`, `positional_embedding`) -- must come from the checkpoint.
+_SCHEDULE_BUFFERS = ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod")
+
+
+def _is_schedule_buffer(key: str) -> bool:
+    if ".diffusion." not in "." + key:
+        return False
+    tail = key.split("diffusion.", 1)[1]
+    return tail in _SCHEDULE_BUFFERS or tail.startswith(("naive_noise_predictor.", "plms_noise_predictor."))
+
+
 def _uncovered(model: nn.Module, loaded: Iterable[str]) -> list:
     have = set(loaded)
     return sorted(k for k in model.state_dict() if not k.startswith("vocoder.") and k not in have)
 
 
-def load_checkpoint(config, checkpoint, device="cuda", model_cls=SVCModel, allow_missing: bool = False, report: Optional[dict] = None):
+def _torch_load(path: str, weights_only: Optional[bool]):
+    """The reference's environment (torch < 2.6) unpickles whatever a Lightning `.ckpt` holds; torch >= 2.6 defaults to `weights_only=True`
+    and refuses optimizer / callback state with non-allowlisted classes.  `None`: try the safe loader first and fall back to the full
+    unpickler WITH a warning (a checkpoint is code: only load files you trust); `True` / `False`: exactly that."""
+    if weights_only is not None:
+        return torch.load(path, map_location="cpu", weights_only=weights_only)
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:  # pickle.UnpicklingError and friends
+        import warnings
+        warnings.warn(f"{path}: the weights-only loader refused this checkpoint ({type(e).__name__}: {str(e).splitlines()[0][:120]}); "
+                      "falling back to the full unpickler as the reference's torch.load does -- pass weights_only=True to forbid this")
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_checkpoint(config, checkpoint, device="cuda", model_cls=SVCModel, allow_missing: bool = False, report: Optional[dict] = None,
+                    weights_only: Optional[bool] = None):
     """utils/inference.py:6-32 with key-coverage checking.  `checkpoint`: a path (file, or a directory whose naturally-sorted last
     entry is taken, tools/diffusion/inference.py:67-74) or an already loaded dict.  `report`, if given, receives
-    {"missing": [...], "unexpected": [...], "loaded": n}."""
+    {"missing": [...], "missing_schedule_buffers": [...], "unexpected": [...], "loaded": n}.  Missing PARAMETERS or data buffers raise
+    `KeyError` unless `allow_missing`; missing config-derived schedule buffers (which `__init__` has already computed from the config)
+    only warn -- the sampler then runs on the config's schedule, as the reference would."""
     model = model_cls(config)
     if isinstance(checkpoint, (str, os.PathLike)):
         path = os.fspath(checkpoint)
@@ -84,20 +116,26 @@ def load_checkpoint(config, checkpoint, device="cuda", model_cls=SVCModel, allow
             if not names:
                 raise FileNotFoundError(f"no checkpoints under {path}")
             path = os.path.join(path, names[-1])
-        state_dict = torch.load(path, map_location="cpu")
+        state_dict = _torch_load(path, weights_only)
     else:
         state_dict = checkpoint
     if "state_dict" in state_dict:          # saved by Lightning
         state_dict = state_dict["state_dict"]
     state_dict = {k: v for k, v in state_dict.items() if not k.startswith("vocoder.")}
     result = model.load_state_dict(state_dict, strict=False)
-    missing = _uncovered(model, state_dict.keys())
+    uncovered = _uncovered(model, state_dict.keys())
+    sched = [k for k in uncovered if _is_schedule_buffer(k)]
+    missing = [k for k in uncovered if not _is_schedule_buffer(k)]
     if report is not None:
-        report.update(missing=missing, unexpected=sorted(result.unexpected_keys), loaded=len(state_dict) - len(result.unexpected_keys))
+        report.update(missing=missing, missing_schedule_buffers=sched, unexpected=sorted(result.unexpected_keys),
+                      loaded=len(state_dict) - len(result.unexpected_keys))
+    if sched:
+        import warnings
+        warnings.warn(f"checkpoint carries no schedule buffers ({sched[0]}, ... {len(sched)} keys): using the ones computed from the config")
     if missing and not allow_missing:
         shown = ", ".join(missing[:8]) + (f", ... ({len(missing)} keys)" if len(missing) > 8 else "")
-        raise KeyError("checkpoint does not cover the model: " + shown + " -- the reference loads with strict=False and would run these on random "
-                       "initialisation; pass allow_missing=True for that behaviour")
+        raise KeyError("checkpoint does not cover the model: " + shown + " -- the reference loads with strict=False and would leave these "
+                       "at their constructor values (random initialisation for weights); pass allow_missing=True for that behaviour")
     model.to(device)
     model.eval()
     return model

@@ -110,8 +110,8 @@ int fdx_wavenet_forward(fdx_handle h, const float* x, const float* t, int n_t, c
                         float* eps, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
- * ConvNext denoiser -- replaces fish_diffusion/modules/convnext.py:155-262 (class ConvNext,
- * cross_attention=False; blocks :12-92), DENOISERS "ConvNextDenoiser"
+ * ConvNext denoiser -- replaces fish_diffusion/modules/convnext.py:155-262 (class ConvNext, with or
+ * without cross-attention; blocks :12-92, :95-152), DENOISERS "ConvNextDenoiser"
  * (archs/diffsinger/diffusions/builder.py:12).  Same call contract as the WaveNet: whichever of
  * fdx_wavenet_prepare / fdx_convnext_prepare ran last selects the denoiser fdx_sampler_run drives.
  * ---------------------------------------------------------------------------------------------- */
@@ -122,7 +122,8 @@ typedef struct fdx_convnext_desc {
   int condition_dim;   /* 256; multiple of 8 */
   int num_layers;      /* 20 */
   int dilation_cycle;  /* 4 (dilations 2^(i % cycle), convnext.py:200) */
-  int cross_attention; /* must be 0: the cross-attention blocks (convnext.py:95-152) are not built */
+  int cross_attention; /* 0 = off; n > 0 = `cross_every_n_layers` of the reference: a CrossAttentionBlock (convnext.py:95-152,186-193) in
+                        * front of every n-th ConvNext block, its tensors in the module's state_dict order (csrc/convnext.hip:47-93) */
 } fdx_convnext_desc;
 /* Canonical tensor order = the module's state_dict order (convnext.py:170-205): input_projection.{weight,bias},
  * diffusion_embedding.{1,3}.{weight,bias}, conditioner_projection.{0,2}.{weight,bias}, per layer gamma,

@@ -217,8 +217,16 @@ def test_branch_free_gelu_rational_is_fp32_class():
             p = (p * x2 + np.float32(c)).astype(np.float32)
         for c in qs[1:]:
             q = (q * x2 + np.float32(c)).astype(np.float32)
-        return (x * p / q).astype(np.float32)
+        r = ((x * p / q).astype(np.float32) * np.float32(rcp_err)).astype(np.float32)                   # v_rcp_f32 is good to 1 ulp
+        return np.where(x2 >= 16, np.copysign(np.float32(1), x), r).astype(np.float32)
 
+    assert "return x2 >= 16.f ? copysignf(1.f, x) : r;" in body
+    # the tails: with the result clamped, gelu is exactly 0 / x beyond the input clamp whatever the reciprocal's last bit does
+    for rcp_err in (1 - 2.0 ** -22, 1.0, 1 + 2.0 ** -22):
+        xt = np.concatenate([np.linspace(-1e4, -5.66, 20001), np.linspace(5.66, 1e4, 20001)]).astype(np.float32)
+        gt = (np.float32(0.5) * xt * (1 + erf32((xt * np.float32(0.70710678118654752440)).astype(np.float32)))).astype(np.float32)
+        assert np.all(gt[xt < 0] == 0) and np.all(gt[xt > 0] == xt[xt > 0]), rcp_err
+    rcp_err = 1.0
     x = np.linspace(-6, 6, 400001).astype(np.float32)
     assert np.abs(erf32(x) - erf(x.astype(np.float64))).max() < 5e-7
     g64 = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))

@@ -46,3 +46,42 @@ def test_slaney_filterbank_against_third_party_table(lib_built):
         assert np.abs(ours - hf).max() < 5e-7 * peak, n_fft
         prod = PitchAdjustableMelSpectrogram(n_fft=n_fft, win_length=n_fft).filterbank().numpy()
         assert prod.shape == hf.shape and np.abs(prod - hf).max() < 5e-7 * peak, n_fft
+
+
+# ------------------------------------------------------------------------------------------------ load_checkpoint
+class _Opaque:                       # a class the weights-only unpickler does not allow-list (stands in for optimizer / callback state)
+    def __init__(self):
+        self.lr = 1e-3
+
+
+def test_load_checkpoint_schedule_buffers_warn_and_full_unpickler_fallback(lib_built, tmp_path):
+    """A reference checkpoint saved without the predictor sub-modules' buffers loads in the reference (strict=False) and samples with the
+    schedule `__init__` computes from the config: here that is a warning + `report["missing_schedule_buffers"]`, while a missing weight or
+    `spec_min` still raises.  A Lightning file whose extra state needs the full unpickler loads with a warning unless `weights_only=True`."""
+    from fish_diffusion_amd.inference import SVCModel, load_checkpoint
+    from oracle import features_ref
+    from tests.helpers import WN_SMALL, wavenet_sd
+    from tests.test_round4_host import lightning_checkpoint, svc_config
+    cfg = svc_config(tmp_path)
+    ck = lightning_checkpoint(SVCModel(cfg), features_ref.seeded_frontend_state(81), features_ref.seeded_frontend_state(82),
+                              wavenet_sd(WN_SMALL, 83), wavenet_sd(WN_SMALL, 84))
+    sd = ck["state_dict"]
+    no_sched = {k: v for k, v in sd.items() if "noise_predictor." not in k and not k.endswith(("diffusion.betas", "alphas_cumprod"))}
+    assert len(no_sched) < len(sd)
+    rep = {}
+    with pytest.warns(UserWarning, match="schedule buffers"):
+        m = load_checkpoint(cfg, {"state_dict": no_sched}, device="cpu", report=rep)
+    assert rep["missing"] == [] and len(rep["missing_schedule_buffers"]) == len(sd) - len(no_sched)
+    ref = SVCModel(cfg)
+    assert torch.equal(m.model.diffusion.naive_noise_predictor.posterior_mean_coef1, ref.model.diffusion.naive_noise_predictor.posterior_mean_coef1)
+    no_spec = {k: v for k, v in sd.items() if not k.endswith("spec_min")}
+    with pytest.raises(KeyError, match="spec_min"):
+        load_checkpoint(cfg, {"state_dict": no_spec}, device="cpu")
+    # non-allowlisted object beside the weights
+    torch.save({"state_dict": sd, "callbacks": {"x": _Opaque()}}, tmp_path / "opaque.ckpt")
+    with pytest.raises(Exception):
+        load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu", weights_only=True)
+    with pytest.warns(UserWarning, match="full unpickler"):
+        m2 = load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu", report=rep)
+    assert rep["missing"] == [] and rep["missing_schedule_buffers"] == []
+    assert torch.equal(m2.model.text_encoder.projection.weight, sd["model.text_encoder.projection.weight"])
