@@ -578,8 +578,9 @@ def build_work(cfg, args, dev, rank, world, n_total, extra=False):
         f0s = [synth_f0(n).to(dev) for n in lens]
         mine = fdist.shard_utterances(lens, vrank, vworld)
         batches = pipeline.make_batches([lens[i] for i in mine], 8, padding_free=exact)
+        w.failures = []      # (utterance id, reason) of this rank: the serving loop isolates failures per utterance (pipeline.synthesize on_error)
         w.step = lambda k: pipeline.synthesize(diff, voc, feats, f0s, max_batch=8, sampler_interval=interval, rank=vrank, world=vworld,
-                                               exact=exact)
+                                               exact=exact, on_error="isolate", failures=w.failures)
         frames = sum(lens[i] for i in mine)
         w.lens, w.mine = lens, mine
         w.audio_s = frames * hop / 44100.0
@@ -748,6 +749,8 @@ def measure(w, steps, warmup, args, dev, do_prof, sclk=False):
     per_rank = fdist.gather_stats([(t_local - t0) / steps * 1e3, w.audio_s, float(w.cfg_extra.get("frames_this_rank", w.B * w.T)),
                                    float(w.cfg_extra.get("utterances_this_rank", w.B))], dev)   # [world, 4]
     dt = fdist.barrier_max(dt, dev)
+    if getattr(w, "failures", None) is not None:      # which utterances the job lost, over all ranks (none, on synthetic input)
+        w.cfg_extra["failed_utterances"] = fdist.gather_failed(sorted({i for i, _ in w.failures}), dev)
     del out
     roofline = None
     if do_prof:

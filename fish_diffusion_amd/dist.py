@@ -177,6 +177,28 @@ def gather_stats(values: Sequence[float], device: torch.device) -> torch.Tensor:
     return torch.stack(out).cpu()
 
 
+def gather_failed(failed: Sequence[int], device: torch.device) -> List[int]:
+    """Every rank's failed utterance ids -> the sorted union, on every rank (the reference's workers each log their own failures and the
+    parent only sees exit codes, tools/preprocessing/extract_features.py:298-305; here the job's result says WHICH utterances are missing).
+    Two small collectives (counts, then ids padded to the longest list); works over RCCL with device tensors and over gloo with CPU ones."""
+    ids = sorted(int(i) for i in failed)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return ids
+    world = dist.get_world_size()
+    n = torch.tensor([len(ids)], dtype=torch.int64, device=device)
+    counts = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    m = max(int(c.item()) for c in counts)
+    if m == 0:
+        return []
+    mine = torch.full((m,), -1, dtype=torch.int64, device=device)
+    if ids:
+        mine[:len(ids)] = torch.tensor(ids, dtype=torch.int64, device=device)
+    rows = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    return sorted({int(v) for r, c in zip(rows, counts) for v in r[:int(c.item())].tolist()})
+
+
 def sum_over_ranks(value: float, device: torch.device) -> float:
     """SUM over ranks of a scalar (fp64)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

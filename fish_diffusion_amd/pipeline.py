@@ -80,7 +80,8 @@ def make_batches(lengths: Sequence[int], max_batch: int, max_pad_ratio: Optional
 def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequence[torch.Tensor], *, max_batch: int = 8,
                sampler_interval: Optional[int] = None, noise_predictor: Optional[str] = None, rank: int = 0, world: int = 1,
                mel_scale: Optional[float] = None, x_init_fn: Optional[Callable] = None,
-               source_noise_fn: Optional[Callable] = None, bucket: int = 64, exact: Optional[bool] = None) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
+               source_noise_fn: Optional[Callable] = None, bucket: int = 64, exact: Optional[bool] = None,
+               on_error: str = "raise", failures: Optional[list] = None) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
     """features[i]: [T_i, E] device tensors; f0s[i]: [T_i].  Returns [(index, mel [T_i, M], wav [T_i * hop])] for the
     utterances this rank owns.  `x_init_fn(idx_list, M, T)` / `source_noise_fn(idx_list, L)` let tests inject the random
     draws (initial x_T; (rand_ini, src_noise)) -- by default they are drawn on the device.  `bucket`: every micro-batch is padded
@@ -93,13 +94,44 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     denoisers have no exact-mask kernels: an explicit `exact=True` raises NotImplementedError from the library, the default picks the
     reference's masked batches there).  False: the reference's own padded-batch semantics with x_masks /
     cond_masks (the masked tail stays alive inside the receptive field: the last ~75 frames of every padded item differ slightly
-    from a run alone)."""
+    from a run alone).
+    `on_error`: "raise" (default) lets the first exception out, as a plain loop would.  "isolate" is the reference's `safe_process`
+    (tools/preprocessing/extract_features.py:175-217: one bad file is logged and the worker carries on): an utterance that fails validation
+    is skipped; a micro-batch that raises is re-run one member at a time so that a bad member does not cost its batch-mates; whatever
+    still fails alone is appended to `failures` as `(index, "ExcType: message")` and left out of the result.  The ids are this rank's;
+    `dist.gather_failed` collects every rank's (the reference counts `failed` per worker, :298-305)."""
+    if on_error not in ("raise", "isolate"):
+        raise ValueError('on_error must be "raise" or "isolate"')
     if len(features) != len(f0s):
         raise ValueError("features and f0s must have the same length")
-    lengths = [int(f.shape[0]) for f in features]
+    if failures is None:
+        failures = []
+    lengths = [int(f.shape[0]) if hasattr(f, "shape") and len(f.shape) >= 1 else 0 for f in features]
     mine = fdist.shard_utterances(lengths, rank, world)
     if not mine:
         return []
+
+    def invalid(i) -> Optional[str]:
+        f, p = features[i], f0s[i]
+        if not torch.is_tensor(f) or f.dim() != 2 or f.shape[0] == 0:
+            return f"features must be a non-empty [T, E] tensor, got {tuple(f.shape) if torch.is_tensor(f) else type(f).__name__}"
+        if not torch.is_tensor(p) or p.dim() != 1 or p.shape[0] != f.shape[0]:
+            return f"f0 must be [T = {f.shape[0]}], got {tuple(p.shape) if torch.is_tensor(p) else type(p).__name__}"
+        if f.shape[1] != features[mine[0]].shape[1] and torch.is_tensor(features[mine[0]]) and features[mine[0]].dim() == 2:
+            return f"feature width {f.shape[1]} differs from the batch's {features[mine[0]].shape[1]}"
+        return None
+
+    if on_error == "isolate":
+        ok = []
+        for i in mine:
+            why = invalid(i)
+            if why is None:
+                ok.append(i)
+            else:
+                failures.append((i, "ValueError: " + why))
+        mine = ok
+        if not mine:
+            return []
     gen = vocoder.model if hasattr(vocoder, "model") else vocoder
     hop = gen.h["hop_size"]
     if mel_scale is None:   # nsf_hifigan.py:79-80: a log10 mel is rescaled to natural log
@@ -108,9 +140,7 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     if exact is None:
         den = getattr(diffusion, "denoise_fn", None)
         exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")
-    out = []
-    for group in make_batches([lengths[i] for i in mine], max_batch, padding_free=bool(exact)):
-        idx = [mine[g] for g in group]
+    def run_group(idx: List[int]) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
         T = max(lengths[i] for i in idx)
         if bucket and bucket > 1:
             T = (T + bucket - 1) // bucket * bucket
@@ -131,6 +161,7 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
         elif ragged:
             kw["x_masks"] = kw["cond_masks"] = masks
         mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
+        res = []
         for b, i in enumerate(idx):
             n = lengths[i]
             vkw = {}
@@ -138,5 +169,24 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
                 vkw["rand_ini"], vkw["src_noise"] = source_noise_fn([i], n * hop)
             m_i = mel[b, :n]
             wav = gen(m_i.T[None].contiguous(), f0[b:b + 1, :n].contiguous(), mel_scale=mel_scale, **vkw)[0, 0]   # [n*hop]
-            out.append((i, m_i, wav))
+            res.append((i, m_i, wav))
+        return res
+
+    def guarded(idx: List[int]) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
+        try:
+            return run_group(idx)
+        except Exception as e:   # noqa: BLE001 -- safe_process catches everything a single utterance can throw
+            if on_error == "raise":
+                raise
+            if len(idx) == 1:
+                failures.append((idx[0], f"{type(e).__name__}: {e}"))
+                return []
+            res = []
+            for i in idx:        # the batch failed as a whole: find the member(s) that fail alone, keep the others
+                res += guarded([i])
+            return res
+
+    out = []
+    for group in make_batches([lengths[i] for i in mine], max_batch, padding_free=bool(exact)):
+        out += guarded([mine[g] for g in group])
     return out
