@@ -509,12 +509,13 @@ struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) +
   float* X; long bs; int ld;                 // residual in, result out (in place), padded rows
   const float* bias; const float* gamma; int M;
   const uint8_t* mask; int mask_ld;
+  int bias_ld = 1, bias_bs = 0;              // bias of (row, item) at bias[row * bias_ld + item * bias_bs]: a per-item column of a [M][n] table
   struct Pre { f2 old; float bias, gamma; };   // (branch-free, mask read in store(): see EpiBias::load)
   __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
     Pre p;
     const int r = min(row, M - 1);
     p.old = ld2(X + b * bs + (long)r * ld + t, two);
-    p.bias = bias[r];
+    p.bias = bias[(long)r * bias_ld + b * bias_bs];
     p.gamma = *(gamma ? gamma + r : bias + r);                  // gamma == null: plain residual add x + (v + bias), see store()
     return p;
   }

@@ -200,7 +200,7 @@ struct CnBufs {
   DevBuf X, N, G, H2, condp, c1, c2, CP, ST;
   DevBuf c2raw, CP2;   // PLMS + cond_masks: condition / per-layer projections of the UNMASKED conditioner (diffusion.py:285)
   DevBuf E, Hm, S0, SB;
-  DevBuf QKV, O, MEM, KVc, KVc2, cmask;   // cross-attention variant: decoder-layer scratch; hoisted keys / values per cross block ([NC][2D] rows)
+  DevBuf QKV, O, MEM, KVc, KVc2, cmask, AP, AML;   // cross-attention variant: decoder-layer scratch; hoisted keys / values per cross block ([NC][2D] rows)
   int ldn = 0, n_emb = 0;
 };
 
@@ -360,6 +360,7 @@ extern "C" int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int 
     // condition + pos * scale_key (:137-141) is step-invariant -> its key / value projection is hoisted here
     if (T > kCnPositions) return fail(h, FDX_E_ARG, "fdx_convnext_prepare: %d frames exceed the positional table (%d)", T, kCnPositions);
     FDX_HIP(h, b.QKV.ensure(sz(3 * D), geom, s)); FDX_HIP(h, b.O.ensure(sz(D), geom, s)); FDX_HIP(h, b.MEM.ensure(sz(D), geom, s));
+    FDX_HIP(h, b.AP.ensure(attn_part_floats(B, T, D, ld) * sizeof(float), false, s)); FDX_HIP(h, b.AML.ensure(attn_ml_floats(B, T) * sizeof(float), false, s));
     FDX_HIP(h, b.KVc.ensure(sz(NC * 2 * D), geom, s));
     for (int c = 0; c < NC; ++c) {
       const auto& x = l.cross[c];
@@ -457,7 +458,7 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
       const auto& x = l.cross[c];
       hipLaunchKernelGGL(k_cn_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, X, X, bsD, ld, SB + (size_t)(L + c) * D * b.ldn, b.ldn, sb_bs,
                          A + l.pos, A + x.scale_q, D, T);
-      const DecScratch sc{b.QKV.f() + kHalo, b.O.f() + kHalo, G};
+      const DecScratch sc{b.QKV.f() + kHalo, b.O.f() + kHalo, G, b.AP.f() + kHalo, b.AML.f()};
       FDX_HIP(h, run_declayer(A, x.dec, B, T, D, H, ld, X, KVc + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, sc, mask, cmask, s));
     }
     const dim3 grid((T + 63) / 64, D / kCnCh, B);

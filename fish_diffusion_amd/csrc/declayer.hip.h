@@ -16,6 +16,7 @@ namespace fdx {
 namespace {
 
 constexpr int kHeads = 8;   // nn.TransformerDecoderLayer(nhead=8), convnext.py:300
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TdLayer {
   PackedW sa_in, sa_out, ca_q, ca_kv, ca_out, lin1, lin2;
@@ -126,7 +127,20 @@ struct AttnArgs {
   const uint8_t* kmask;                   // [B][Tk] bytes, 1 = key ignored (key_padding_mask), or null
   int Tq, Tk;
   float scale;                            // 1 / sqrt(DH)
+  // query-split kernel only (k_attn_qs): key range split over `ksplit` workgroups; split s leaves its un-normalised O^T at P + s * p_split
+  // (addressed like O) and its (max, sum) per query at ML[((s * B + b) * kHeads + h) * 2 + {0, 1}][TqR]
+  float* P; long p_split;
+  float* ML; int TqR;
+  int ksplit, B;
+#ifdef FDX_ATTN_TRACE
+  unsigned long long* trace;              // [workgroup][wave][8] shader-clock stamps (tools/ubench/attnqs.hip only)
+#endif
 };
+#ifdef FDX_ATTN_TRACE
+#define FDX_ATTN_STAMP(k) do { if (a.trace && lane == 0) a.trace[(((long)blockIdx.z * gridDim.x + blockIdx.x) * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FDX_ATTN_STAMP(k) do { } while (0)
+#endif
 
 // NQ = 32-query blocks per workgroup: 2 (64 queries) when that already fills the chip, 1 to double the workgroup count
 // Four waves (one per SIMD) split the key tiles.  (Eight waves = two per SIMD without the register prefetch: 41.5 us against 29.4, round 4.)
@@ -335,6 +349,320 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ attention, query-split (round 5)
+// Round 4's k_attn gives a workgroup 32 queries and lets its four waves split the KEY tiles: every wave streams its own K / V tiles from
+// global memory into registers, a workgroup reads the head's whole K and V (441 KB at T = 861) for 7 MFLOP, and the launch sits on the
+// global_load -> VGPR path (16 of the 18 B/clk/CU it delivers): 29 us, 33 % of the fp32 MFMA roof.  Here the four waves of a workgroup own
+// 32 QUERIES each and share every K / V tile through LDS (one cooperative 16-byte-per-lane fetch per tile, double-buffered, one barrier per
+// tile), so a tile is fetched once per 128 queries instead of once per 32; the chip is filled by splitting the KEY range over `ksplit`
+// workgroups (flash-decoding): each leaves (max, sum, un-normalised O^T) and k_attn_combine folds them in a fixed order.  Operand bytes per
+// workgroup: 110 KB of K / V + 32 KB of Q at T = 861 (was 441 + 8).  The softmax runs in base 2 (log2 e folded into the query scale).
+//   grid.x = kHeads * n_qblocks * ksplit with the HEAD in the low bits of the linear id: workgroup i lands on XCD i % 8, so head h's Q / K / V
+//   live in ONE XCD's L2 (8 heads, 8 XCDs) instead of in all eight.
+//   LDS per buffer: K tile as [ks][rb][half][n] (exactly the lane order of the score product's A operand: conflict-free ds_read_b32 pairs),
+//   V tile as [d][65] (the second product reads it transposed: stride 65 over the lanes of a half = 32 distinct banks).
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
+  constexpr int KS = DH / 2;                 // MFMA k-steps of the score product
+  constexpr int RBD = (DH + 31) / 32;        // 32-row blocks of O^T
+  constexpr int VLD = 65;
+  constexpr int KT = KS * 128, VT = DH * VLD;          // floats per staged K / V tile (64 keys)
+  constexpr int UPT = DH / 16;               // 16-byte fetch units per thread per operand tile (DH rows x 16 units / 256 threads)
+  __shared__ float lds[2 * (KT + VT)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, n = lane & 31;
+  const int lin = blockIdx.x;
+  const int h = lin % kHeads, j = lin / kHeads;
+  const int split = j % a.ksplit, qb = j / a.ksplit, b = blockIdx.z;
+  const int q0 = qb * 128 + wave * 32;
+  const int units = (a.Tk + 31) >> 5;        // 32-key units, dealt to the splits in balanced runs
+  const int u0 = (int)((long)units * split / a.ksplit), u1 = (int)((long)units * (split + 1) / a.ksplit);
+  const int kbeg = u0 * 32, kend = min(u1 * 32, a.Tk);
+  const int n_kt = (u1 - u0 + 1) >> 1;       // 64-key tiles; the last one may hold 32 keys
+  const float* Qh = a.Q + b * a.q_bs + (long)h * DH * a.ldq;
+  const float* Kh = a.K + b * a.k_bs + (long)h * DH * a.ldk;
+  const float* Vh = a.V + b * a.v_bs + (long)h * DH * a.ldv;
+  const float NEG = -__builtin_inff();
+  const bool has_mask = a.kmask != nullptr;
+  const uint8_t* mrow = has_mask ? a.kmask + (long)b * a.Tk : reinterpret_cast<const uint8_t*>(Kh);
+
+  // B operand of the score product: this lane's slice of Q for the whole launch, pre-multiplied by log2(e) / sqrt(DH).  The loads go out
+  // FIRST and the first K / V tile right behind them (pinned: hipcc sank the Q loads below the first barrier, two fabric round trips in a row)
+  FDX_ATTN_STAMP(0);
+  float qreg[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qreg[ks] = Qh[(long)(2 * ks + half) * a.ldq + min(q0 + n, a.Tq - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x16 o[RBD];
+#pragma unroll
+  for (int x = 0; x < RBD; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[x][r] = 0.f;
+  float m = NEG, l = 0.f;
+
+  // cooperative fetch of one 64-key tile: unit u = i * 256 + tid -> row d = u / 16, keys 4 (u % 16) .. + 3 (16 lanes = one 256-byte row segment)
+  f32x4 kld[UPT], vld[UPT];
+  unsigned mnext = 0;
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = i * 256 + tid, d = u >> 4, c = (u & 15) * 4;
+      kld[i] = *reinterpret_cast<const f32x4*>(Kh + (long)d * a.ldk + k0 + c);
+      vld[i] = *reinterpret_cast<const f32x4*>(Vh + (long)d * a.ldv + k0 + c);
+    }
+    mnext = mrow[(unsigned)min(k0 + lane, a.Tk - 1)];
+  };
+  auto stage = [&](float* buf, int k0) __attribute__((always_inline)) {
+    float* kb = buf;
+    float* vb = buf + KT;
+    const bool tail = k0 + 64 > a.Tk;          // columns past Tk are row padding: whatever they hold must not reach 0 * V
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = i * 256 + tid, d = u >> 4, c = (u & 15) * 4;
+      *reinterpret_cast<f32x4*>(kb + (d >> 1) * 128 + (c >> 5) * 64 + (d & 1) * 32 + (c & 31)) = kld[i];
+      f32x4 v = vld[i];
+      if (tail) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k0 + c + e < a.Tk) ? v[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vb[d * VLD + c + e] = v[e];
+    }
+  };
+
+  fetch(kbeg);
+  __builtin_amdgcn_sched_barrier(0);
+  const float qs = a.scale * 1.44269504088896340736f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qreg[ks] *= qs;
+  FDX_ATTN_STAMP(1);
+  stage(lds, kbeg);
+  unsigned mreg = mnext;
+  __syncthreads();
+  FDX_ATTN_STAMP(2);
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int k0 = kbeg + kt * 64;
+    const bool more = kt + 1 < n_kt;
+    float* kb = lds + (kt & 1) * (KT + VT);
+    float* vb = kb + KT;
+    if (more) fetch(k0 + 64);                      // in flight behind this tile's two products
+    // keys this tile must ignore (past this split's range / past Tk / key padding), as a wave-uniform bit set
+    const unsigned long long badm = __ballot((k0 + lane >= kend) || (has_mask && mreg != 0));
+    const bool both = k0 + 32 < kend;             // the second 32 keys of the tile exist (workgroup-uniform)
+    // ---- S^T = K^T Q
+    f32x16 s[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[rb][r] = 0.f;
+    if (both) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float a0 = kb[ks * 128 + lane], a1 = kb[ks * 128 + 64 + lane];
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qreg[ks], s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qreg[ks], s[1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[ks * 128 + lane], qreg[ks], s[0], 0, 0, 0);
+    }
+    // ---- key mask + online softmax over the key axis (accumulator registers of one lane + one cross-half exchange)
+    if (badm != 0ull) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = rb * 32 + acc_row(r, 0);          // this element's key bit in the low lane half; + 4 in the high half
+          const unsigned long long lanes = (((badm >> c) & 1) ? 0x00000000FFFFFFFFull : 0ull) | (((badm >> (c + 4)) & 1) ? 0xFFFFFFFF00000000ull : 0ull);
+          const bool bad = __builtin_amdgcn_inverse_ballot_w64(lanes);
+          s[rb][r] = bad ? NEG : s[rb][r];
+        }
+    }
+    // The reference maximum m moves only when some query of the wave sees a score more than 2^8 above it (always on the first tile): between
+    // moves the weights are 2^(s - m) <= 256 and O^T / l need no rescaling -- same sum, same normalisation, 16 fewer VALU passes over the
+    // accumulators per tile (fp32 VALU work is additive to the fp32 MFMAs).
+    float mx = NEG;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[rb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (__ballot(mx > m + 8.f) != 0ull) {
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - (m_new == NEG ? 0.f : m_new));   // m = -inf (nothing seen yet): 0
+      l *= alpha;
+      m = m_new;
+      if (kt > 0) {
+#pragma unroll
+        for (int x = 0; x < RBD; ++x)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[x][r] *= alpha;
+      }
+    }
+    const float m_use = m == NEG ? 0.f : m;      // every key so far masked: keep exp2() finite, all weights 0
+    float sum = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[rb][r] - m_use);
+        s[rb][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32);
+    l += sum;
+    // ---- O^T += V P^T : the k-pair of step (rb, r) is the key pair the two lane halves hold in s[rb][r]
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      if (rb == 1 && !both) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = rb * 32 + acc_row(r, half);
+#pragma unroll
+        for (int x = 0; x < RBD; ++x) {
+          const int d = x * 32 + n;
+          const float av = d < DH ? vb[d * VLD + kl] : 0.f;
+          o[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[rb][r], o[x], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      stage(lds + ((kt + 1) & 1) * (KT + VT), k0 + 64);
+      mreg = mnext;
+    }
+    __syncthreads();
+    if (kt < 3) FDX_ATTN_STAMP(3 + kt);
+  }
+  FDX_ATTN_STAMP(6);
+
+  const int q = q0 + n;
+  if (q >= a.Tq) return;
+  if (a.ksplit == 1) {
+    const float rl = 1.f / l;
+#pragma unroll
+    for (int x = 0; x < RBD; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = x * 32 + acc_row(r, half);
+        if (d < DH) a.O[b * a.o_bs + (long)(h * DH + d) * a.ldo + q] = o[x][r] * rl;
+      }
+    return;
+  }
+  float* P = a.P + split * a.p_split + b * a.o_bs;
+#pragma unroll
+  for (int x = 0; x < RBD; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = x * 32 + acc_row(r, half);
+      if (d < DH) P[(long)(h * DH + d) * a.ldo + q] = o[x][r];
+    }
+  if (half == 0) {
+    float* ml = a.ML + (((long)split * a.B + b) * kHeads + h) * 2 * a.TqR;
+    ml[q] = m;
+    ml[a.TqR + q] = l;
+  }
+}
+
+// O[c][q] = sum_s 2^(m_s - M) P_s[c][q] / sum_s 2^(m_s - M) l_s,  M = max_s m_s  -- splits folded in index order (deterministic).
+// One thread = one query x 4 channels; KSP is a template parameter so that all 4 KSP operand loads are unconditional and in flight
+// together (with `if (s < ksplit)` around each load hipcc waited for every load in turn: 64 dependent round trips, 21 us per launch).
+template <int DH, int KSP>
+__global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
+  constexpr int CH = DH / 16;                 // 16-channel chunks per head
+  const int q = blockIdx.x * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
+  const int h = blockIdx.y / CH, chunk = blockIdx.y - h * CH, b = blockIdx.z;
+  const int qc = min(q, a.Tq - 1);
+  float w[KSP], lv[KSP], M = -__builtin_inff();
+#pragma unroll
+  for (int s = 0; s < KSP; ++s) {
+    const float* ml = a.ML + ((((long)s * a.B + b) * kHeads + h) * 2) * a.TqR;
+    w[s] = ml[qc];
+    lv[s] = ml[a.TqR + qc];
+  }
+  const long off = b * a.o_bs + (long)(h * DH + chunk * 16 + cg * 4) * a.ldo + qc;
+  float pv[4][KSP];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int s = 0; s < KSP; ++s) pv[ci][s] = a.P[s * a.p_split + off + (long)ci * a.ldo];
+#pragma unroll
+  for (int s = 0; s < KSP; ++s) M = fmaxf(M, w[s]);
+  const float M_use = M == -__builtin_inff() ? 0.f : M;
+  float L = 0.f;
+#pragma unroll
+  for (int s = 0; s < KSP; ++s) {
+    w[s] = __builtin_amdgcn_exp2f(w[s] - M_use);
+    L += lv[s] * w[s];
+  }
+  const float rl = 1.f / L;
+  if (q >= a.Tq) return;
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) {
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < KSP; ++s) acc += pv[ci][s] * w[s];
+    a.O[off + (long)ci * a.ldo] = acc * rl;
+  }
+}
+
+// key splits of the query-split kernel: enough workgroups for ~7/8 of the 256 CUs, never finer than one 32-key unit
+inline int& attn_ksplit_forced() {   // FDX_ATTN_KSPLIT=<n> (A/B); the ubench sets it directly
+  static int v = [] { const char* e = getenv("FDX_ATTN_KSPLIT"); return e ? atoi(e) : 0; }();
+  return v;
+}
+inline int attn_ksplit(int B, int Tq, int Tk) {
+  const int forced = attn_ksplit_forced();
+  const int units = (Tk + 31) / 32;
+  const long base = (long)B * kHeads * ((Tq + 127) / 128);
+  int ks = forced > 0 ? forced : (int)((224 + base - 1) / base);
+  return max(1, min(min(ks, 8), units));
+}
+// floats of scratch the split path needs: partial O^T per split + (max, sum) per query
+inline size_t attn_part_floats(int B, int T, int D, int ld) { return (size_t)attn_ksplit(B, T, T) * B * D * ld; }
+inline size_t attn_ml_floats(int B, int T) { return (size_t)attn_ksplit(B, T, T) * B * kHeads * 2 * round_up(T, 128); }
+inline bool attn_use_qs() {   // FDX_ATTN=old: round 4's key-split kernel (A/B)
+  static const bool v = [] { const char* e = getenv("FDX_ATTN"); return !(e && e[0] == 'o'); }();
+  return v;
+}
+
+hipError_t launch_attn_qs(int DH, AttnArgs a, int B, hipStream_t s, ProfEvents* prof) {
+  a.B = B;
+  a.ksplit = (a.P && a.ML) ? attn_ksplit(B, a.Tq, a.Tk) : 1;
+  a.TqR = round_up(a.Tq, 128);
+  a.p_split = (long)B * a.o_bs;
+  const int n_qb = (a.Tq + 127) / 128;
+  const dim3 grid(kHeads * n_qb * a.ksplit, 1, B), blk(256);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: QK^T and PV of one attention launch = 2 * 2 * Tq * Tk * D flops per item
+  if (prof) {
+    prof->note(PROF_TD_ATTN, "k_attn_qs<%d> (v_mfma_f32_32x32x2_f32 fp32 flash attention: 128-query workgroups share K / V tiles through LDS, keys split %d ways; %ld workgroups%s)",
+               DH, a.ksplit, (long)grid.x * B, a.ksplit > 1 ? " + k_attn_combine, not in the timed interval" : "");
+    prof->take(PROF_TD_ATTN, 4.0 * (double)a.Tq * a.Tk * (double)(DH * kHeads) * B, ev0, ev1);
+  }
+#define FDX_ATTN(DH_)                                                                                   \
+  {                                                                                                     \
+    if (ev0) hipExtLaunchKernelGGL((k_attn_qs<DH_>), grid, blk, 0, s, ev0, ev1, 0, a);                   \
+    else hipLaunchKernelGGL((k_attn_qs<DH_>), grid, blk, 0, s, a);                                       \
+    const dim3 cgrid((a.Tq + 63) / 64, kHeads * (DH_ / 16), B);                                          \
+    switch (a.ksplit) {                                                                                 \
+      case 2: hipLaunchKernelGGL((k_attn_combine<DH_, 2>), cgrid, blk, 0, s, a); break;                  \
+      case 3: hipLaunchKernelGGL((k_attn_combine<DH_, 3>), cgrid, blk, 0, s, a); break;                  \
+      case 4: hipLaunchKernelGGL((k_attn_combine<DH_, 4>), cgrid, blk, 0, s, a); break;                  \
+      case 5: hipLaunchKernelGGL((k_attn_combine<DH_, 5>), cgrid, blk, 0, s, a); break;                  \
+      case 6: hipLaunchKernelGGL((k_attn_combine<DH_, 6>), cgrid, blk, 0, s, a); break;                  \
+      case 7: hipLaunchKernelGGL((k_attn_combine<DH_, 7>), cgrid, blk, 0, s, a); break;                  \
+      case 8: hipLaunchKernelGGL((k_attn_combine<DH_, 8>), cgrid, blk, 0, s, a); break;                  \
+      default: break;                                                                                   \
+    }                                                                                                   \
+  }
+  if (DH == 64) FDX_ATTN(64)
+  else if (DH == 32) FDX_ATTN(32)
+  else FDX_ATTN(16)
+#undef FDX_ATTN
+  return hipGetLastError();
+}
+
 template <int NQ>
 hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const dim3 grid((a.Tq + 32 * NQ - 1) / (32 * NQ), kHeads, B), blk(256);
@@ -348,6 +676,7 @@ hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s, hipEv
   return hipGetLastError();
 }
 hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s, ProfEvents* prof = nullptr) {
+  if (attn_use_qs()) return launch_attn_qs(DH, a, B, s, prof);
   // 64-query workgroups only when they already give every CU one (B * heads * T/64 >= 256); else 32-query ones
   const bool nq2 = (long)B * kHeads * ((a.Tq + 63) / 64) >= 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: QK^T and PV of one attention launch = 2 * 2 * Tq * Tk * D flops per item
@@ -361,23 +690,28 @@ hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s, ProfEven
 }
 
 // Scratch of one decoder layer (owned by the caller; padded rows [B][ch][ld], pointers past the left halo)
-struct DecScratch { float* QKV; float* O; float* G; };   // [3D], [D], [H]
+struct DecScratch { float* QKV; float* O; float* G; float* P = nullptr; float* ML = nullptr; };   // [3D], [D], [H]; attention split scratch (attn_part_floats / attn_ml_floats; null = never split)
 
 // x = norm1(x + out_proj(attn(in_proj(x)))); x = norm2(x + out_proj(attn(q(x), K, V))); x = norm3(x + linear2(gelu(linear1(x)))), in place
 // on X.  The cross-attention keys / values come from `KV` [B][2D][ld] (already projected with y.ca_kv: the caller decides whether
 // that projection is per call or hoisted; kv_bs = floats between batch items of KV).  tgt_kpm / mem_kpm: [B][T] key-padding masks (1 = ignored) or null.
+// `ca_bias` (optional): the cross-attention out-projection's bias as a per-item column of a table, bias(row, item) = ca_bias[row * ca_bias_ld +
+// item * ca_bias_bs] -- the transformer denoiser folds the diffusion step's path through the value projection into it (tfdec.hip).
 inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV, long kv_bs,
-                               const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s, ProfEvents* prof = nullptr) {
+                               const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s, ProfEvents* prof = nullptr,
+                               const float* ca_bias = nullptr, int ca_bias_ld = 1, int ca_bias_bs = 0) {
   const long bsD = (long)D * ld, bsH = (long)H * ld;
   const int DH = D / kHeads;
-  auto residual = [&](const PackedW& p, const float* in, long in_bs) {   // X += W in + b
+  auto residual = [&](const PackedW& p, const float* in, long in_bs, const float* bias = nullptr, int b_ld = 1, int b_bs = 0) {   // X += W in + b
     EpiScaleRes e{};
-    e.X = X; e.bs = bsD; e.ld = ld; e.bias = A + p.b_off; e.gamma = nullptr; e.M = D; e.mask = nullptr; e.mask_ld = T;
+    e.X = X; e.bs = bsD; e.ld = ld; e.bias = bias ? bias : A + p.b_off; e.bias_ld = b_ld; e.bias_bs = b_bs; e.gamma = nullptr; e.M = D;
+    e.mask = nullptr; e.mask_ld = T;
     return gemm(A, p, B, T, in, in_bs, ld, e, s);
   };
   hipError_t e;
   AttnArgs at{};
   at.O = sc.O; at.o_bs = bsD; at.ldo = ld; at.Tq = T; at.Tk = T; at.scale = 1.f / sqrtf((float)DH);
+  at.P = sc.P; at.ML = sc.ML;
   // ---- self-attention block
   if ((e = gemm(A, y.sa_in, B, T, X, bsD, ld, bias_epi(sc.QKV, 3 * bsD, ld, A + y.sa_in.b_off, 3 * D, ACT_NONE), s)) != hipSuccess) return e;
   at.Q = sc.QKV; at.q_bs = 3 * bsD; at.ldq = ld;
@@ -392,7 +726,7 @@ inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, i
   at.K = KV; at.k_bs = kv_bs; at.V = KV + (size_t)D * ld; at.v_bs = kv_bs;
   at.kmask = mem_kpm;
   if ((e = launch_attn(DH, at, B, s, prof)) != hipSuccess) return e;
-  if ((e = residual(y.ca_out, sc.O, bsD)) != hipSuccess) return e;
+  if ((e = residual(y.ca_out, sc.O, bsD, ca_bias, ca_bias_ld, ca_bias_bs)) != hipSuccess) return e;
   launch_layernorm(X, bsD, ld, A + y.n2w, A + y.n2b, B, D, T, s);
   // ---- feed-forward block
   if ((e = gemm(A, y.lin1, B, T, X, bsD, ld, bias_epi(sc.G, bsH, ld, A + y.lin1.b_off, H, ACT_GELU), s)) != hipSuccess) return e;

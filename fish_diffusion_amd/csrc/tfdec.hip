@@ -10,9 +10,14 @@
 //   O^T[d][query]  += V P^T    (A = the V tile staged through LDS, B = the S^T accumulators used in place: the MFMA k-pair
 //                               of step r is exactly the key pair (acc_row(r, 0), acc_row(r, 1)) the two lane halves hold)
 // One workgroup = 64 queries x 1 head; its 4 waves split the key tiles and merge their (max, sum, O) triples through LDS.
-// Hoisted per utterance batch: condition_projection(conditioner) + positional embedding (fdx_tfdec_prepare); per sampler run:
-// the step-embedding MLP for all timesteps.  Per call the memory = mask(C0 + step) is rebuilt (one elementwise launch) and each
-// layer projects its own K / V from it -- exactly the reference's order of operations (no algebraic shortcuts through softmax).
+// Hoisted per utterance batch (fdx_tfdec_prepare): C0 = condition_projection(conditioner) + positional embedding, and every layer's
+// cross-attention keys / values of C0.  The reference's memory is mask(C0 + step 1^T) (convnext.py:353,359-360), step = the diffusion-step
+// MLP's output, constant over frames, and the projections are linear:
+//     K = Wk C0 + bk + (Wk step) 1^T        a per-query constant on every score: softmax cancels it (round 5: dropped, not computed)
+//     V = Wv C0 + bv + (Wv step) 1^T        softmax rows sum to 1: the attention output gains exactly Wv step per channel,
+// which the out-projection turns into a per-(layer, step) BIAS, Wo (Wv step) + bo -- computed for all timesteps of a sampler run next to the
+// step embeddings (fdx_td_embed).  Masked memory frames only ever meet the softmax as ignored keys (memory_key_padding_mask is the same
+// cond_masks), so nothing else of the mask survives.  Round 4 rebuilt the memory and ran 12 [2D x D] projections per denoiser call.
 #include "common.hip.h"
 #include "elementwise.hip.h"
 #include "declayer.hip.h"
@@ -60,21 +65,10 @@ void td_layout(const fdx_tfdec_desc& d, TdLayout& l) {
 }
 
 
-// mem[b][c][t] = masked ? 0 : C0[b][c][t] + step[c]                (convnext.py:353,359-360)
-__global__ void k_td_mem(float* __restrict__ mem, const float* __restrict__ C0, long bs, int ld, const float* __restrict__ S0,
-                         int s_ld, int s_bs, const uint8_t* __restrict__ mask, int D, int T) {
-  const int t = blockIdx.x * kEwBlock + threadIdx.x;
-  if (t >= T) return;
-  const int b = blockIdx.y / D, c = blockIdx.y - b * D;
-  const long o = b * bs + (long)c * ld + t;
-  const float v = C0[o] + S0[(long)c * s_ld + b * s_bs];
-  mem[o] = (mask && mask[(long)b * T + t]) ? 0.f : v;
-}
-
-
 struct TdBufs {
-  DevBuf X, QKV, KV, O, G, Hin, H2, mem, C0, condp, c1, cmask;
-  DevBuf E, Hm, S0;
+  DevBuf X, QKV, KVh, O, G, Hin, H2, C0, condp, c1, cmask;   // KVh: [B][L][2D][ld] hoisted cross-attention keys / values
+  DevBuf AP, AML;   // attention: partial O^T and (max, sum) of the key splits (declayer.hip.h k_attn_qs)
+  DevBuf E, Hm, S0, SV, CB;   // per sampler run: step embeddings [D][n]; Wv step [D][n] (scratch); cross-attention out-projection bias [L][D][n]
   int ldn = 0;
 };
 
@@ -171,10 +165,12 @@ extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, 
   TdBufs& b = S->b;
   FDX_HIP(h, h->xin.ensure(sz(M), geom, s));
   FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
-  FDX_HIP(h, b.X.ensure(sz(D), geom, s)); FDX_HIP(h, b.QKV.ensure(sz(3 * D), geom, s)); FDX_HIP(h, b.KV.ensure(sz(2 * D), geom, s));
+  const int L = d.num_layers;
+  FDX_HIP(h, b.X.ensure(sz(D), geom, s)); FDX_HIP(h, b.QKV.ensure(sz(3 * D), geom, s)); FDX_HIP(h, b.KVh.ensure(sz(2 * D) * L, geom, s));
   FDX_HIP(h, b.O.ensure(sz(D), geom, s)); FDX_HIP(h, b.G.ensure(sz(H), geom, s)); FDX_HIP(h, b.Hin.ensure(sz(H), geom, s));
-  FDX_HIP(h, b.H2.ensure(sz(D), geom, s)); FDX_HIP(h, b.mem.ensure(sz(D), geom, s)); FDX_HIP(h, b.C0.ensure(sz(D), geom, s));
+  FDX_HIP(h, b.H2.ensure(sz(D), geom, s)); FDX_HIP(h, b.C0.ensure(sz(D), geom, s));
   FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s));
+  FDX_HIP(h, b.AP.ensure(attn_part_floats(B, T, D, ld) * sizeof(float), false, s)); FDX_HIP(h, b.AML.ensure(attn_ml_floats(B, T) * sizeof(float), false, s));
   // C0 = condition_projection(conditioner) + positional_embedding[:T] * position_scale_key   (convnext.py:348,353-357)
   hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, b.condp.f() + kHalo, (long)E * ld, ld, cond, (long)E * T, T, E, T,
                      1.f, (const uint8_t*)nullptr);
@@ -184,8 +180,14 @@ extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, 
                   bias_epi(b.C0.f() + kHalo, (long)D * ld, ld, A + l.cond2.b_off, D, ACT_NONE), s));
   hipLaunchKernelGGL(k_td_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, b.C0.f() + kHalo, (long)D * ld, ld, A + l.pos, A + l.scale_k,
                      (const uint8_t*)nullptr, D, T);
+  // every layer's cross-attention keys / values of C0 (the step's share never needs projecting per call: see the header)
+  for (int i = 0; i < L; ++i) {
+    const auto& y = l.layers[i];
+    FDX_HIP(h, gemm(A, y.ca_kv, B, T, b.C0.f() + kHalo, (long)D * ld, ld,
+                    bias_epi(b.KVh.f() + kHalo + (size_t)i * 2 * D * ld, (long)L * 2 * D * ld, ld, A + y.ca_kv.b_off, 2 * D, ACT_NONE), s));
+  }
   h->cond_masked = cond_mask != nullptr;
-  if (cond_mask) {   // private copy: the memory mask is applied on every call (and dropped for PLMS' one unmasked call)
+  if (cond_mask) {   // private copy: the key-padding mask of the cross-attention (dropped for PLMS' one unmasked call)
     FDX_HIP(h, b.cmask.ensure((size_t)B * T, false, s));
     FDX_HIP(h, hipMemcpyAsync(b.cmask.p, cond_mask, (size_t)B * T, hipMemcpyDeviceToDevice, s));
   }
@@ -210,6 +212,20 @@ int fdx_td_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_step_embed, ew_grid(n, D), dim3(kEwBlock), 0, s, b.E.f() + kHalo, ldn, t_dev, n, D);
   FDX_HIP(h, gemm(A, l.emb1, 1, n, b.E.f() + kHalo, 0, ldn, bias_epi(b.Hm.f() + kHalo, 0, ldn, A + l.emb1.b_off, H, ACT_GELU), s));
   FDX_HIP(h, gemm(A, l.emb3, 1, n, b.Hm.f() + kHalo, 0, ldn, bias_epi(b.S0.f() + kHalo, 0, ldn, A + l.emb3.b_off, D, ACT_NONE), s));
+  // cross-attention out-projection bias per (layer, timestep): Wo (Wv step) + bo.  Wv = rows [D, 2D) of the packed [2D x D] key / value
+  // projection = its second half of 64-row tiles, addressed in place.
+  const int L = S->d.num_layers;
+  FDX_HIP(h, b.SV.ensure((size_t)D * ldn * 4, geom, s));
+  FDX_HIP(h, b.CB.ensure((size_t)L * D * ldn * 4, geom, s));
+  for (int i = 0; i < L; ++i) {
+    const auto& y = l.layers[i];
+    PackedW wv = y.ca_kv;
+    wv.rows = D; wv.n_mtiles = D / 64;
+    wv.w_off = y.ca_kv.w_off + packed_floats(D / 64, 2, y.ca_kv.cin8, 1);
+    FDX_HIP(h, gemm(A, wv, 1, n, b.S0.f() + kHalo, 0, ldn, bias_epi(b.SV.f() + kHalo, 0, ldn, nullptr, D, ACT_NONE), s));
+    FDX_HIP(h, gemm(A, y.ca_out, 1, n, b.SV.f() + kHalo, 0, ldn,
+                    bias_epi(b.CB.f() + kHalo + (size_t)i * D * ldn, 0, ldn, A + y.ca_out.b_off, D, ACT_NONE), s));
+  }
   return FDX_OK;
 }
 
@@ -224,22 +240,21 @@ int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
   const int B = h->B, T = h->T, ld = h->ld;
   TdBufs& b = S->b;
   const long bsD = (long)D * ld, bsH = (long)H * ld;
-  float* X = b.X.f() + kHalo; float* QKV = b.QKV.f() + kHalo; float* KV = b.KV.f() + kHalo; float* O = b.O.f() + kHalo;
-  float* G = b.G.f() + kHalo; float* Hin = b.Hin.f() + kHalo; float* H2 = b.H2.f() + kHalo; float* mem = b.mem.f() + kHalo;
+  float* X = b.X.f() + kHalo; float* QKV = b.QKV.f() + kHalo; const float* KVh = b.KVh.f() + kHalo; float* O = b.O.f() + kHalo;
+  float* G = b.G.f() + kHalo; float* Hin = b.Hin.f() + kHalo; float* H2 = b.H2.f() + kHalo;
+  const int L = d.num_layers;
   const uint8_t* cmask = (h->cond_masked && !unmasked_cond) ? static_cast<const uint8_t*>(b.cmask.p) : nullptr;
   const dim3 blk(kEwBlock);
   // x = input_projection(x)^T + pos * scale_q, masked                                         (convnext.py:343-346,356-357)
   FDX_HIP(h, gemm(A, l.in0, B, T, xin, (long)M * ld, ld, bias_epi(Hin, bsH, ld, A + l.in0.b_off, H, ACT_GELU), s));
   FDX_HIP(h, gemm(A, l.in2, B, T, Hin, bsH, ld, bias_epi(X, bsD, ld, A + l.in2.b_off, D, ACT_NONE), s));
   hipLaunchKernelGGL(k_td_addpos, ew_grid(T, B * D), blk, 0, s, X, bsD, ld, A + l.pos, A + l.scale_q, mask, D, T);
-  // memory = mask(C0 + diffusion_step)                                                          (:353,359-360)
-  hipLaunchKernelGGL(k_td_mem, ew_grid(T, B * D), blk, 0, s, mem, b.C0.f() + kHalo, bsD, ld, b.S0.f() + kHalo + col0, b.ldn, sb_bs, cmask, D, T);
-  const DecScratch sc{QKV, O, G};
-  for (const auto& y : l.layers) {
-    // every layer projects its own keys / values from the per-call memory (it contains the diffusion step: not hoistable)
-    FDX_HIP(h, gemm(A, y.ca_kv, B, T, mem, bsD, ld, bias_epi(KV, 2 * bsD, ld, A + y.ca_kv.b_off, 2 * D, ACT_NONE), s));
-    FDX_HIP(h, run_declayer(A, y, B, T, D, H, ld, X, KV, 2 * bsD, sc, mask, cmask, s, &h->prof));
-  }
+  // memory = mask(C0 + diffusion_step) (:353,359-360) is never formed: its keys / values are the hoisted ones of C0, the step's share is the
+  // per-step bias of each layer's cross-attention out-projection (column col0 of CB; sb_bs = its stride between batch items)
+  const DecScratch sc{QKV, O, G, b.AP.f() + kHalo, b.AML.f()};
+  for (int i = 0; i < L; ++i)
+    FDX_HIP(h, run_declayer(A, l.layers[i], B, T, D, H, ld, X, KVh + (size_t)i * 2 * D * ld, (long)L * 2 * bsD, sc, mask, cmask, s, &h->prof,
+                            b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs));
   FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
   {
     EpiBias e = bias_epi(eps_out, o_bs, ldo, A + l.out2.b_off, M, ACT_NONE);
