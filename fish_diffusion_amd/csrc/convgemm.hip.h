@@ -641,6 +641,9 @@ constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result tra
 // the 256 VGPRs that let two workgroups share a CU, like every other instantiation already does unprompted.)
 // (Measured and removed, round 4 -- see profiles/NOTES.md: 8 K-splitting waves per workgroup (2 % slower), 128-row MT = 2 tiles (+1 % at batch 2,
 // -10 % at batch 8), a 2-D tile -> XCD map and a late epilogue prefetch for this family.)
+// (Measured and removed, round 5 -- profiles/r05_mt2_and_splitk_rect_ab.txt: workgroups owning TWO packed m-tiles (128 x 64 tiles, 12 instead of 16
+// B/clk/CU of operands, 224 instead of 448 workgroups for a 2048-row GEMM over 861 columns; bit-identical): ConvNext pwconv1 26.2 -> 32.6 us, the
+// transformer's linear1 likewise -- one workgroup per CU loses the overlap two co-resident 64 x 64 workgroups give each other's fills and epilogues.)
 template <int RB, bool SPLITK, int PRE, class Epi, int OPK = OPK_F32>
 __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
@@ -658,12 +661,10 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
   const int half = lane >> 5, li = lane & 31;
   FDX_STAMP(0);
 
-  // ---- XCD-aware logical tile id (block b runs on XCD b % 8; give each XCD a contiguous chunk)
-  const int G = a.n_tiles_n * a.n_mtiles, bid = blockIdx.x;   // == gridDim.x, from preloaded arguments
-  const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
-  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int mtg = L / a.n_tiles_n;            // packed m-tile
-  const int nt = L - mtg * a.n_tiles_n;
+  // ---- XCD-aware logical tile id (block b runs on XCD b % 8): row runs, or -- when the activation operand outweighs the weights (round 5:
+  // ConvNext pwconv2 at batch 1 fetched its 7 MB of activations into all eight L2s, 64.8 MB per launch) -- 4 row quarters x 2 column halves
+  int mtg, nt;                                // packed m-tile, column tile
+  conv_tile_of_block(a.n_tiles_n, a.n_mtiles, a.xcd_rect, blockIdx.x, mtg, nt);
   const int item = nt / a.tiles_per_item;
   const int tile_in_item = nt - item * a.tiles_per_item;
   constexpr int COLS = SPLITK ? 64 : 256;
@@ -683,10 +684,10 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
   // first operand loads (so they do not delay the K loop's start) and land behind the K loop.
   // The tile's sites are dealt to the NW waves in order, site s = wave*NS + i:
   //   paired / RB=1: accumulator row r = s & 15;   unpaired RB=2: row block (s >> 4) & 1, r = s & 15.
-  constexpr int NS = SPLITK ? ((Epi::kPaired || RB == 1) ? 16 / NW : 32 / NW) : 1;
+  constexpr int NS = SPLITK ? (Epi::kPaired ? 16 / NW : RBX * 16 / NW) : 1;
   auto site_row = [&](int sidx) {             // first logical row of the 32-row block the site lives in, + its row inside
     const int blk = sidx >> 4, r = sidx & 15;
-    const int rb = (Epi::kPaired || RB == 1) ? 0 : (blk & 1);
+    const int rb = Epi::kPaired ? 0 : blk;    // accumulator block = 32-row block of the tile
     return row_base + rb * 32 + acc_row(r, half);
   };
   typename Epi::Pre pre[NS];
@@ -1034,6 +1035,16 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
 }
 
 // ------------------------------------------------------------------------------------------ host launch
+// Tile -> XCD map of the split-K family (small grids).  Row runs fetch the weights once chip-wide and the activation operand once per XCD: right
+// while there are more rows than columns.  With more columns than rows (ConvNext pwconv2, the transformer's linear2 / out-projections at batch 1:
+// 512 rows x 861 columns) 4 row quarters x 2 column halves halve the activation re-reads for 4 x the (smaller) weight reads.  Needs the tile counts
+// to divide; FDX_SPLITK_RECT=0 keeps row runs everywhere (A/B).  A scheduling choice only: results are bit-identical.
+inline int splitk_xcd_rect(int n_tiles_n, int n_mt, long rows, long cols) {
+  static const int on = [] { const char* e = getenv("FDX_SPLITK_RECT"); return e ? atoi(e) : 1; }();
+  if (!on || cols <= rows) return 0;
+  return ((n_mt & 3) == 0 && (n_tiles_n & 1) == 0 && (long)n_tiles_n * n_mt >= 64) ? 2 : 0;
+}
+
 struct ConvGeom {   // everything the launcher needs besides pointers
   int B, T;         // items, valid columns per item
   int cin8;         // Cin / 8 (padded)
@@ -1054,7 +1065,7 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   a.tiles_per_item = (g.T + cols - 1) / cols;
   a.n_tiles_n = g.B * a.tiles_per_item;
   a.n_mtiles = g.n_mtiles;
-  a.xcd_rect = 0;                      // (this family keeps the row-run map)
+  a.xcd_rect = SPLITK ? splitk_xcd_rect(a.n_tiles_n, a.n_mtiles, 32 * RB * a.n_mtiles, (long)g.B * g.T) : 0;
   a.in_slope = in_slope;
   a.col_stats = col_stats; a.ln_R = ln_R; a.n_groups = n_groups; a.ln_eps = ln_eps;
   const int grid = a.n_tiles_n * a.n_mtiles;

@@ -45,3 +45,46 @@ def test_generator_resblock2_matches_reference_golden(dev, tag):
     err = abs_err(wav.cpu(), g["wav"])
     print(f"resblock2 {tag}: wav abs err {err:.3e}")
     assert err < WAV_ABS
+
+
+# ------------------------------------------------------------------------------------------------ 2-D tile -> XCD map of the split-K GEMM family
+def test_splitk_xcd_rect_map_is_bit_identical_to_row_runs(dev):
+    """convgemm.hip.h `splitk_xcd_rect`: which XCD runs which tile is a scheduling choice (it decides which L2 fetches what, not what is computed).
+    Full-width ConvNext and transformer denoisers with the map off (FDX_SPLITK_RECT=0) and automatic, each in its own process: bit for bit
+    equal outputs on ragged geometries, masks included."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from fish_diffusion_amd import DENOISERS
+from tests.helpers import convnext_sd, tfdec_sd
+dev = torch.device("cuda", 0)
+h = hashlib.sha1()
+g = torch.Generator().manual_seed(1)
+for kind, cfg, sd in (("ConvNextDenoiser", dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=2, dilation_cycle=2), convnext_sd),
+                      ("TransformerDecoderDenoiser", dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=1), tfdec_sd)):
+    net = DENOISERS.build(dict(type=kind, **cfg))
+    net.load_state_dict(sd(cfg, 7), strict=True)
+    net = net.to(dev).eval()
+    for B, T in ((1, 37), (2, 113), (1, 430), (1, 861), (3, 200)):
+        x, c, t = torch.randn(B, 128, T, generator=g).to(dev), torch.randn(B, 256, T, generator=g).to(dev), (torch.rand(B, generator=g) * 999).to(dev)
+        m = torch.zeros(B, T, dtype=torch.bool, device=dev)
+        m[-1, T - T // 5:] = True
+        for masks in (None, m):
+            y = net(x, t, c, x_masks=masks, cond_masks=masks)
+            assert torch.isfinite(y).all()
+            h.update(y.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+''' % ROOT
+    digests = {}
+    for tag, val in (("row_runs", "0"), ("auto", None)):
+        env = dict(os.environ)
+        env.pop("FDX_SPLITK_RECT", None)
+        if val is not None:
+            env["FDX_SPLITK_RECT"] = val
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DIGEST" in r.stdout, tag + "\n" + r.stdout + r.stderr
+        digests[tag] = r.stdout.split("DIGEST")[1].split()[0]
+    print(digests)
+    assert len(set(digests.values())) == 1, digests
