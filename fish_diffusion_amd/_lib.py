@@ -99,6 +99,7 @@ _SIGS = {
     "fdx_tfdec_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
     "fdx_sampler_run": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_uint64, _P, _P]),
     "fdx_sampler_run_ragged": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_uint64, _P, _P]),
+    "fdx_sampler_set_items": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "fdx_q_sample": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P]),
     "fdx_denorm_spec": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "fdx_randn": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P]),

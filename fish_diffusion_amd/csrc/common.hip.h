@@ -179,6 +179,13 @@ struct fdx_ctx {
   // exact-mask runs (fdx_sampler_run_ragged): 1 / 0 per frame in the padded row layout
   fdx::DevBuf keepbuf;
   const float* ragged_keep = nullptr;   // non-null only while such a run is being enqueued / recorded
+  // item layout of an exact-ragged row (fdx_sampler_set_items): what the attention-based denoisers need beside the hole mask
+  std::vector<int> items;               // host: {offset, length} per item; empty = dense batches
+  fdx::DevBuf items_dev;                // int4 per item {offset, length, 0, 0}
+  fdx::DevBuf pidx_dev;                 // int per column of the row: position inside its item (0 in holes)
+  uint64_t items_hash = 0;              // part of the sampler-graph key (grids depend on the layout)
+  int items_max_len = 0, items_T = 0;
+  int n_items() const { return (int)items.size() / 2; }
 
   // ---- nsf
   bool nsf_ok = false;

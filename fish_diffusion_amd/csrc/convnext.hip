@@ -100,14 +100,15 @@ void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
 // X[b][c][t] += (sb ? sb[c] : 0) + pos[t][c] * scale    (CrossAttentionBlock.forward: x + diffusion_step_projection(step), then
 // + positional_embedding * position_scale_query, convnext.py:127-136; with sb == null and out != in: condition + pos * scale_key)
 __global__ void k_cn_addpos(float* out, const float* in, long bs, int ld, const float* __restrict__ sb, int sb_ld,
-                            int sb_bs, const float* __restrict__ pos, const float* __restrict__ scale, int D, int T) {
+                            int sb_bs, const float* __restrict__ pos, const float* __restrict__ scale, int D, int T,
+                            const int* __restrict__ pidx /* exact-ragged rows: position inside the item; null = the column */) {
   const int t = blockIdx.x * kEwBlock + threadIdx.x;
   if (t >= T) return;
   const int b = blockIdx.y / D, c = blockIdx.y - b * D;
   const long o = b * bs + (long)c * ld + t;
   float v = in[o];
   if (sb) v = v + sb[(long)c * sb_ld + b * sb_bs];
-  out[o] = v + pos[(long)t * D + c] * scale[0];
+  out[o] = v + pos[(long)(pidx ? pidx[t] : t) * D + c] * scale[0];
 }
 
 // ------------------------------------------------------------------------------------------------ dwconv + LayerNorm
@@ -358,14 +359,20 @@ extern "C" int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int 
   } else {
     // cross-attention variant: the ConvNeXt blocks get no condition (convnext.py:246-250); every cross block's memory
     // condition + pos * scale_key (:137-141) is step-invariant -> its key / value projection is hoisted here
-    if (T > kCnPositions) return fail(h, FDX_E_ARG, "fdx_convnext_prepare: %d frames exceed the positional table (%d)", T, kCnPositions);
+    const bool ragged = h->n_items() > 0;
+    if (ragged && (B != 1 || h->items_T != T))
+      return fail(h, FDX_E_ARG, "fdx_convnext_prepare: the item layout describes one row of %d frames, got a batch of %d x %d", h->items_T, B, T);
+    const int Tpos = ragged ? h->items_max_len : T;
+    if (Tpos > kCnPositions) return fail(h, FDX_E_ARG, "fdx_convnext_prepare: %d frames exceed the positional table (%d)", Tpos, kCnPositions);
+    const int* pidx = ragged ? static_cast<const int*>(h->pidx_dev.p) : nullptr;
     FDX_HIP(h, b.QKV.ensure(sz(3 * D), geom, s)); FDX_HIP(h, b.O.ensure(sz(D), geom, s)); FDX_HIP(h, b.MEM.ensure(sz(D), geom, s));
-    FDX_HIP(h, b.AP.ensure(attn_part_floats(B, T, D, ld) * sizeof(float), false, s)); FDX_HIP(h, b.AML.ensure(attn_ml_floats(B, T) * sizeof(float), false, s));
+    FDX_HIP(h, b.AP.ensure(attn_part_floats(B, T, D, ld, h->n_items()) * sizeof(float), false, s));
+  FDX_HIP(h, b.AML.ensure(attn_ml_floats(B, T, h->n_items(), h->items_max_len) * sizeof(float), false, s));
     FDX_HIP(h, b.KVc.ensure(sz(NC * 2 * D), geom, s));
     for (int c = 0; c < NC; ++c) {
       const auto& x = l.cross[c];
       hipLaunchKernelGGL(k_cn_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, b.MEM.f() + kHalo, b.c2.f() + kHalo, (long)D * ld, ld,
-                         (const float*)nullptr, 0, 0, A + l.pos, A + x.scale_k, D, T);
+                         (const float*)nullptr, 0, 0, A + l.pos, A + x.scale_k, D, T, pidx);
       FDX_HIP(h, gemm(A, x.dec.ca_kv, B, T, b.MEM.f() + kHalo, (long)D * ld, ld,
                       bias_epi(b.KVc.f() + kHalo + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, ld, A + x.dec.ca_kv.b_off, 2 * D, ACT_NONE), s));
     }
@@ -415,7 +422,7 @@ int fdx_cn_plms_setup(fdx_ctx* h, hipStream_t s) {
     for (int c = 0; c < NC; ++c) {
       const auto& x = l.cross[c];
       hipLaunchKernelGGL(k_cn_addpos, ew_grid(h->T, h->B * D), dim3(kEwBlock), 0, s, S->b.MEM.f() + kHalo, S->b.c2raw.f() + kHalo, (long)D * ld, ld,
-                         (const float*)nullptr, 0, 0, A + l.pos, A + x.scale_k, D, h->T);
+                         (const float*)nullptr, 0, 0, A + l.pos, A + x.scale_k, D, h->T, (const int*)nullptr);
       FDX_HIP(h, gemm(A, x.dec.ca_kv, h->B, h->T, S->b.MEM.f() + kHalo, (long)D * ld, ld,
                       bias_epi(S->b.KVc2.f() + kHalo + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, ld, A + x.dec.ca_kv.b_off, 2 * D, ACT_NONE), s));
     }
@@ -456,10 +463,14 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
     if (NC && i % d.cross_attention == 0) {   // CrossAttentionBlock (convnext.py:127-152)
       const int c = i / d.cross_attention;
       const auto& x = l.cross[c];
+      const bool ragged = h->n_items() > 0 && B == 1 && h->items_T == T;
+      AttnItems items;
+      if (ragged) { items.dev = static_cast<const int4*>(h->items_dev.p); items.host = &h->items; items.max_len = h->items_max_len; }
       hipLaunchKernelGGL(k_cn_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, X, X, bsD, ld, SB + (size_t)(L + c) * D * b.ldn, b.ldn, sb_bs,
-                         A + l.pos, A + x.scale_q, D, T);
+                         A + l.pos, A + x.scale_q, D, T, ragged ? static_cast<const int*>(h->pidx_dev.p) : (const int*)nullptr);
       const DecScratch sc{b.QKV.f() + kHalo, b.O.f() + kHalo, G, b.AP.f() + kHalo, b.AML.f()};
-      FDX_HIP(h, run_declayer(A, x.dec, B, T, D, H, ld, X, KVc + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, sc, mask, cmask, s));
+      FDX_HIP(h, run_declayer(A, x.dec, B, T, D, H, ld, X, KVc + (size_t)c * 2 * D * ld, (long)NC * 2 * D * ld, sc, mask, cmask, s, nullptr,
+                              nullptr, 1, 0, items));
     }
     const dim3 grid((T + 63) / 64, D / kCnCh, B);
     hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, N, b.ST.f(), X, bsD, ld, CP ? CP + (size_t)i * D * ld : nullptr, (long)L * D * ld,

@@ -50,13 +50,14 @@ inline int pack_declayer(float* A, const TdLayer& y, const float* const* w, int 
 }
 
 // X[b][c][t] = masked ? 0 : X[b][c][t] + pos[t][c] * scale        (convnext.py:344-346,356-357 / :348,353)
+// pidx (exact-ragged rows, fdx_sampler_set_items): the frame's position inside its own item; null = its column
 __global__ void k_td_addpos(float* __restrict__ X, long bs, int ld, const float* __restrict__ pos, const float* __restrict__ scale,
-                            const uint8_t* __restrict__ mask, int D, int T) {
+                            const uint8_t* __restrict__ mask, int D, int T, const int* __restrict__ pidx) {
   const int t = blockIdx.x * kEwBlock + threadIdx.x;
   if (t >= T) return;
   const int b = blockIdx.y / D, c = blockIdx.y - b * D;
   const long o = b * bs + (long)c * ld + t;
-  const float v = X[o] + pos[(long)t * D + c] * scale[0];
+  const float v = X[o] + pos[(long)(pidx ? pidx[t] : t) * D + c] * scale[0];
   X[o] = (mask && mask[(long)b * T + t]) ? 0.f : v;
 }
 
@@ -132,6 +133,9 @@ struct AttnArgs {
   float* P; long p_split;
   float* ML; int TqR;
   int ksplit, B;
+  // exact-ragged rows: grid.z walks the items of ONE row; item i = columns [items[i].x, + items[i].y) is its own attention problem (Tq = Tk =
+  // its length) and splits its keys as a batch-1 run of it alone would (attn_ksplit_of(1, len)): `ksplit` is then the largest over the items
+  const int4* items; int ks_force;
 #ifdef FDX_ATTN_TRACE
   unsigned long long* trace;              // [workgroup][wave][8] shader-clock stamps (tools/ubench/attnqs.hip only)
 #endif
@@ -350,6 +354,17 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 }
 
 
+// key splits of the query-split kernel: enough workgroups for ~7/8 of the 256 CUs, never finer than one 32-key unit (host and device: an item of
+// an exact-ragged row picks its own split from its own length)
+__host__ __device__ inline int attn_ksplit_of(int B, int Tq, int Tk, int forced) {
+  const int units = (Tk + 31) / 32;
+  const long base = (long)B * kHeads * ((Tq + 127) / 128);
+  int ks = forced > 0 ? forced : (int)((224 + base - 1) / base);
+  ks = ks < 8 ? ks : 8;
+  ks = ks < units ? ks : units;
+  return ks > 1 ? ks : 1;
+}
+
 // ------------------------------------------------------------------------------------------------ attention, query-split (round 5)
 // Round 4's k_attn gives a workgroup 32 queries and lets its four waves split the KEY tiles: every wave streams its own K / V tiles from
 // global memory into registers, a workgroup reads the head's whole K and V (441 KB at T = 861) for 7 MFLOP, and the launch sits on the
@@ -374,17 +389,24 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
   const int half = lane >> 5, n = lane & 31;
   const int lin = blockIdx.x;
   const int h = lin % kHeads, j = lin / kHeads;
-  const int split = j % a.ksplit, qb = j / a.ksplit, b = blockIdx.z;
+  const int split = j % a.ksplit, qb = j / a.ksplit;
+  int b = blockIdx.z, slot = blockIdx.z, col0 = 0, ksplit = a.ksplit;
+  if (a.items) {                             // exact-ragged row: this workgroup's item (everything below sees it as a batch-1 problem at col0)
+    const int4 it = a.items[blockIdx.z];
+    b = 0; col0 = it.x; a.Tq = a.Tk = it.y;
+    ksplit = attn_ksplit_of(1, it.y, it.y, a.ks_force);
+    if (split >= ksplit || qb * 128 >= it.y) return;
+  }
   const int q0 = qb * 128 + wave * 32;
   const int units = (a.Tk + 31) >> 5;        // 32-key units, dealt to the splits in balanced runs
-  const int u0 = (int)((long)units * split / a.ksplit), u1 = (int)((long)units * (split + 1) / a.ksplit);
+  const int u0 = (int)((long)units * split / ksplit), u1 = (int)((long)units * (split + 1) / ksplit);
   const int kbeg = u0 * 32, kend = min(u1 * 32, a.Tk);
   const int n_kt = (u1 - u0 + 1) >> 1;       // 64-key tiles; the last one may hold 32 keys
-  const float* Qh = a.Q + b * a.q_bs + (long)h * DH * a.ldq;
-  const float* Kh = a.K + b * a.k_bs + (long)h * DH * a.ldk;
-  const float* Vh = a.V + b * a.v_bs + (long)h * DH * a.ldv;
+  const float* Qh = a.Q + b * a.q_bs + (long)h * DH * a.ldq + col0;
+  const float* Kh = a.K + b * a.k_bs + (long)h * DH * a.ldk + col0;
+  const float* Vh = a.V + b * a.v_bs + (long)h * DH * a.ldv + col0;
   const float NEG = -__builtin_inff();
-  const bool has_mask = a.kmask != nullptr;
+  const bool has_mask = a.kmask != nullptr && !a.items;     // (an item's keys are its own frames: no padding inside)
   const uint8_t* mrow = has_mask ? a.kmask + (long)b * a.Tk : reinterpret_cast<const uint8_t*>(Kh);
 
   // B operand of the score product: this lane's slice of Q for the whole launch, pre-multiplied by log2(e) / sqrt(DH).  The loads go out
@@ -539,18 +561,18 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
 
   const int q = q0 + n;
   if (q >= a.Tq) return;
-  if (a.ksplit == 1) {
+  if (ksplit == 1) {
     const float rl = 1.f / l;
 #pragma unroll
     for (int x = 0; x < RBD; ++x)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = x * 32 + acc_row(r, half);
-        if (d < DH) a.O[b * a.o_bs + (long)(h * DH + d) * a.ldo + q] = o[x][r] * rl;
+        if (d < DH) a.O[b * a.o_bs + (long)(h * DH + d) * a.ldo + col0 + q] = o[x][r] * rl;
       }
     return;
   }
-  float* P = a.P + split * a.p_split + b * a.o_bs;
+  float* P = a.P + split * a.p_split + b * a.o_bs + col0;
 #pragma unroll
   for (int x = 0; x < RBD; ++x)
 #pragma unroll
@@ -559,7 +581,7 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
       if (d < DH) P[(long)(h * DH + d) * a.ldo + q] = o[x][r];
     }
   if (half == 0) {
-    float* ml = a.ML + (((long)split * a.B + b) * kHeads + h) * 2 * a.TqR;
+    float* ml = a.ML + (((long)split * a.B + slot) * kHeads + h) * 2 * a.TqR;
     ml[q] = m;
     ml[a.TqR + q] = l;
   }
@@ -572,24 +594,37 @@ template <int DH, int KSP>
 __global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
   constexpr int CH = DH / 16;                 // 16-channel chunks per head
   const int q = blockIdx.x * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
-  const int h = blockIdx.y / CH, chunk = blockIdx.y - h * CH, b = blockIdx.z;
+  const int h = blockIdx.y / CH, chunk = blockIdx.y - h * CH;
+  int b = blockIdx.z, col0 = 0, ks = KSP;
+  const int slot = blockIdx.z;
+  if (a.items) {
+    const int4 it = a.items[blockIdx.z];
+    b = 0; col0 = it.x; a.Tq = it.y;
+    ks = attn_ksplit_of(1, it.y, it.y, a.ks_force);
+    if (ks == 1 || blockIdx.x * 64 >= it.y) return;      // an unsplit item was written normalised by the attention kernel itself
+  }
   const int qc = min(q, a.Tq - 1);
-  float w[KSP], lv[KSP], M = -__builtin_inff();
+  const float NEG = -__builtin_inff();
+  float w[KSP], lv[KSP], M = NEG;
 #pragma unroll
-  for (int s = 0; s < KSP; ++s) {
-    const float* ml = a.ML + ((((long)s * a.B + b) * kHeads + h) * 2) * a.TqR;
+  for (int s = 0; s < KSP; ++s) {             // (loads are unconditional -- a split the item does not have reads a sibling's slot -- and selected)
+    const float* ml = a.ML + ((((long)s * a.B + slot) * kHeads + h) * 2) * a.TqR;
     w[s] = ml[qc];
     lv[s] = ml[a.TqR + qc];
   }
-  const long off = b * a.o_bs + (long)(h * DH + chunk * 16 + cg * 4) * a.ldo + qc;
+  const long off = b * a.o_bs + (long)(h * DH + chunk * 16 + cg * 4) * a.ldo + col0 + qc;
   float pv[4][KSP];
 #pragma unroll
   for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
     for (int s = 0; s < KSP; ++s) pv[ci][s] = a.P[s * a.p_split + off + (long)ci * a.ldo];
 #pragma unroll
-  for (int s = 0; s < KSP; ++s) M = fmaxf(M, w[s]);
-  const float M_use = M == -__builtin_inff() ? 0.f : M;
+  for (int s = 0; s < KSP; ++s) {
+    w[s] = s < ks ? w[s] : NEG;
+    lv[s] = s < ks ? lv[s] : 0.f;
+    M = fmaxf(M, w[s]);
+  }
+  const float M_use = M == NEG ? 0.f : M;
   float L = 0.f;
 #pragma unroll
   for (int s = 0; s < KSP; ++s) {
@@ -602,49 +637,64 @@ __global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
   for (int ci = 0; ci < 4; ++ci) {
     float acc = 0.f;
 #pragma unroll
-    for (int s = 0; s < KSP; ++s) acc += pv[ci][s] * w[s];
+    for (int s = 0; s < KSP; ++s) acc += (s < ks ? pv[ci][s] : 0.f) * w[s];
     a.O[off + (long)ci * a.ldo] = acc * rl;
   }
 }
 
-// key splits of the query-split kernel: enough workgroups for ~7/8 of the 256 CUs, never finer than one 32-key unit
 inline int& attn_ksplit_forced() {   // FDX_ATTN_KSPLIT=<n> (A/B); the ubench sets it directly
   static int v = [] { const char* e = getenv("FDX_ATTN_KSPLIT"); return e ? atoi(e) : 0; }();
   return v;
 }
-inline int attn_ksplit(int B, int Tq, int Tk) {
-  const int forced = attn_ksplit_forced();
-  const int units = (Tk + 31) / 32;
-  const long base = (long)B * kHeads * ((Tq + 127) / 128);
-  int ks = forced > 0 ? forced : (int)((224 + base - 1) / base);
-  return max(1, min(min(ks, 8), units));
-}
+inline int attn_ksplit(int B, int Tq, int Tk) { return attn_ksplit_of(B, Tq, Tk, attn_ksplit_forced()); }
 // floats of scratch the split path needs: partial O^T per split + (max, sum) per query
-inline size_t attn_part_floats(int B, int T, int D, int ld) { return (size_t)attn_ksplit(B, T, T) * B * D * ld; }
-inline size_t attn_ml_floats(int B, int T) { return (size_t)attn_ksplit(B, T, T) * B * kHeads * 2 * round_up(T, 128); }
+// (an exact-ragged row -- n_items > 0, B == 1 -- splits every item up to 8 ways, each item with its own (max, sum) slots)
+inline size_t attn_part_floats(int B, int T, int D, int ld, int n_items = 0) { return (size_t)(n_items ? 8 : attn_ksplit(B, T, T)) * B * D * ld; }
+inline size_t attn_ml_floats(int B, int T, int n_items = 0, int max_len = 0) {
+  if (n_items) return (size_t)8 * n_items * kHeads * 2 * round_up(max_len, 128);
+  return (size_t)attn_ksplit(B, T, T) * B * kHeads * 2 * round_up(T, 128);
+}
 inline bool attn_use_qs() {   // FDX_ATTN=old: round 4's key-split kernel (A/B)
   static const bool v = [] { const char* e = getenv("FDX_ATTN"); return !(e && e[0] == 'o'); }();
   return v;
 }
 
-hipError_t launch_attn_qs(int DH, AttnArgs a, int B, hipStream_t s, ProfEvents* prof) {
-  a.B = B;
-  a.ksplit = (a.P && a.ML) ? attn_ksplit(B, a.Tq, a.Tk) : 1;
-  a.TqR = round_up(a.Tq, 128);
-  a.p_split = (long)B * a.o_bs;
-  const int n_qb = (a.Tq + 127) / 128;
-  const dim3 grid(kHeads * n_qb * a.ksplit, 1, B), blk(256);
+struct AttnItems { const int4* dev = nullptr; const std::vector<int>* host = nullptr; int max_len = 0; };   // exact-ragged row layout (fdx_ctx::items)
+
+hipError_t launch_attn_qs(int DH, AttnArgs a, int B, hipStream_t s, ProfEvents* prof, const AttnItems& items = AttnItems{}) {
+  a.items = nullptr; a.ks_force = attn_ksplit_forced();
+  int n_z = B, Tq_grid = a.Tq;
+  if (items.dev) {                           // one row, grid.z = items; the grid is sized for the longest item and the finest split
+    a.items = items.dev;
+    n_z = (int)items.host->size() / 2;
+    Tq_grid = items.max_len;
+    a.B = n_z;
+    a.ksplit = 1;
+    for (int i = 0; i < n_z; ++i) a.ksplit = max(a.ksplit, attn_ksplit_of(1, (*items.host)[2 * i + 1], (*items.host)[2 * i + 1], a.ks_force));
+    a.TqR = round_up(items.max_len, 128);
+    a.p_split = a.o_bs;                      // the row is ONE batch item
+  } else {
+    a.B = B;
+    a.ksplit = (a.P && a.ML) ? attn_ksplit(B, a.Tq, a.Tk) : 1;
+    a.TqR = round_up(a.Tq, 128);
+    a.p_split = (long)B * a.o_bs;
+  }
+  const int n_qb = (Tq_grid + 127) / 128;
+  const dim3 grid(kHeads * n_qb * a.ksplit, 1, n_z), blk(256);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: QK^T and PV of one attention launch = 2 * 2 * Tq * Tk * D flops per item
   if (prof) {
     prof->note(PROF_TD_ATTN, "k_attn_qs<%d> (v_mfma_f32_32x32x2_f32 fp32 flash attention: 128-query workgroups share K / V tiles through LDS, keys split %d ways; %ld workgroups%s)",
-               DH, a.ksplit, (long)grid.x * B, a.ksplit > 1 ? " + k_attn_combine, not in the timed interval" : "");
-    prof->take(PROF_TD_ATTN, 4.0 * (double)a.Tq * a.Tk * (double)(DH * kHeads) * B, ev0, ev1);
+               DH, a.ksplit, (long)grid.x * n_z, a.ksplit > 1 ? " + k_attn_combine, not in the timed interval" : "");
+    double fl = 0;
+    if (items.dev) for (int i = 0; i < n_z; ++i) fl += 4.0 * (double)(*items.host)[2 * i + 1] * (*items.host)[2 * i + 1] * (double)(DH * kHeads);
+    else fl = 4.0 * (double)a.Tq * a.Tk * (double)(DH * kHeads) * B;
+    prof->take(PROF_TD_ATTN, fl, ev0, ev1);
   }
 #define FDX_ATTN(DH_)                                                                                   \
   {                                                                                                     \
     if (ev0) hipExtLaunchKernelGGL((k_attn_qs<DH_>), grid, blk, 0, s, ev0, ev1, 0, a);                   \
     else hipLaunchKernelGGL((k_attn_qs<DH_>), grid, blk, 0, s, a);                                       \
-    const dim3 cgrid((a.Tq + 63) / 64, kHeads * (DH_ / 16), B);                                          \
+    const dim3 cgrid((Tq_grid + 63) / 64, kHeads * (DH_ / 16), n_z);                                     \
     switch (a.ksplit) {                                                                                 \
       case 2: hipLaunchKernelGGL((k_attn_combine<DH_, 2>), cgrid, blk, 0, s, a); break;                  \
       case 3: hipLaunchKernelGGL((k_attn_combine<DH_, 3>), cgrid, blk, 0, s, a); break;                  \
@@ -675,8 +725,8 @@ hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s, hipEv
 #undef FDX_ATTN
   return hipGetLastError();
 }
-hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s, ProfEvents* prof = nullptr) {
-  if (attn_use_qs()) return launch_attn_qs(DH, a, B, s, prof);
+hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s, ProfEvents* prof = nullptr, const AttnItems& items = AttnItems{}) {
+  if (attn_use_qs() || items.dev) return launch_attn_qs(DH, a, B, s, prof, items);
   // 64-query workgroups only when they already give every CU one (B * heads * T/64 >= 256); else 32-query ones
   const bool nq2 = (long)B * kHeads * ((a.Tq + 63) / 64) >= 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: QK^T and PV of one attention launch = 2 * 2 * Tq * Tk * D flops per item
@@ -699,7 +749,7 @@ struct DecScratch { float* QKV; float* O; float* G; float* P = nullptr; float* M
 // item * ca_bias_bs] -- the transformer denoiser folds the diffusion step's path through the value projection into it (tfdec.hip).
 inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV, long kv_bs,
                                const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s, ProfEvents* prof = nullptr,
-                               const float* ca_bias = nullptr, int ca_bias_ld = 1, int ca_bias_bs = 0) {
+                               const float* ca_bias = nullptr, int ca_bias_ld = 1, int ca_bias_bs = 0, const AttnItems& items = AttnItems{}) {
   const long bsD = (long)D * ld, bsH = (long)H * ld;
   const int DH = D / kHeads;
   auto residual = [&](const PackedW& p, const float* in, long in_bs, const float* bias = nullptr, int b_ld = 1, int b_bs = 0) {   // X += W in + b
@@ -718,14 +768,14 @@ inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, i
   at.K = sc.QKV + (size_t)D * ld; at.k_bs = 3 * bsD; at.ldk = ld;
   at.V = sc.QKV + (size_t)2 * D * ld; at.v_bs = 3 * bsD; at.ldv = ld;
   at.kmask = tgt_kpm;
-  if ((e = launch_attn(DH, at, B, s, prof)) != hipSuccess) return e;
+  if ((e = launch_attn(DH, at, B, s, prof, items)) != hipSuccess) return e;
   if ((e = residual(y.sa_out, sc.O, bsD)) != hipSuccess) return e;
   launch_layernorm(X, bsD, ld, A + y.n1w, A + y.n1b, B, D, T, s);
   // ---- cross-attention block
   if ((e = gemm(A, y.ca_q, B, T, X, bsD, ld, bias_epi(sc.QKV, 3 * bsD, ld, A + y.ca_q.b_off, D, ACT_NONE), s)) != hipSuccess) return e;
   at.K = KV; at.k_bs = kv_bs; at.V = KV + (size_t)D * ld; at.v_bs = kv_bs;
   at.kmask = mem_kpm;
-  if ((e = launch_attn(DH, at, B, s, prof)) != hipSuccess) return e;
+  if ((e = launch_attn(DH, at, B, s, prof, items)) != hipSuccess) return e;
   if ((e = residual(y.ca_out, sc.O, bsD, ca_bias, ca_bias_ld, ca_bias_bs)) != hipSuccess) return e;
   launch_layernorm(X, bsD, ld, A + y.n2w, A + y.n2b, B, D, T, s);
   // ---- feed-forward block

@@ -152,7 +152,14 @@ extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, 
   if (!S->ok) return fail(h, FDX_E_STATE, "fdx_tfdec_prepare: no weights attached");
   if (!cond || B <= 0 || T <= 0) return fail(h, FDX_E_ARG, "fdx_tfdec_prepare: bad cond/B/T");
   const auto& d = S->d;
-  if (T > d.n_positions) return fail(h, FDX_E_ARG, "fdx_tfdec_prepare: %d frames exceed the positional table (%d)", T, d.n_positions);
+  // exact-ragged row (fdx_sampler_set_items): positions restart at every item, attention stays inside it
+  const bool ragged = h->n_items() > 0;
+  if (ragged && (B != 1 || h->items_T != T))
+    return fail(h, FDX_E_ARG, "fdx_tfdec_prepare: the item layout describes one row of %d frames, got a batch of %d x %d (clear it with fdx_sampler_set_items(.., 0, ..))",
+                h->items_T, B, T);
+  const int Tpos = ragged ? h->items_max_len : T;
+  if (Tpos > d.n_positions) return fail(h, FDX_E_ARG, "fdx_tfdec_prepare: %d frames exceed the positional table (%d)", Tpos, d.n_positions);
+  const int* pidx = ragged ? static_cast<const int*>(h->pidx_dev.p) : nullptr;
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
   const auto& l = S->l;
@@ -170,7 +177,8 @@ extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, 
   FDX_HIP(h, b.O.ensure(sz(D), geom, s)); FDX_HIP(h, b.G.ensure(sz(H), geom, s)); FDX_HIP(h, b.Hin.ensure(sz(H), geom, s));
   FDX_HIP(h, b.H2.ensure(sz(D), geom, s)); FDX_HIP(h, b.C0.ensure(sz(D), geom, s));
   FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s));
-  FDX_HIP(h, b.AP.ensure(attn_part_floats(B, T, D, ld) * sizeof(float), false, s)); FDX_HIP(h, b.AML.ensure(attn_ml_floats(B, T) * sizeof(float), false, s));
+  FDX_HIP(h, b.AP.ensure(attn_part_floats(B, T, D, ld, h->n_items()) * sizeof(float), false, s));
+  FDX_HIP(h, b.AML.ensure(attn_ml_floats(B, T, h->n_items(), h->items_max_len) * sizeof(float), false, s));
   // C0 = condition_projection(conditioner) + positional_embedding[:T] * position_scale_key   (convnext.py:348,353-357)
   hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, b.condp.f() + kHalo, (long)E * ld, ld, cond, (long)E * T, T, E, T,
                      1.f, (const uint8_t*)nullptr);
@@ -179,7 +187,7 @@ extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, 
   FDX_HIP(h, gemm(A, l.cond2, B, T, b.c1.f() + kHalo, (long)H * ld, ld,
                   bias_epi(b.C0.f() + kHalo, (long)D * ld, ld, A + l.cond2.b_off, D, ACT_NONE), s));
   hipLaunchKernelGGL(k_td_addpos, ew_grid(T, B * D), dim3(kEwBlock), 0, s, b.C0.f() + kHalo, (long)D * ld, ld, A + l.pos, A + l.scale_k,
-                     (const uint8_t*)nullptr, D, T);
+                     (const uint8_t*)nullptr, D, T, pidx);
   // every layer's cross-attention keys / values of C0 (the step's share never needs projecting per call: see the header)
   for (int i = 0; i < L; ++i) {
     const auto& y = l.layers[i];
@@ -248,13 +256,17 @@ int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
   // x = input_projection(x)^T + pos * scale_q, masked                                         (convnext.py:343-346,356-357)
   FDX_HIP(h, gemm(A, l.in0, B, T, xin, (long)M * ld, ld, bias_epi(Hin, bsH, ld, A + l.in0.b_off, H, ACT_GELU), s));
   FDX_HIP(h, gemm(A, l.in2, B, T, Hin, bsH, ld, bias_epi(X, bsD, ld, A + l.in2.b_off, D, ACT_NONE), s));
-  hipLaunchKernelGGL(k_td_addpos, ew_grid(T, B * D), blk, 0, s, X, bsD, ld, A + l.pos, A + l.scale_q, mask, D, T);
+  const bool ragged = h->n_items() > 0 && B == 1 && h->items_T == T;
+  AttnItems items;
+  if (ragged) { items.dev = static_cast<const int4*>(h->items_dev.p); items.host = &h->items; items.max_len = h->items_max_len; }
+  hipLaunchKernelGGL(k_td_addpos, ew_grid(T, B * D), blk, 0, s, X, bsD, ld, A + l.pos, A + l.scale_q, mask, D, T,
+                     ragged ? static_cast<const int*>(h->pidx_dev.p) : (const int*)nullptr);
   // memory = mask(C0 + diffusion_step) (:353,359-360) is never formed: its keys / values are the hoisted ones of C0, the step's share is the
   // per-step bias of each layer's cross-attention out-projection (column col0 of CB; sb_bs = its stride between batch items)
   const DecScratch sc{QKV, O, G, b.AP.f() + kHalo, b.AML.f()};
   for (int i = 0; i < L; ++i)
     FDX_HIP(h, run_declayer(A, l.layers[i], B, T, D, H, ld, X, KVh + (size_t)i * 2 * D * ld, (long)L * 2 * bsD, sc, mask, cmask, s, &h->prof,
-                            b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs));
+                            b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs, items));
   FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
   {
     EpiBias e = bias_epi(eps_out, o_bs, ldo, A + l.out2.b_off, M, ACT_NONE);

@@ -971,8 +971,10 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
   static const bool fuse_unipc = [] { const char* e = getenv("FDX_UNIPC_FUSED"); return !e || atoi(e) != 0; }();
   auto model = [&](const float* xin, int col, bool masked, const EpiUniPC* fuse = nullptr) {
     // the one unmasked call of PLMS uses the conditioner slab of the UNMASKED conditioner (built in the set-up phase)
-    if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked);
-    if (h->den_kind == 2) return fdx_td_forward_core(h, xin, col, 0, masked ? x_mask : nullptr, eps, bs, ld, s, !masked);
+    // (exact-mask mode: the mask marks frames that do not exist, for an item run alone as well -- PLMS's unmasked call keeps it)
+    const bool keep_mask = masked || h->ragged_keep;
+    if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, keep_mask ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked);
+    if (h->den_kind == 2) return fdx_td_forward_core(h, xin, col, 0, keep_mask ? x_mask : nullptr, eps, bs, ld, s, !masked);
     const float* P = (!masked && h->cond_masked) ? h->P2.f() : nullptr;
     // (exact-mask mode: the mask marks frames that do not exist, for an item run alone as well -- PLMS's unmasked call keeps it)
     return wn_forward_core(h, xin, col, 0, (masked || h->ragged_keep) ? x_mask : nullptr, eps, bs, ld, s, P, fuse);
@@ -1131,7 +1133,7 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
     const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
                               (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, h->alloc_gen,
                               (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn, (uint64_t)(uintptr_t)h->td,
-                              (uint64_t)(uintptr_t)h->ragged_keep};
+                              (uint64_t)(uintptr_t)h->ragged_keep, h->items_hash};
     key = fnv1a(parts, sizeof parts, key);
     fdx_ctx::GraphEntry* hit = nullptr;
     for (auto& g : h->graphs) if (g.key == key) hit = &g;
@@ -1182,18 +1184,66 @@ extern "C" int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* tab, 
   if (!h) return FDX_E_ARG;
   if (!h->prepared) return fail(h, FDX_E_STATE, "fdx_sampler_run_ragged: call attach + prepare first");
   if (!x_mask) return fail(h, FDX_E_ARG, "fdx_sampler_run_ragged: null mask");
-  if (h->den_kind != 0) return fail(h, FDX_E_NOIMPL, "fdx_sampler_run_ragged: exact-mask runs are built for the WaveNet denoiser");
   const int B = h->B, T = h->T, ld = h->ld;
+  if (h->den_kind != 0 && h->n_items() && (B != 1 || h->items_T != T))
+    return fail(h, FDX_E_STATE, "fdx_sampler_run_ragged: the item layout (fdx_sampler_set_items) describes a row of %d frames, the prepared batch is %d x %d",
+                h->items_T, B, T);
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
   FDX_HIP(h, h->keepbuf.ensure((size_t)B * ld * sizeof(float), true, s));
   hipLaunchKernelGGL(k_keep_from_mask, dim3((T + 255) / 256, B), dim3(256), 0, s, h->keepbuf.f(), ld, x_mask, B, T);
   // the conv's input must read 0 wherever no frame exists: what earlier runs (other masks) left there is cleared
-  FDX_HIP(h, hipMemsetAsync(h->Y.p, 0, (size_t)B * h->wd.residual_channels * ld * sizeof(float), s));
+  if (h->den_kind == 0) FDX_HIP(h, hipMemsetAsync(h->Y.p, 0, (size_t)B * h->wd.residual_channels * ld * sizeof(float), s));
+  // (ConvNext / transformer: every per-frame op is column-local and the depthwise conv masks its own input, convnext.hip k_dwconv_stats; the
+  // attention layers need the item layout -- their prepare refuses a ragged run without it)
   h->ragged_keep = h->keepbuf.f() + kHalo;
   const int rc = fdx_sampler_run(h, kind, tab, n_rows, x, step_noise, seed, x_mask, st);
   h->ragged_keep = nullptr;
   return rc;
+}
+
+// pidx[t] = t - offset of the item frame t belongs to (0 in holes)
+static __global__ void k_items_pidx(int* __restrict__ pidx, const int4* __restrict__ items, int n_items, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  int p = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const int4 it = items[i];
+    if (t >= it.x && t < it.x + it.y) p = t - it.x;
+  }
+  pidx[t] = p;
+}
+
+extern "C" int fdx_sampler_set_items(fdx_handle h, const int* offsets, const int* lens, int n_items, int T, fdx_stream st) {
+  GenScope gen_scope(h);
+  if (!h) return FDX_E_ARG;
+  if (n_items < 0 || (n_items > 0 && (!offsets || !lens || T <= 0))) return fail(h, FDX_E_ARG, "fdx_sampler_set_items: bad arguments");
+  h->prepared = false;                      // the hoisted condition path depends on the layout (positions): prepare again
+  h->items.clear();
+  h->items_hash = 0; h->items_max_len = 0; h->items_T = 0;
+  if (n_items == 0) return FDX_OK;
+  int end = 0;
+  std::vector<int> packed((size_t)n_items * 4, 0);
+  for (int i = 0; i < n_items; ++i) {
+    if (offsets[i] % 32 || offsets[i] < end || lens[i] <= 0 || offsets[i] + lens[i] > T)
+      return fail(h, FDX_E_ARG, "fdx_sampler_set_items: item %d = [%d, %d) must start at a multiple of 32, follow item %d and end inside the row of %d frames",
+                  i, offsets[i], offsets[i] + lens[i], i - 1, T);
+    end = offsets[i] + lens[i];
+    h->items.push_back(offsets[i]); h->items.push_back(lens[i]);
+    packed[4 * i] = offsets[i]; packed[4 * i + 1] = lens[i];
+    h->items_max_len = std::max(h->items_max_len, lens[i]);
+  }
+  h->items_T = T;
+  h->items_hash = fnv1a(h->items.data(), h->items.size() * sizeof(int), 0x9e3779b97f4a7c15ull) ^ (uint64_t)T;
+  hipStream_t s = as_stream(st);
+  FDX_HIP(h, hipSetDevice(h->device));
+  FDX_HIP(h, h->items_dev.ensure(packed.size() * sizeof(int), false, s));
+  FDX_HIP(h, h->pidx_dev.ensure((size_t)T * sizeof(int), false, s));
+  FDX_HIP(h, hipMemcpyAsync(h->items_dev.p, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  FDX_HIP(h, hipStreamSynchronize(s));     // `packed` is a local
+  hipLaunchKernelGGL(k_items_pidx, dim3((T + 255) / 256), dim3(256), 0, s, static_cast<int*>(h->pidx_dev.p), static_cast<const int4*>(h->items_dev.p), n_items, T);
+  FDX_HIP(h, hipGetLastError());
+  return FDX_OK;
 }
 
 extern "C" int fdx_graph_stats(fdx_handle h, long* captures, long* launches, int* cached) {

@@ -113,26 +113,38 @@ class GaussianDiffusion(nn.Module):
     RAGGED_BUCKET = 64   # the single row is padded to a multiple of this (bounds the number of geometries a stream produces)
 
     def _ragged_gap(self) -> int:
-        """A hole isolates its two sides exactly when it is at least as wide as the widest dilated tap's reach, 2^(dilation_cycle-1)
-        frames (wavenet.py:88-95: k = 3, dilation 2^(i % cycle)).  16 covers dilation_cycle <= 5; a deeper cycle widens the hole."""
+        """A hole isolates its two sides exactly when it is at least as wide as the widest tap's reach.  WaveNet: 2^(dilation_cycle-1) frames
+        (wavenet.py:88-95: k = 3, dilation 2^(i % cycle)); 16 covers dilation_cycle <= 5, a deeper cycle widens the hole.  ConvNext: the
+        depthwise conv has k = 7 (convnext.py:33-40): 3 * 2^(dilation_cycle-1).  The transformer has no convolution (holes only align items)."""
         cyc = int(getattr(self.denoise_fn, "dilation_cycle", 4) or 1)
+        kind = getattr(self.denoise_fn, "_KIND", "")
+        if kind == "convnext":
+            return 3 * 2 ** max(0, cyc - 1)
+        if kind == "tfdec":
+            return 1
         return max(self.RAGGED_GAP, 2 ** max(0, cyc - 1))
 
     def _forward_ragged(self, eng, cond, x, lens, kind, table, step_noise, seed, st):
         """Exact-ragged batch: items laid end to end in one row with holes between them, `fdx_sampler_run_ragged`, results scattered
         back to the padded [B, T, M] layout.  The gathers / scatters are plain copies (torch as plumbing); all arithmetic is in the
-        library."""
-        if not hasattr(_lib.lib(), "fdx_sampler_run_ragged") or getattr(self.denoise_fn, "_KIND", "") != "wavenet":
-            raise NotImplementedError("exact-ragged batches are built for the WaveNet denoiser")
+        library.  The attention-based denoisers (transformer, ConvNext with cross-attention) are also told where the items lie
+        (`fdx_sampler_set_items`): attention stays inside an item and positions restart at its first frame; their items start at
+        multiples of 32 frames."""
+        den_kind = getattr(self.denoise_fn, "_KIND", "")
+        if not hasattr(_lib.lib(), "fdx_sampler_run_ragged") or den_kind not in ("wavenet", "convnext", "tfdec"):
+            raise NotImplementedError("exact-ragged batches need one of the HIP denoisers")
         device = x.device
         B, M, T = x.shape
         gap = self._ragged_gap()
+        align = 1 if den_kind == "wavenet" else 32
         offs, cur = [], 0
         for n in lens:
+            cur = (cur + align - 1) // align * align
             offs.append(cur)
             cur += n + gap
         Tc = cur - gap
         Tc = (Tc + self.RAGGED_BUCKET - 1) // self.RAGGED_BUCKET * self.RAGGED_BUCKET
+        needs_items = den_kind == "tfdec" or (den_kind == "convnext" and getattr(self.denoise_fn, "cross_attention", False))
         cond_c = torch.zeros((1, cond.shape[1], Tc), device=device, dtype=torch.float32)
         x_c = torch.zeros((1, M, Tc), device=device, dtype=torch.float32)
         hole = torch.ones((1, Tc), device=device, dtype=torch.uint8)
@@ -155,19 +167,28 @@ class GaussianDiffusion(nn.Module):
         smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         smax = self.spec_max.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         with eng.lock:
-            self.denoise_fn.prepare(cond_c, None)
-            for r0 in range(0, n_rows, chunk):
-                r1 = min(n_rows, r0 + chunk)
-                if inject and step_noise is not None:
-                    self._ragged_scatter(sn[:r1 - r0, 0], step_noise[r0:r1], cols, flat)
-                elif inject:
-                    for i in range(r1 - r0):
-                        self._ragged_scatter(sn[i:i + 1, 0], draw.normal_()[None], cols, flat)
-                tab = table[r0:r1]
-                _lib.check(_lib.lib().fdx_sampler_run_ragged(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x_c),
-                                                             _lib.ptr(sn if inject else None), seed + r0, _lib.ptr(hole), st), eng.h)
-            _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x_c), 1, M, Tc, C.c_void_p(smin.data_ptr()),
-                                                  C.c_void_p(smax.data_ptr()), smin.numel(), _lib.ptr(mel_c), st), eng.h)
+            if needs_items:
+                oa, la = (C.c_int * B)(*offs), (C.c_int * B)(*lens)
+                _lib.check(_lib.lib().fdx_sampler_set_items(eng.h, oa, la, B, Tc, st), eng.h)
+                self.denoise_fn._prep_sig = None
+            try:
+                self.denoise_fn.prepare(cond_c, None)
+                for r0 in range(0, n_rows, chunk):
+                    r1 = min(n_rows, r0 + chunk)
+                    if inject and step_noise is not None:
+                        self._ragged_scatter(sn[:r1 - r0, 0], step_noise[r0:r1], cols, flat)
+                    elif inject:
+                        for i in range(r1 - r0):
+                            self._ragged_scatter(sn[i:i + 1, 0], draw.normal_()[None], cols, flat)
+                    tab = table[r0:r1]
+                    _lib.check(_lib.lib().fdx_sampler_run_ragged(eng.h, kind, C.c_void_p(tab.ctypes.data), r1 - r0, _lib.ptr(x_c),
+                                                                 _lib.ptr(sn if inject else None), seed + r0, _lib.ptr(hole), st), eng.h)
+                _lib.check(_lib.lib().fdx_denorm_spec(eng.h, _lib.ptr(x_c), 1, M, Tc, C.c_void_p(smin.data_ptr()),
+                                                      C.c_void_p(smax.data_ptr()), smin.numel(), _lib.ptr(mel_c), st), eng.h)
+            finally:
+                if needs_items:      # dense batches again: the layout must not outlive this run
+                    _lib.check(_lib.lib().fdx_sampler_set_items(eng.h, None, None, 0, 0, st), eng.h)
+                    self.denoise_fn._prep_sig = None
         mel = torch.zeros((B, T, M), device=device, dtype=torch.float32)
         for b, (o, n) in enumerate(zip(offs, lens)):
             mel[b, :n] = mel_c[0, o:o + n]

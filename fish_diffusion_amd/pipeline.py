@@ -86,13 +86,14 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     utterances this rank owns.  `x_init_fn(idx_list, M, T)` / `source_noise_fn(idx_list, L)` let tests inject the random
     draws (initial x_T; (rand_ini, src_noise)) -- by default they are drawn on the device.  `bucket`: every micro-batch is padded
     to a multiple of this many frames (0 / 1 = pad to the longest member only).
-    `exact` (default: True for the WaveNet denoiser in fp32 or fp16x3 storage): padded batches run in the library's EXACT-RAGGED mode
+    `exact` (default: True for the three HIP denoisers in fp32 storage, and the WaveNet in fp16x3): padded batches run in the library's EXACT-RAGGED mode
     -- every utterance's result is what a batch-1 run of it alone gives (the reference's one-segment-at-a-time loop): bit for bit in
     fp32 storage, to fp32 rounding in the opt-in fp16x3 storage (a long row may run the 128-wide fp16-split tiles where the short item alone
     runs the 64 x 64 fp16-split tiles: both fp32-class, not bit-identical to each other) -- and padding costs no arithmetic.  Whether the
-    mode exists is a static property of (denoiser, storage): decided ONCE, before batching (bf16 storage and the ConvNext / transformer
-    denoisers have no exact-mask kernels: an explicit `exact=True` raises NotImplementedError from the library, the default picks the
-    reference's masked batches there).  False: the reference's own padded-batch semantics with x_masks /
+    mode exists is a static property of (denoiser, storage): decided ONCE, before batching (bf16 storage has no exact-mask kernels: an
+    explicit `exact=True` raises NotImplementedError from the library, the default picks the reference's masked batches there; the
+    ConvNext and transformer denoisers run exact since round 5 -- attention per item, positions restarting at every item).  False: the
+    reference's own padded-batch semantics with x_masks /
     cond_masks (the masked tail stays alive inside the receptive field: the last ~75 frames of every padded item differ slightly
     from a run alone).
     `on_error`: "raise" (default) lets the first exception out, as a plain loop would.  "isolate" is the reference's `safe_process`
@@ -139,7 +140,8 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     dev = features[mine[0]].device
     if exact is None:
         den = getattr(diffusion, "denoise_fn", None)
-        exact = type(den).__name__ == "WaveNet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")
+        kind = getattr(den, "_KIND", "")
+        exact = (kind == "wavenet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")) or kind in ("convnext", "tfdec")
     def run_group(idx: List[int]) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
         T = max(lengths[i] for i in idx)
         if bucket and bucket > 1:

@@ -199,6 +199,15 @@ int fdx_sampler_run(fdx_handle h, int kind, const float* host_table, int n_rows,
  * its stand-alone run to fp32 rounding, not bit for bit.  Not available in bf16 storage (FDX_E_NOIMPL). */
 int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* host_table, int n_rows, float* x, const float* step_noise,
                            uint64_t seed, const uint8_t* x_mask, fdx_stream s);
+/* Exact-mask runs of the OTHER denoisers behind the same contract (modules/convnext.py:211 ConvNext.forward, :325 TransformerDecoderDenoiser.forward;
+ * round 5).  The ConvNeXt blocks are a depthwise conv (k = 7, dilation <= 2^(cycle-1): reach 3 * 2^(cycle-1) frames) between per-frame ops, so a
+ * hole at least that wide isolates its sides exactly as for the WaveNet and fdx_sampler_run_ragged needs nothing more.  Attention does not stop
+ * at holes and the positional table is indexed by the frame's position IN ITS UTTERANCE, so the attention-based denoisers (the transformer;
+ * ConvNext with cross-attention) must be told where the items of the ONE row (B == 1) lie: call this BEFORE fdx_*_prepare with host arrays of
+ * n_items offsets (multiples of 32, ascending, non-overlapping) and lengths; self- and cross-attention then run per item over its own frames
+ * and positions restart at each offset.  n_items == 0 clears the layout (dense batches).  T = length of the row the items lie in.  Every item
+ * comes out bit-identical to a batch-1 run of it alone (the key split of an item's attention depends on its own length only). */
+int fdx_sampler_set_items(fdx_handle h, const int* host_offsets, const int* host_lens, int n_items, int T, fdx_stream s);
 /* The start of shallow diffusion, diffusion.py:223-232: out = q_sample(norm_spec(src), t, noise).
  *   normalise != 0: v = (src - spec_min) / (spec_max - spec_min) * 2 - 1 (diffusion.py:315-316).  spec_min/max are host arrays of
  *   n_spec floats; the reference's [1,1,n] buffers broadcast against the LAST axis of the [B,M,T] tensor, so n_spec is 1 or T.

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
   uint8_t* dmask;
   attn_ksplit_forced() = 8;
   CHECK(hipMalloc(&dq, n3 * 4)); CHECK(hipMalloc(&dO0, n1 * 4)); CHECK(hipMalloc(&dO1, n1 * 4));
-  CHECK(hipMalloc(&dP, attn_part_floats(B, T, D, ld) * 4)); CHECK(hipMalloc(&dML, attn_ml_floats(B, T) * 4));
+  CHECK(hipMalloc(&dP, (size_t)8 * B * D * ld * 4)); CHECK(hipMalloc(&dML, (size_t)8 * B * kHeads * 2 * round_up(T, 128) * 4));
   CHECK(hipMalloc(&dmask, hmask.size()));
   CHECK(hipMemcpy(dq, hq.data(), n3 * 4, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(dmask, hmask.data(), hmask.size(), hipMemcpyHostToDevice));
