@@ -332,12 +332,15 @@ class SclkSampler:
 
     def __init__(self, dev_index: int, period_s: float = 0.02):
         self.period, self.samples, self._stop, self._thr, self.path, self.why = period_s, [], threading.Event(), None, None, None
+        self.power_path, self.power = None, []      # board power (hwmon, microwatts) beside the clock: VERDICT r4 item 4(a)
         try:
             p = torch.cuda.get_device_properties(dev_index)
             want = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
             for card in sorted(glob.glob("/sys/class/drm/card*/device")):
                 if os.path.basename(os.path.realpath(card)) == want and os.path.exists(os.path.join(card, "pp_dpm_sclk")):
                     self.path = os.path.join(card, "pp_dpm_sclk")
+                    pw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_input")))
+                    self.power_path = pw[0] if pw else None
             if self.path is None:
                 self.why = f"no /sys/class/drm/card*/device matches PCI {want}"
         except Exception as e:   # noqa: BLE001
@@ -357,6 +360,11 @@ class SclkSampler:
             v = self._read()
             if v is not None:
                 self.samples.append(v)
+            if self.power_path:
+                try:
+                    self.power.append(float(open(self.power_path).read()) / 1e6)
+                except Exception:   # noqa: BLE001
+                    pass
             self._stop.wait(self.period)
 
     def __enter__(self):
@@ -374,9 +382,13 @@ class SclkSampler:
         if not self.samples:
             return {"mean": None, "samples": 0, "source": self.path, "note": self.why or "no samples"}
         s = sorted(self.samples)
-        return {"mean": round(sum(s) / len(s), 1), "median": s[len(s) // 2], "min": s[0], "max": s[-1], "samples": len(s),
-                "period_ms": self.period * 1e3, "source": self.path,
-                "note": "sysfs pp_dpm_sclk ('*' level) of this GPU, sampled by a host thread during the timed region"}
+        out = {"mean": round(sum(s) / len(s), 1), "median": s[len(s) // 2], "min": s[0], "max": s[-1], "samples": len(s),
+               "period_ms": self.period * 1e3, "source": self.path,
+               "note": "sysfs pp_dpm_sclk ('*' level) of this GPU, sampled by a host thread during the timed region"}
+        if self.power:
+            out["board_power_w"] = {"mean": round(sum(self.power) / len(self.power), 1), "max": round(max(self.power), 1), "samples": len(self.power),
+                                    "source": self.power_path}
+        return out
 
 
 def cpu_denoiser(diff):
@@ -812,14 +824,22 @@ def headline_stages_and_pcie(w, steps, args, dev, extra):
     """Per-stage times of one more step (torch events on the current stream: whole stages, not single kernels) and the PCIe-inclusive repeat."""
     diff, voc, pool, f0, interval = w.diff, w.voc, w.pool, w.f0, w.interval
     B, T, hop = w.B, w.T, w.hop
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    voc.wav2spec(torch.zeros(B, T * hop, device=dev))      # (first call: DFT / filterbank tables, frame buffers)
     ev[0].record()
     mel = diff(pool[0], sampler_interval=interval)
     ev[1].record()
-    voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)
+    wav = voc.model(mel.transpose(1, 2), f0, mel_scale=2.30259)
     ev[2].record()
+    # SURVEY 8(d)'s fourth stage: the STFT / mel front end (`NsfHifiGAN.wav2spec`, nsf_hifigan.py:91-107) on the waveform just produced --
+    # outside the timed region (the mel -> waveform path does not call it), here for the per-stage figure only
+    voc.wav2spec(wav[:, 0])
+    ev[3].record()
     torch.cuda.synchronize()
-    stages = {"denoise": round(ev[0].elapsed_time(ev[1]), 2), "vocoder": round(ev[1].elapsed_time(ev[2]), 2)}
+    stages = {"denoise": round(ev[0].elapsed_time(ev[1]), 2), "vocoder": round(ev[1].elapsed_time(ev[2]), 2),
+              "mel": round(ev[2].elapsed_time(ev[3]), 3),
+              "note": "torch events around whole stages of ONE extra step after the timed region; `mel` = wav2spec (reflect pad + Hann + DFT + magnitude + "
+                      "slaney filterbank + log) of the produced waveform, not part of the mel -> waveform step"}
     if not args.no_pcie:      # the same step with host-resident inputs / outputs (SURVEY 8d): reported beside `value`
         hf = [p.cpu().pin_memory() for p in pool[:max(2, min(len(pool), steps))]]
         hf0 = f0.cpu().pin_memory()

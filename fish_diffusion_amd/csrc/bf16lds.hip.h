@@ -362,8 +362,7 @@ __global__ __launch_bounds__(BfGeom<WN>::kThreads, WN == 4 ? 1 : 2) void bf16lds
       }
     }
   }
-  FDX_STAMP(5);
-  FDX_STAMP_RT1();
+  FDX_STAMP_END();
 }
 
 template <class Epi, int WN, int F16S>

@@ -139,12 +139,17 @@ inline int use_xcd_rect(int n_tiles_n, int n_mt, int taps) {
 // slot 7: the wave's lifetime on the constant 100 MHz real-time counter (s_memrealtime): shader cycles / real time = the clock the kernel ran at
 #define FDX_STAMP_RT0() const unsigned long long fdx_rt0 = __builtin_amdgcn_s_memrealtime()
 #define FDX_STAMP_RT1() do { if (a.trace && lane == 0) a.trace[((long)blockIdx.x * (blockDim.x >> 6) + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - fdx_rt0; } while (0)
+// the last shader-clock stamp and the real-time reading taken BACK TO BACK, before either is stored (round 5: with FDX_STAMP(5); FDX_STAMP_RT1();
+// the real-time window also held the wait for slot 5's own store to issue behind the epilogue's stores -- is that the "2.13 GHz"?)
+#define FDX_STAMP_END() do { const unsigned long long fdx_c5 = __builtin_amdgcn_s_memtime(), fdx_r1 = __builtin_amdgcn_s_memrealtime();         \
+    if (a.trace && lane == 0) { unsigned long long* fdx_t = a.trace + ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 8; fdx_t[5] = fdx_c5; fdx_t[7] = fdx_r1 - fdx_rt0; } } while (0)
 struct TraceState { unsigned long long* buf = nullptr; int max_launches = 0, n = 0, blocks_cap = 0; };
 inline TraceState g_trace;
 #else
 #define FDX_STAMP(k) do { } while (0)
 #define FDX_STAMP_RT0() do { } while (0)
 #define FDX_STAMP_RT1() do { } while (0)
+#define FDX_STAMP_END() do { } while (0)
 #endif
 
 __device__ __forceinline__ void conv_args_cold(ConvArgs& a, const ConvArgsCold& c) {

@@ -197,8 +197,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(FDX_CONV_HOT_PARAMS, Co
     if constexpr (Epi::kPaired) epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), rsum(sidx + 8), pre[i]);
     else epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), pre[i]);
   }
-  FDX_STAMP(5);
-  FDX_STAMP_RT1();
+  FDX_STAMP_END();
 }
 
 template <class Epi>

@@ -343,8 +343,7 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
     if constexpr (Epi::kPaired) epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), rsum(sidx + NR * 2), pre[i]);
     else epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), pre[i]);
   }
-  FDX_STAMP(5);
-  FDX_STAMP_RT1();
+  FDX_STAMP_END();
 }
 
 template <class Epi, int NR, int NM>
