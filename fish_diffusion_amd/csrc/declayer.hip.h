@@ -145,6 +145,15 @@ struct AttnArgs {
 #else
 #define FDX_ATTN_STAMP(k) do { } while (0)
 #endif
+// FDX_ATTN_TRACE == 2: the phases INSIDE the second tile instead of whole tiles (slots 3..7: tile start, scores issued, softmax done, second
+// product issued, next tile staged + barrier); the order of the phases is pinned, so this build is a little slower than the product's
+#if defined(FDX_ATTN_TRACE) && FDX_ATTN_TRACE == 2
+#define FDX_ATTN_FINE(k) do { __builtin_amdgcn_sched_barrier(0); if (kt == 1) FDX_ATTN_STAMP(k); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FDX_ATTN_COARSE(k) do { } while (0)
+#else
+#define FDX_ATTN_FINE(k) do { } while (0)
+#define FDX_ATTN_COARSE(k) FDX_ATTN_STAMP(k)
+#endif
 
 // NQ = 32-query blocks per workgroup: 2 (64 queries) when that already fills the chip, 1 to double the workgroup count
 // Four waves (one per SIMD) split the key tiles.  (Eight waves = two per SIMD without the register prefetch: 41.5 us against 29.4, round 4.)
@@ -437,8 +446,8 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
     mnext = mrow[(unsigned)min(k0 + lane, a.Tk - 1)];
   };
   auto stage = [&](float* buf, int k0) __attribute__((always_inline)) {
-    float* kb = buf;
-    float* vb = buf + KT;
+    float* vb = buf;           // V tile first: its fragment reads then reach every key from two lane bases with 8-bit dword offsets, and the K
+    float* kb = buf + VT;      // tile (VT = 65 x 64 dwords behind) every fragment from ONE base with ds_read2st64's 64-dword offset units
     const bool tail = k0 + 64 > a.Tk;          // columns past Tk are row padding: whatever they hold must not reach 0 * V
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
@@ -467,8 +476,9 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
   for (int kt = 0; kt < n_kt; ++kt) {
     const int k0 = kbeg + kt * 64;
     const bool more = kt + 1 < n_kt;
-    float* kb = lds + (kt & 1) * (KT + VT);
-    float* vb = kb + KT;
+    float* vb = lds + (kt & 1) * (KT + VT);
+    float* kb = vb + VT;
+    FDX_ATTN_FINE(3);
     if (more) fetch(k0 + 64);                      // in flight behind this tile's two products
     // keys this tile must ignore (past this split's range / past Tk / key padding), as a wave-uniform bit set
     const unsigned long long badm = __ballot((k0 + lane >= kend) || (has_mask && mreg != 0));
@@ -490,6 +500,7 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[ks * 128 + lane], qreg[ks], s[0], 0, 0, 0);
     }
+    FDX_ATTN_FINE(4);
     // ---- key mask + online softmax over the key axis (accumulator registers of one lane + one cross-half exchange)
     if (badm != 0ull) {
 #pragma unroll
@@ -535,6 +546,7 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
       }
     sum += __shfl_xor(sum, 32);
     l += sum;
+    FDX_ATTN_FINE(5);
     // ---- O^T += V P^T : the k-pair of step (rb, r) is the key pair the two lane halves hold in s[rb][r]
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -550,14 +562,16 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
         }
       }
     }
+    FDX_ATTN_FINE(6);
     if (more) {
       stage(lds + ((kt + 1) & 1) * (KT + VT), k0 + 64);
       mreg = mnext;
     }
     __syncthreads();
-    if (kt < 3) FDX_ATTN_STAMP(3 + kt);
+    FDX_ATTN_FINE(7);
+    if (kt < 3) FDX_ATTN_COARSE(3 + kt);
   }
-  FDX_ATTN_STAMP(6);
+  FDX_ATTN_COARSE(6);
 
   const int q = q0 + n;
   if (q >= a.Tq) return;

@@ -139,24 +139,32 @@ int main(int argc, char** argv) {
     CHECK(hipStreamSynchronize(s));
     std::vector<unsigned long long> tr(nw * 8);
     CHECK(hipMemcpy(tr.data(), dtrace, nw * 8 * 8, hipMemcpyDeviceToHost));
+#if FDX_ATTN_TRACE == 2
+    const char* names[] = {"Q loads issued -> Q scaled (first fabric round trip)", "first K / V tile staged + barrier", "(tile 0)",
+                           "tile 1: next tile's loads issued + score product issued", "tile 1: softmax (mask, max, exp2, sum)",
+                           "tile 1: second product issued", "tile 1: next tile staged into LDS + barrier"};
+    const int last = 7;
+#else
     const char* names[] = {"Q loads issued -> Q scaled (first fabric round trip)", "first K / V tile staged + barrier", "tile 0", "tile 1", "tile 2",
-                           "remaining tiles"};
-    double sums[6] = {0}, tot = 0;
+                           "remaining tiles", ""};
+    const int last = 6;
+#endif
+    double sums[7] = {0}, tot = 0;
     size_t cnt = 0;
     for (size_t w = 0; w < nw; ++w) {
       const unsigned long long* t = &tr[w * 8];
-      if (!t[0] || !t[6]) continue;
+      if (!t[0] || !t[last]) continue;
       unsigned long long prev = t[0];
-      for (int k = 1; k <= 6; ++k) {
+      for (int k = 1; k <= last; ++k) {
         const unsigned long long cur = t[k] ? t[k] : prev;
         sums[k - 1] += (double)(cur - prev);
         prev = cur;
       }
-      tot += (double)(t[6] - t[0]);
+      tot += (double)(t[last] - t[0]);
       ++cnt;
     }
-    printf("k_attn_qs<64>, keys split %d ways: mean shader cycles per wave over %zu waves (stamps are s_memtime), start -> last barrier %.0f:\n", ks, cnt, tot / cnt);
-    for (int k = 0; k < 6; ++k) printf("    %-58s %9.0f\n", names[k], sums[k] / cnt);
+    printf("k_attn_qs<64>, keys split %d ways: mean shader cycles per wave over %zu waves (stamps are s_memtime), first -> last stamp %.0f:\n", ks, cnt, tot / cnt);
+    for (int k = 0; k < last; ++k) printf("    %-62s %9.0f\n", names[k], sums[k] / cnt);
   }
 #endif
   return 0;
