@@ -260,7 +260,7 @@ def usable_cores() -> int:
 
 
 TRAFFIC_KEYS = {"convgate": ("EpiGate",), "outproj": ("EpiResSkip",), "nsf_resblock": ("2, false, 1, EpiResblock",),
-                "rg_resblock": ("2, false, 1, EpiResblock",), "cn_pwconv1": ("2, true, 2, EpiBias",), "td_attn": ("k_attn",)}
+                "rg_resblock": ("2, false, 1, EpiResblock",), "cn_pwconv1": ("2, true, 2, EpiBias",), "td_attn": ("k_attn_qs",)}
 
 
 def pmc_traffic(config: str, kernel: str, expect: dict):
