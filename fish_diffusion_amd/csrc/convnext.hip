@@ -125,25 +125,30 @@ __global__ void k_cn_addpos(float* out, const float* in, long bs, int ld, const 
 constexpr int kCnCh = 32;            // channels per workgroup
 constexpr int kCnMaxW = 64 + 6 * 8;  // widest staged row (dilation 8)
 
-__global__ __launch_bounds__(256) void k_dwconv_stats(float* __restrict__ U, float* __restrict__ ST, const float* __restrict__ X, long bs,
-                                                      int ld, const float* __restrict__ CP, long cp_bs,   // layer slab [D][ld]
+// (argument order: what the first loads need -- X, geometry, CP, SB -- fills the 14 dwords the dispatcher preloads into SGPRs
+// (-amdgpu-kernarg-preload-count=14, _build.py); the rest is fetched from the kernarg segment while those loads are in flight.  With the
+// outputs first, every group of arguments was a kernarg round trip in front of its first use.)
+__global__ __launch_bounds__(256) void k_dwconv_stats(const float* __restrict__ X, long bs, int ld, int T, int dil, int D,
+                                                      const float* __restrict__ CP, long cp_bs,            // layer slab [D][ld]
                                                       const float* __restrict__ SB, int sb_ld, int sb_bs,  // [D][sb_ld], column = step
-                                                      const uint8_t* __restrict__ mask, const float* __restrict__ dw_w,
-                                                      const float* __restrict__ dw_b, int D, int T, int dil) {
+                                                      const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ U, float* __restrict__ ST) {
   __shared__ float v[kCnCh][kCnMaxW];
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = blockIdx.x * 64, g = blockIdx.y, b = blockIdx.z;
   const int W = 64 + 6 * dil, tl = t0 - 3 * dil;
-  // ---- stage v: wave wv loads channels wv, wv + 4, ...; lanes cover the W columns in two chunks
-  bool ok[2];
+  // ---- stage v: wave wv loads channels wv, wv + 4, ...; lanes cover the W columns in two chunks.  Order of issue: (1) the frame's x and
+  // condition values, which need only preloaded arguments; (2) ONE kernarg fetch for everything else (touched together below: left to their first
+  // uses they were a round trip each); (3) the mask bytes, step projections and taps, all unconditional; then the first wait.
+  bool inside[2];
   int col[2], tq[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     col[q] = lane + 64 * q;
     const int tt = tl + col[q];
     tq[q] = min(max(tt, 0), T - 1);   // loads are unconditional (all in flight at once) from a clamped frame, then selected
-    ok[q] = col[q] < W && tt >= 0 && tt < T && !(mask && mask[(long)b * T + tq[q]]);
+    inside[q] = col[q] < W && tt >= 0 && tt < T;
   }
   const float* xb = X + b * bs;
   const float* cb = CP + b * cp_bs;
@@ -151,13 +156,33 @@ __global__ __launch_bounds__(256) void k_dwconv_stats(float* __restrict__ U, flo
 #pragma unroll
   for (int j = 0; j < kCnCh / 4; ++j) {
     const int c = g * kCnCh + wv + 4 * j;
-    sbv[j] = SB[(long)c * sb_ld + b * sb_bs];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       xv[j][q] = xb[(long)c * ld + tq[q]];
       cv[j][q] = CP ? cb[(long)c * ld + tq[q]] : 0.f;
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  if ((reinterpret_cast<uintptr_t>(dw_w) | reinterpret_cast<uintptr_t>(dw_b) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(ST) |
+       reinterpret_cast<uintptr_t>(mask) | (uintptr_t)(unsigned)sb_ld | (uintptr_t)(unsigned)sb_bs) == 0) return;
+  const uint8_t* mrow = mask ? mask + (long)b * T : reinterpret_cast<const uint8_t*>(dw_w);   // no mask: any readable bytes, ignored
+  uint8_t mb[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) mb[q] = mrow[mask ? tq[q] : 0];      // (used below, behind the other loads' issue: a use here is a vmcnt(0))
+  // (the wave's 8 step-projection values as one vector load, lane j & 7 -> channel wv + 4 j: as wave-uniform loads they were 8 scalar loads
+  // with a wait behind each, in front of everything else)
+  const float sbl = SB[(long)(g * kCnCh + wv + 4 * (lane & 7)) * sb_ld + b * sb_bs];
+  // the 8 x 7 taps + biases this wave's channels need, fetched with the frame (behind the barrier they would be a second memory round trip)
+  // (ONE vector load per wave: its 8 channels' 56 taps are contiguous, lanes 56..63 take the 8 biases; as 64 wave-uniform loads hipcc issued
+  // 64 scalar loads with a wait behind each)
+  const int c8 = g * kCnCh + wv * 8;
+  const float wl = lane < 56 ? dw_w[c8 * 7 + lane] : dw_b[c8 + lane - 56];
+  __builtin_amdgcn_sched_barrier(0);
+  bool ok[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) ok[q] = inside[q] && !(mask && mb[q]);
+#pragma unroll
+  for (int j = 0; j < kCnCh / 4; ++j) sbv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sbl), j));
 #pragma unroll
   for (int j = 0; j < kCnCh / 4; ++j)
 #pragma unroll
@@ -168,13 +193,16 @@ __global__ __launch_bounds__(256) void k_dwconv_stats(float* __restrict__ U, flo
   const int t = t0 + lane;
   float u[8];
   float s1 = 0.f;
+  auto bcast = [&](int src) __attribute__((always_inline)) {   // wave-uniform value of lane `src` (a scalar register)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), src));
+  };
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int ch = wv * 8 + j, c = g * kCnCh + ch;
+    const int ch = wv * 8 + j;
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) acc += dw_w[c * 7 + k] * v[ch][lane + k * dil];
-    u[j] = acc + dw_b[c];
+    for (int k = 0; k < 7; ++k) acc += bcast(j * 7 + k) * v[ch][lane + k * dil];
+    u[j] = acc + bcast(56 + j);
     s1 += u[j];
   }
   red[wv][lane] = s1;
@@ -473,8 +501,8 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
                               nullptr, 1, 0, items));
     }
     const dim3 grid((T + 63) / 64, D / kCnCh, B);
-    hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, N, b.ST.f(), X, bsD, ld, CP ? CP + (size_t)i * D * ld : nullptr, (long)L * D * ld,
-                       SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, mask, A + l.dw_w[i], A + l.dw_b[i], D, T, l.dil[i]);
+    hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, X, bsD, ld, T, l.dil[i], D, CP ? CP + (size_t)i * D * ld : nullptr, (long)L * D * ld,
+                       SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, A + l.dw_w[i], A + l.dw_b[i], mask, N, b.ST.f());
     {  // pwconv1 over LayerNorm(u): centring + rstd inside the GEMM, affine folded into the packed weights
       const PackedW& p = l.pw1[i];
       ConvGeom gg{B, T, p.cin8, 1, 0, 0, p.n_mtiles};

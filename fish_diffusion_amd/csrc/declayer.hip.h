@@ -70,8 +70,7 @@ template <int FR>
 __global__ __launch_bounds__(256) void k_td_layernorm(float* __restrict__ X, long bs, int ld, const float* __restrict__ w,
                                                       const float* __restrict__ bia, int D, int T, float eps) {
   constexpr int CG = 256 / FR, CPT = 512 / CG;       // channel groups; channels per thread at the largest D (512)
-  __shared__ float red[4][FR];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[CG][2][FR];                   // per channel group and frame: the group's mean and centred sum of squares
   const int tc = threadIdx.x & (FR - 1), cg = threadIdx.x / FR;
   const int b = blockIdx.y, t = blockIdx.x * FR + tc;
   const int cpt = D / CG;
@@ -80,28 +79,35 @@ __global__ __launch_bounds__(256) void k_td_layernorm(float* __restrict__ X, lon
   // (unconditional loads from a clamped row: behind `if (ci < cpt)` hipcc waits for each load before it issues the next --
   // the kernel's time was proportional to the channels per thread: 11.3 us at 16)
   float u[CPT];
-  float s1 = 0.f;
 #pragma unroll
   for (int ci = 0; ci < CPT; ++ci) u[ci] = xb[(long)(cg * cpt + min(ci, cpt - 1)) * ld];
-#pragma unroll
-  for (int ci = 0; ci < CPT; ++ci) s1 += ci < cpt ? u[ci] : 0.f;
-  auto total = [&](float v) {                         // over the channel groups: lanes of equal frame, then the four waves
-#pragma unroll
-    for (int off = FR; off < 64; off <<= 1) v += __shfl_xor(v, off);
-    __syncthreads();
-    if (lane < FR) red[wave][lane] = v;
-    __syncthreads();
-    return (red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]);
-  };
-  const float mean = total(s1) / (float)D;
-  float s2 = 0.f;
-#pragma unroll
-  for (int ci = 0; ci < CPT; ++ci) { const float dl = u[ci] - mean; s2 += ci < cpt ? dl * dl : 0.f; }
-  const float rstd = 1.f / sqrtf(total(s2) / (float)D + eps);
-  if (!live) return;
+  // (the affine parameters are fetched HERE, with the frame: behind the reduction's barrier -- where they are used, and where hipcc leaves
+  // a load it may not move across a barrier -- they cost the kernel one more memory round trip at its very end)
   float wv[CPT], bv[CPT];
 #pragma unroll
   for (int ci = 0; ci < CPT; ++ci) { const int c = cg * cpt + min(ci, cpt - 1); wv[ci] = w[c]; bv[ci] = bia[c]; }
+  // Two-pass statistics of the thread's own channels (exact), then ONE exchange: every thread publishes (mean_g, M2_g) of its group and
+  // combines the CG groups of its frame in a fixed order (Chan et al.: M2 = sum M2_g + n_g sum (mean_g - mean)^2 -- products of centred
+  // quantities only).  Round 4 ran two shuffle + LDS reductions back to back (mean, then the centred squares): two more barriers.
+  float s1 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < CPT; ++ci) s1 += ci < cpt ? u[ci] : 0.f;
+  const float mean_g = s1 / (float)cpt;
+  float m2_g = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < CPT; ++ci) { const float dl = u[ci] - mean_g; m2_g += ci < cpt ? dl * dl : 0.f; }
+  red[cg][0][tc] = mean_g;
+  red[cg][1][tc] = m2_g;
+  __syncthreads();
+  float msum = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < CG; ++g) { msum += red[g][0][tc]; m2 += red[g][1][tc]; }
+  const float mean = msum / (float)CG;
+  float dev2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < CG; ++g) { const float dl = red[g][0][tc] - mean; dev2 += dl * dl; }
+  const float rstd = 1.f / sqrtf((m2 + (float)cpt * dev2) / (float)D + eps);
+  if (!live) return;
 #pragma unroll
   for (int ci = 0; ci < CPT; ++ci)
     if (ci < cpt) xb[(long)(cg * cpt + ci) * ld] = (u[ci] - mean) * rstd * wv[ci] + bv[ci];
@@ -604,34 +610,37 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
 // O[c][q] = sum_s 2^(m_s - M) P_s[c][q] / sum_s 2^(m_s - M) l_s,  M = max_s m_s  -- splits folded in index order (deterministic).
 // One thread = one query x 4 channels; KSP is a template parameter so that all 4 KSP operand loads are unconditional and in flight
 // together (with `if (s < ksplit)` around each load hipcc waited for every load in turn: 64 dependent round trips, 21 us per launch).
+// (scalar arguments, the 14 dwords the dispatcher preloads first: a by-value AttnArgs is fetched from the kernarg segment, one fabric round trip in
+// front of a kernel that is three round trips long)
 template <int DH, int KSP>
-__global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
+__global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ P, const float* __restrict__ ML, float* __restrict__ O, long o_bs,
+                                                      long p_split, int ldo, int TqR, int Tq, int B, const int4* __restrict__ items, int ks_force) {
   constexpr int CH = DH / 16;                 // 16-channel chunks per head
   const int q = blockIdx.x * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
   const int h = blockIdx.y / CH, chunk = blockIdx.y - h * CH;
   int b = blockIdx.z, col0 = 0, ks = KSP;
   const int slot = blockIdx.z;
-  if (a.items) {
-    const int4 it = a.items[blockIdx.z];
-    b = 0; col0 = it.x; a.Tq = it.y;
-    ks = attn_ksplit_of(1, it.y, it.y, a.ks_force);
+  if (items) {
+    const int4 it = items[blockIdx.z];
+    b = 0; col0 = it.x; Tq = it.y;
+    ks = attn_ksplit_of(1, it.y, it.y, ks_force);
     if (ks == 1 || blockIdx.x * 64 >= it.y) return;      // an unsplit item was written normalised by the attention kernel itself
   }
-  const int qc = min(q, a.Tq - 1);
+  const int qc = min(q, Tq - 1);
   const float NEG = -__builtin_inff();
   float w[KSP], lv[KSP], M = NEG;
 #pragma unroll
   for (int s = 0; s < KSP; ++s) {             // (loads are unconditional -- a split the item does not have reads a sibling's slot -- and selected)
-    const float* ml = a.ML + ((((long)s * a.B + slot) * kHeads + h) * 2) * a.TqR;
+    const float* ml = ML + ((((long)s * B + slot) * kHeads + h) * 2) * TqR;
     w[s] = ml[qc];
-    lv[s] = ml[a.TqR + qc];
+    lv[s] = ml[TqR + qc];
   }
-  const long off = b * a.o_bs + (long)(h * DH + chunk * 16 + cg * 4) * a.ldo + col0 + qc;
+  const long off = b * o_bs + (long)(h * DH + chunk * 16 + cg * 4) * ldo + col0 + qc;
   float pv[4][KSP];
 #pragma unroll
   for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-    for (int s = 0; s < KSP; ++s) pv[ci][s] = a.P[s * a.p_split + off + (long)ci * a.ldo];
+    for (int s = 0; s < KSP; ++s) pv[ci][s] = P[s * p_split + off + (long)ci * ldo];
 #pragma unroll
   for (int s = 0; s < KSP; ++s) {
     w[s] = s < ks ? w[s] : NEG;
@@ -646,13 +655,13 @@ __global__ __launch_bounds__(256) void k_attn_combine(AttnArgs a) {
     L += lv[s] * w[s];
   }
   const float rl = 1.f / L;
-  if (q >= a.Tq) return;
+  if (q >= Tq) return;
 #pragma unroll
   for (int ci = 0; ci < 4; ++ci) {
     float acc = 0.f;
 #pragma unroll
     for (int s = 0; s < KSP; ++s) acc += (s < ks ? pv[ci][s] : 0.f) * w[s];
-    a.O[off + (long)ci * a.ldo] = acc * rl;
+    O[off + (long)ci * ldo] = acc * rl;
   }
 }
 
@@ -704,19 +713,20 @@ hipError_t launch_attn_qs(int DH, AttnArgs a, int B, hipStream_t s, ProfEvents* 
     else fl = 4.0 * (double)a.Tq * a.Tk * (double)(DH * kHeads) * B;
     prof->take(PROF_TD_ATTN, fl, ev0, ev1);
   }
+#define FDX_COMBINE_ARGS a.P, a.ML, a.O, a.o_bs, a.p_split, a.ldo, a.TqR, a.Tq, a.B, a.items, a.ks_force
 #define FDX_ATTN(DH_)                                                                                   \
   {                                                                                                     \
     if (ev0) hipExtLaunchKernelGGL((k_attn_qs<DH_>), grid, blk, 0, s, ev0, ev1, 0, a);                   \
     else hipLaunchKernelGGL((k_attn_qs<DH_>), grid, blk, 0, s, a);                                       \
     const dim3 cgrid((Tq_grid + 63) / 64, kHeads * (DH_ / 16), n_z);                                     \
     switch (a.ksplit) {                                                                                 \
-      case 2: hipLaunchKernelGGL((k_attn_combine<DH_, 2>), cgrid, blk, 0, s, a); break;                  \
-      case 3: hipLaunchKernelGGL((k_attn_combine<DH_, 3>), cgrid, blk, 0, s, a); break;                  \
-      case 4: hipLaunchKernelGGL((k_attn_combine<DH_, 4>), cgrid, blk, 0, s, a); break;                  \
-      case 5: hipLaunchKernelGGL((k_attn_combine<DH_, 5>), cgrid, blk, 0, s, a); break;                  \
-      case 6: hipLaunchKernelGGL((k_attn_combine<DH_, 6>), cgrid, blk, 0, s, a); break;                  \
-      case 7: hipLaunchKernelGGL((k_attn_combine<DH_, 7>), cgrid, blk, 0, s, a); break;                  \
-      case 8: hipLaunchKernelGGL((k_attn_combine<DH_, 8>), cgrid, blk, 0, s, a); break;                  \
+      case 2: hipLaunchKernelGGL((k_attn_combine<DH_, 2>), cgrid, blk, 0, s, FDX_COMBINE_ARGS); break;                  \
+      case 3: hipLaunchKernelGGL((k_attn_combine<DH_, 3>), cgrid, blk, 0, s, FDX_COMBINE_ARGS); break;                  \
+      case 4: hipLaunchKernelGGL((k_attn_combine<DH_, 4>), cgrid, blk, 0, s, FDX_COMBINE_ARGS); break;                  \
+      case 5: hipLaunchKernelGGL((k_attn_combine<DH_, 5>), cgrid, blk, 0, s, FDX_COMBINE_ARGS); break;                  \
+      case 6: hipLaunchKernelGGL((k_attn_combine<DH_, 6>), cgrid, blk, 0, s, FDX_COMBINE_ARGS); break;                  \
+      case 7: hipLaunchKernelGGL((k_attn_combine<DH_, 7>), cgrid, blk, 0, s, FDX_COMBINE_ARGS); break;                  \
+      case 8: hipLaunchKernelGGL((k_attn_combine<DH_, 8>), cgrid, blk, 0, s, FDX_COMBINE_ARGS); break;                  \
       default: break;                                                                                   \
     }                                                                                                   \
   }
@@ -724,6 +734,7 @@ hipError_t launch_attn_qs(int DH, AttnArgs a, int B, hipStream_t s, ProfEvents* 
   else if (DH == 32) FDX_ATTN(32)
   else FDX_ATTN(16)
 #undef FDX_ATTN
+#undef FDX_COMBINE_ARGS
   return hipGetLastError();
 }
 
