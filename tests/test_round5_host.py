@@ -85,3 +85,76 @@ def test_load_checkpoint_schedule_buffers_warn_and_full_unpickler_fallback(lib_b
         m2 = load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu", report=rep)
     assert rep["missing"] == [] and rep["missing_schedule_buffers"] == []
     assert torch.equal(m2.model.text_encoder.projection.weight, sd["model.text_encoder.projection.weight"])
+
+
+# ------------------------------------------------------------------------------------------------ query-split attention: host-checkable logic
+def _ksplit_of(B, Tq, Tk, forced=0, heads=8):
+    """`attn_ksplit_of` (csrc/declayer.hip.h), restated: the formula is read against the source below."""
+    units = (Tk + 31) // 32
+    base = B * heads * ((Tq + 127) // 128)
+    ks = forced if forced > 0 else (224 + base - 1) // base
+    return max(1, min(ks, 8, units))
+
+
+def test_attention_key_split_partition_and_combine_are_exact():
+    """k_attn_qs / k_attn_combine (csrc/declayer.hip.h), the parts that need no GPU: (a) the key range of an item is dealt to `ksplit`
+    workgroups in balanced runs of 32-key units that cover every key exactly once, for every length and split the launcher can pick
+    (incl. the per-item splits of an exact-ragged row, which depend on the item's own length only); (b) folding the splits' (max, sum,
+    un-normalised O) triples in index order with base-2 weights reproduces softmax(QK^T / sqrt(d)) V -- whatever reference maximum a split
+    used (the kernel's lazy maximum is any value within 2^8 of the true one); (c) the staged K tile's LDS order [ks][rb][half][n] is a
+    bijection onto (channel, key) that hands lane (half, n) of k-step ks the MFMA A fragment K[2 ks + half][rb 32 + n]."""
+    import os
+    src = open(os.path.join(os.path.dirname(__file__), "..", "fish_diffusion_amd", "csrc", "declayer.hip.h")).read()
+    assert "int ks = forced > 0 ? forced : (int)((224 + base - 1) / base);" in src and "const long base = (long)B * kHeads * ((Tq + 127) / 128);" in src
+    assert "const int u0 = (int)((long)units * split / ksplit), u1 = (int)((long)units * (split + 1) / ksplit);" in src
+    assert "(d >> 1) * 128 + (c >> 5) * 64 + (d & 1) * 32 + (c & 31)" in src
+    # (a)
+    for T in (1, 31, 32, 33, 64, 65, 129, 430, 861, 1722, 4096):
+        for B in (1, 2, 8, 33):
+            for forced in (0, 1, 3, 5, 8):
+                ks = _ksplit_of(B, T, T, forced)
+                units = (T + 31) // 32
+                assert 1 <= ks <= min(8, units)
+                covered = []
+                for s in range(ks):
+                    u0, u1 = units * s // ks, units * (s + 1) // ks
+                    assert u1 > u0                                   # no empty split
+                    kbeg, kend = u0 * 32, min(u1 * 32, T)
+                    n_kt = (u1 - u0 + 1) >> 1
+                    assert kbeg + 64 * n_kt >= kend and kbeg + 64 * (n_kt - 1) < kend
+                    covered += list(range(kbeg, kend))
+                assert covered == list(range(T)), (T, B, forced)
+    assert _ksplit_of(1, 861, 861) == 4 and _ksplit_of(8, 861, 861) == 1 and _ksplit_of(1, 70, 70) == 3
+    # (b)
+    rng = np.random.default_rng(5)
+    T, dh = 203, 16
+    q, k, v = rng.standard_normal((T, dh)), rng.standard_normal((T, dh)) * 2, rng.standard_normal((T, dh))
+    s2 = (q @ k.T) / np.sqrt(dh) * np.log2(np.e)                     # base-2 scores [query, key]
+    p = np.exp2(s2 - s2.max(1, keepdims=True))
+    want = (p / p.sum(1, keepdims=True)) @ v
+    for ks in (2, 3, 4, 7):
+        units = (T + 31) // 32
+        parts = []
+        for s in range(ks):
+            u0, u1 = units * s // ks, units * (s + 1) // ks
+            sl = slice(u0 * 32, min(u1 * 32, T))
+            m = s2[:, sl].max(1) - rng.uniform(0, 8, T)              # a lazy reference: up to 2^8 below the split's true maximum
+            w = np.exp2(s2[:, sl] - m[:, None])
+            parts.append((m, w.sum(1), w @ v[sl]))
+        M = np.max([m for m, _, _ in parts], axis=0)
+        L = sum(l * np.exp2(m - M) for m, l, _ in parts)
+        got = sum(o * np.exp2(m - M)[:, None] for m, _, o in parts) / L[:, None]
+        assert np.abs(got - want).max() < 1e-12, ks
+    # (c)
+    DH = 64
+    seen = set()
+    for d in range(DH):
+        for c in range(0, 64, 4):                                    # the staging thread's 16-byte group: keys c .. c + 3 of channel d
+            base = (d >> 1) * 128 + (c >> 5) * 64 + (d & 1) * 32 + (c & 31)
+            for e in range(4):
+                seen.add(base + e)
+                ks_, rem = divmod(base + e, 128)
+                rb, lane = divmod(rem, 64)
+                half, n = divmod(lane, 32)
+                assert (2 * ks_ + half, rb * 32 + n) == (d, c + e)
+    assert seen == set(range(DH * 64))
