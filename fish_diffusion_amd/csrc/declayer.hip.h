@@ -161,214 +161,6 @@ struct AttnArgs {
 #define FDX_ATTN_COARSE(k) FDX_ATTN_STAMP(k)
 #endif
 
-// NQ = 32-query blocks per workgroup: 2 (64 queries) when that already fills the chip, 1 to double the workgroup count
-// Four waves (one per SIMD) split the key tiles.  (Eight waves = two per SIMD without the register prefetch: 41.5 us against 29.4, round 4.)
-template <int DH, int NQ>
-__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
-  constexpr int NWV = 4;
-  constexpr int KS = DH / 2;                 // MFMA k-steps of the score product
-  constexpr int RBD = (DH + 31) / 32;        // 32-row blocks of O^T
-  constexpr int VLD = 65;                    // padded row of the staged V tile
-  constexpr int NBLK = RBD * NQ;
-  constexpr int LDS_F = (NWV * DH * VLD > NWV * NBLK * 16 * 64 + NWV * 2 * NQ * 64) ? NWV * DH * VLD : NWV * NBLK * 16 * 64 + NWV * 2 * NQ * 64;
-  __shared__ float lds[LDS_F];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = lane >> 5, n = lane & 31;
-  const int q0 = blockIdx.x * (32 * NQ), h = blockIdx.y, b = blockIdx.z;
-  const float* Qh = a.Q + b * a.q_bs + (long)h * DH * a.ldq;
-  const float* Kh = a.K + b * a.k_bs + (long)h * DH * a.ldk;
-  const float* Vh = a.V + b * a.v_bs + (long)h * DH * a.ldv;
-  const float NEG = -__builtin_inff();
-
-  // B operand of the score product: this lane's slice of Q, for the whole launch, pre-multiplied by 1/sqrt(DH) (as the reference's
-  // multi_head_attention_forward scales q before the product)
-  float qreg[KS][NQ];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int nb = 0; nb < NQ; ++nb) qreg[ks][nb] = Qh[(long)(2 * ks + half) * a.ldq + min(q0 + nb * 32 + n, a.Tq - 1)] * a.scale;
-
-  f32x16 o[RBD][NQ];
-#pragma unroll
-  for (int x = 0; x < RBD; ++x)
-#pragma unroll
-    for (int nb = 0; nb < NQ; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[x][nb][r] = 0.f;
-  float m[NQ], l[NQ];
-#pragma unroll
-  for (int nb = 0; nb < NQ; ++nb) { m[nb] = NEG; l[nb] = 0.f; }
-  float* vt = lds + wave * DH * VLD;
-
-  // The K and V operands of a tile are fetched into registers one tile ahead, two K rows + two V rows behind each k-step of the score
-  // product (their issue slots hide under the MFMAs that have just consumed the registers; the fabric latency runs behind the softmax and
-  // the second product).  Every load is a wave-uniform row pointer + a 32-bit lane offset (no 64-bit vector address arithmetic).
-  // The key-padding mask of a tile is ONE byte per lane (key k0 + lane), fetched with the operands and turned into a 64-bit key set by a
-  // ballot: the softmax selects on bits of a scalar.  (Round 4: it was 32 conditional byte loads per tile, each behind its own vmcnt(0).)
-  const int n_kt = (a.Tk + 63) / 64;
-  const bool has_mask = a.kmask != nullptr;
-  const uint8_t* mrow = has_mask ? a.kmask + (long)b * a.Tk : reinterpret_cast<const uint8_t*>(Kh);   // no mask: any readable bytes, ignored
-  float kreg[KS][2], vreg[DH];
-  unsigned mreg = 0;
-  // (buffer loads: one resource per operand, lane offset in a VGPR, row offset in an SGPR)
-  const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Kh), 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vh), 0, -1, 0x00020000);
-  auto fetch_ks = [&](int k0, int ks) __attribute__((always_inline)) {   // the operands k-step `ks` consumes + two V rows
-    const int kc0 = 4 * (half * a.ldk + min(k0 + n, a.Tk - 1)), kc1 = 4 * (half * a.ldk + min(k0 + 32 + n, a.Tk - 1));
-    const int vc = 4 * min(k0 + lane, a.Tk - 1);
-    kreg[ks][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kres, kc0, 8 * ks * a.ldk, 0));
-    kreg[ks][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kres, kc1, 8 * ks * a.ldk, 0));
-    vreg[2 * ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vres, vc, 8 * ks * a.ldv, 0));
-    vreg[2 * ks + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vres, vc, (8 * ks + 4) * a.ldv, 0));
-  };
-  auto fetch_mask = [&](int k0) __attribute__((always_inline)) { mreg = mrow[(unsigned)min(k0 + lane, a.Tk - 1)]; };
-  // (not for 64-query x 64-channel workgroups: their accumulators leave no room for a second operand set in 512 VGPRs)
-  constexpr bool PF = !(DH == 64 && NQ == 2);
-  static_assert(2 * KS == DH, "one V row pair per k-step");
-  if (PF && wave < n_kt) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) fetch_ks(wave * 64, ks);
-    fetch_mask(wave * 64);
-  }
-  for (int kt = wave; kt < n_kt; kt += NWV) {
-    const int k0 = kt * 64;
-    const bool more = kt + NWV < n_kt;         // wave-uniform
-    // ---- stage this tile of V (coalesced rows) for the second product
-    if constexpr (PF) {
-#pragma unroll
-      for (int d = 0; d < DH; ++d) vt[d * VLD + lane] = vreg[d];
-    } else {
-      fetch_mask(k0);
-#pragma unroll 8
-      for (int d = 0; d < DH; ++d)
-        vt[d * VLD + lane] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vres, 4 * min(k0 + lane, a.Tk - 1), 4 * d * a.ldv, 0));
-    }
-    // keys this tile must ignore (tile overhang + key padding), as a wave-uniform bit set
-    const unsigned long long badm = __ballot((k0 + lane >= a.Tk) || (has_mask && mreg != 0));
-    // ---- S^T = K^T Q
-    f32x16 s[2][NQ];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int nb = 0; nb < NQ; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[rb][nb][r] = 0.f;
-    auto scores = [&](auto prefetch) __attribute__((always_inline)) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        float ak[2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-          ak[rb] = PF ? kreg[ks][rb]
-                      : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kres, 4 * (half * a.ldk + min(k0 + rb * 32 + n, a.Tk - 1)), 8 * ks * a.ldk, 0));
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int nb = 0; nb < NQ; ++nb) s[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[rb], qreg[ks][nb], s[rb][nb], 0, 0, 0);
-        if constexpr (decltype(prefetch)::value) fetch_ks(k0 + 64 * NWV, ks);
-      }
-    };
-    if (PF && more) { scores(std::true_type{}); fetch_mask(k0 + 64 * NWV); }
-    else scores(std::false_type{});
-    // ---- key mask, online softmax over the key axis
-    float mx[NQ];
-#pragma unroll
-    for (int nb = 0; nb < NQ; ++nb) mx[nb] = NEG;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = rb * 32 + acc_row(r, 0);          // this element's key bit in the low lane half; + 4 in the high half
-        const unsigned long long lanes = (((badm >> c) & 1) ? 0x00000000FFFFFFFFull : 0ull) | (((badm >> (c + 4)) & 1) ? 0xFFFFFFFF00000000ull : 0ull);
-        const bool bad = __builtin_amdgcn_inverse_ballot_w64(lanes);
-#pragma unroll
-        for (int nb = 0; nb < NQ; ++nb) {
-          const float v = bad ? NEG : s[rb][nb][r];
-          s[rb][nb][r] = v;
-          mx[nb] = fmaxf(mx[nb], v);
-        }
-      }
-#pragma unroll
-    for (int nb = 0; nb < NQ; ++nb) {
-      mx[nb] = fmaxf(mx[nb], __shfl_xor(mx[nb], 32));
-      const float m_new = fmaxf(m[nb], mx[nb]);
-      const float m_use = m_new == NEG ? 0.f : m_new;      // every key so far masked: keep exp() finite, all weights 0
-      const float alpha = expf(m[nb] - m_use);
-      float sum = 0.f;
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __expf(s[rb][nb][r] - m_use);
-          s[rb][nb][r] = p;
-          sum += p;
-        }
-      sum += __shfl_xor(sum, 32);
-      l[nb] = l[nb] * alpha + sum;
-      m[nb] = m_new;
-#pragma unroll
-      for (int x = 0; x < RBD; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[x][nb][r] *= alpha;
-    }
-    // ---- O^T += V P^T : the k-pair of step (rb, r) is the key pair the two lane halves hold in s[rb][.][r]
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = rb * 32 + acc_row(r, half);
-#pragma unroll
-        for (int x = 0; x < RBD; ++x) {
-          const int d = x * 32 + n;
-          const float av = d < DH ? vt[d * VLD + kl] : 0.f;
-#pragma unroll
-          for (int nb = 0; nb < NQ; ++nb) o[x][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[rb][nb][r], o[x][nb], 0, 0, 0);
-        }
-      }
-  }
-
-  // ---- merge the NWV waves' (m, l, O) through LDS; wave w finishes accumulator rows r = RPW w .. RPW w + RPW - 1 of every block (RPW = 16 / NWV)
-  __syncthreads();
-  float* ob = lds;                                   // [wave][blk][r][lane]
-  float* ml = lds + NWV * NBLK * 16 * 64;            // [wave][{m,l}][nb][lane]
-#pragma unroll
-  for (int x = 0; x < RBD; ++x)
-#pragma unroll
-    for (int nb = 0; nb < NQ; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ob[((wave * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] = o[x][nb][r];
-#pragma unroll
-  for (int nb = 0; nb < NQ; ++nb) {
-    ml[((wave * 2 + 0) * NQ + nb) * 64 + lane] = m[nb];
-    ml[((wave * 2 + 1) * NQ + nb) * 64 + lane] = l[nb];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int nb = 0; nb < NQ; ++nb) {
-    float mw[NWV], M = NEG, L = 0.f, wg[NWV];
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) { mw[w] = ml[((w * 2 + 0) * NQ + nb) * 64 + lane]; M = fmaxf(M, mw[w]); }
-    const float M_use = M == NEG ? 0.f : M;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) { wg[w] = expf(mw[w] - M_use); L += ml[((w * 2 + 1) * NQ + nb) * 64 + lane] * wg[w]; }
-    const int q = q0 + nb * 32 + n;
-    if (q >= a.Tq) continue;
-#pragma unroll
-    for (int x = 0; x < RBD; ++x)
-#pragma unroll
-      for (int rr = 0; rr < 16 / NWV; ++rr) {
-        const int r = wave * (16 / NWV) + rr;
-        const int d = x * 32 + acc_row(r, half);
-        if (d >= DH) continue;
-        float acc = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) acc += ob[((w * NBLK + x * NQ + nb) * 16 + r) * 64 + lane] * wg[w];
-        a.O[b * a.o_bs + (long)(h * DH + d) * a.ldo + q] = acc / L;
-      }
-  }
-}
-
-
 // key splits of the query-split kernel: enough workgroups for ~7/8 of the 256 CUs, never finer than one 32-key unit (host and device: an item of
 // an exact-ragged row picks its own split from its own length)
 __host__ __device__ inline int attn_ksplit_of(int B, int Tq, int Tk, int forced) {
@@ -381,7 +173,7 @@ __host__ __device__ inline int attn_ksplit_of(int B, int Tq, int Tk, int forced)
 }
 
 // ------------------------------------------------------------------------------------------------ attention, query-split (round 5)
-// Round 4's k_attn gives a workgroup 32 queries and lets its four waves split the KEY tiles: every wave streams its own K / V tiles from
+// Round 4's kernel (k_attn, removed; git history / profiles/r05_attention_ubench_*.txt hold its numbers) gave a workgroup 32 queries and let its four waves split the KEY tiles: every wave streams its own K / V tiles from
 // global memory into registers, a workgroup reads the head's whole K and V (441 KB at T = 861) for 7 MFLOP, and the launch sits on the
 // global_load -> VGPR path (16 of the 18 B/clk/CU it delivers): 29 us, 33 % of the fp32 MFMA roof.  Here the four waves of a workgroup own
 // 32 QUERIES each and share every K / V tile through LDS (one cooperative 16-byte-per-lane fetch per tile, double-buffered, one barrier per
@@ -677,11 +469,6 @@ inline size_t attn_ml_floats(int B, int T, int n_items = 0, int max_len = 0) {
   if (n_items) return (size_t)8 * n_items * kHeads * 2 * round_up(max_len, 128);
   return (size_t)attn_ksplit(B, T, T) * B * kHeads * 2 * round_up(T, 128);
 }
-inline bool attn_use_qs() {   // FDX_ATTN=old: round 4's key-split kernel (A/B)
-  static const bool v = [] { const char* e = getenv("FDX_ATTN"); return !(e && e[0] == 'o'); }();
-  return v;
-}
-
 struct AttnItems { const int4* dev = nullptr; const std::vector<int>* host = nullptr; int max_len = 0; };   // exact-ragged row layout (fdx_ctx::items)
 
 hipError_t launch_attn_qs(int DH, AttnArgs a, int B, hipStream_t s, ProfEvents* prof, const AttnItems& items = AttnItems{}) {
@@ -738,30 +525,8 @@ hipError_t launch_attn_qs(int DH, AttnArgs a, int B, hipStream_t s, ProfEvents* 
   return hipGetLastError();
 }
 
-template <int NQ>
-hipError_t launch_attn_nq(int DH, const AttnArgs& a, int B, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-  const dim3 grid((a.Tq + 32 * NQ - 1) / (32 * NQ), kHeads, B), blk(256);
-#define FDX_ATTN(DH_)                                                                                   \
-  if (ev0) hipExtLaunchKernelGGL((k_attn<DH_, NQ>), grid, blk, 0, s, ev0, ev1, 0, a);                    \
-  else hipLaunchKernelGGL((k_attn<DH_, NQ>), grid, blk, 0, s, a);
-  if (DH == 64) { FDX_ATTN(64) }
-  else if (DH == 32) { FDX_ATTN(32) }
-  else { FDX_ATTN(16) }
-#undef FDX_ATTN
-  return hipGetLastError();
-}
 hipError_t launch_attn(int DH, const AttnArgs& a, int B, hipStream_t s, ProfEvents* prof = nullptr, const AttnItems& items = AttnItems{}) {
-  if (attn_use_qs() || items.dev) return launch_attn_qs(DH, a, B, s, prof, items);
-  // 64-query workgroups only when they already give every CU one (B * heads * T/64 >= 256); else 32-query ones
-  const bool nq2 = (long)B * kHeads * ((a.Tq + 63) / 64) >= 256;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: QK^T and PV of one attention launch = 2 * 2 * Tq * Tk * D flops per item
-  if (prof) {
-    prof->note(PROF_TD_ATTN, "k_attn<%d, %d> (v_mfma_f32_32x32x2_f32 fp32 flash attention, %d-query workgroups; %ld workgroups)", DH, nq2 ? 2 : 1,
-               nq2 ? 64 : 32, (long)B * kHeads * ((a.Tq + (nq2 ? 63 : 31)) / (nq2 ? 64 : 32)));
-    prof->take(PROF_TD_ATTN, 4.0 * (double)a.Tq * a.Tk * (double)(DH * kHeads) * B, ev0, ev1);
-  }
-  if (nq2) return launch_attn_nq<2>(DH, a, B, s, ev0, ev1);
-  return launch_attn_nq<1>(DH, a, B, s, ev0, ev1);
+  return launch_attn_qs(DH, a, B, s, prof, items);
 }
 
 // Scratch of one decoder layer (owned by the caller; padded rows [B][ch][ld], pointers past the left halo)

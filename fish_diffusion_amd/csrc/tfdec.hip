@@ -9,7 +9,8 @@
 //   online softmax over the key axis = over accumulator registers of one lane (+ one cross-half exchange): no row shuffles
 //   O^T[d][query]  += V P^T    (A = the V tile staged through LDS, B = the S^T accumulators used in place: the MFMA k-pair
 //                               of step r is exactly the key pair (acc_row(r, 0), acc_row(r, 1)) the two lane halves hold)
-// One workgroup = 64 queries x 1 head; its 4 waves split the key tiles and merge their (max, sum, O) triples through LDS.
+// One workgroup = 128 queries x 1 head (32 per wave), its 4 waves sharing every K / V tile through LDS; the KEY range is split over up to 8
+// workgroups whose (max, sum, O) triples a small combine kernel folds in a fixed order (declayer.hip.h, k_attn_qs / k_attn_combine).
 // Hoisted per utterance batch (fdx_tfdec_prepare): C0 = condition_projection(conditioner) + positional embedding, and every layer's
 // cross-attention keys / values of C0.  The reference's memory is mask(C0 + step 1^T) (convnext.py:353,359-360), step = the diffusion-step
 // MLP's output, constant over frames, and the projections are linear:
