@@ -118,9 +118,12 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
             return f"features must be a non-empty [T, E] tensor, got {tuple(f.shape) if torch.is_tensor(f) else type(f).__name__}"
         if not torch.is_tensor(p) or p.dim() != 1 or p.shape[0] != f.shape[0]:
             return f"f0 must be [T = {f.shape[0]}], got {tuple(p.shape) if torch.is_tensor(p) else type(p).__name__}"
-        if f.shape[1] != features[mine[0]].shape[1] and torch.is_tensor(features[mine[0]]) and features[mine[0]].dim() == 2:
-            return f"feature width {f.shape[1]} differs from the batch's {features[mine[0]].shape[1]}"
+        if width is not None and f.shape[1] != width:
+            return f"feature width {f.shape[1]} differs from the job's {width}"
         return None
+
+    # the job's feature width: the first well-formed utterance's (a malformed first entry must not decide it, or take the check down)
+    width = next((int(features[i].shape[1]) for i in mine if torch.is_tensor(features[i]) and features[i].dim() == 2 and features[i].shape[0] > 0), None)
 
     if on_error == "isolate":
         ok = []
