@@ -88,7 +88,7 @@ enum { PROF_WN_CONVGATE = 0,    // WaveNet: dilated conv k=3 + gate (convgemm16s
        PROF_NSF_RESBLOCK = 2,   // NSF-HiFiGAN: the ResBlock convs on convgemm_kernel<2,false,PRE_LRELU,EpiResblock> (C >= 64 stages)
        PROF_RG_RESBLOCK = 3,    // RefineGAN: the same instantiation inside its ResBlocks (down path + ParallelResBlocks)
        PROF_CN_PWCONV1 = 4,     // ConvNext: pwconv1 (LayerNorm folded in, GELU epilogue)
-       PROF_TD_ATTN = 5,        // TransformerDecoder: k_attn (fp32 flash attention, self + cross)
+       PROF_TD_ATTN = 5,        // TransformerDecoder: k_attn_qs (fp32 flash attention, self + cross; the combine kernel is not in the interval)
        PROF_KINDS = 6 };
 struct ProfEvents {
   bool on = false;

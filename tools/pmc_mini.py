@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""A SHORT run of one bench geometry for the rocprofv3 PMC passes that die on the full bench command (round 5: `--pmc FETCH_SIZE|WRITE_SIZE`
+over `bench.py --config tfdec|sharded` segfaults inside rocprofv3; round 4: hung on 8 k incomplete dispatches).  Same kernels, same shapes, a
+few hundred dispatches instead of 45 k: a 4-step UniPC run, eager (no hipGraph), so per-launch traffic of every kernel is what the passes see.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <dir> -o pmc -- python tools/pmc_mini.py tfdec      (and WRITE_SIZE in a second pass)
+    python tools/pmc_traffic.py <fetch_db> <write_db> tfdec > profiles/r05_tfdec_pmc_traffic.json
+
+  tfdec    TransformerDecoderDenoiser (dim 512 x 12 layers), batch 1 x 861 frames               = bench.py --config tfdec
+  sharded  WaveNet (C = 512 x 20 layers), one exact-ragged micro-batch of 8 utterances, longest 861 frames  = a micro-batch of --config sharded
+"""
+import os
+import sys
+
+os.environ["FDX_NO_GRAPH"] = "1"
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fish_diffusion_amd import GaussianDiffusion  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "tfdec"
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(4)
+if cfg == "tfdec":
+    from oracle import tfdec_ref  # (seeded weights only)
+    c = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=12)
+    diff = GaussianDiffusion(dict(type="TransformerDecoderDenoiser", **c), spec_min=[-5], spec_max=[0])
+    diff.denoise_fn.load_state_dict(tfdec_ref.seeded_state(1, **c))
+    diff = diff.to(dev).eval()
+    feats = torch.randn(1, 861, 256, generator=g).to(dev)
+    run = lambda: diff(feats, sampler_interval=250)   # noqa: E731
+elif cfg == "sharded":
+    from oracle import wavenet_ref
+    c = dict(mel_channels=128, d_encoder=256, residual_channels=512, residual_layers=20, dilation_cycle=4, use_linear_bias=True)
+    diff = GaussianDiffusion(dict(type="WaveNetDenoiser", **c), spec_min=[-5], spec_max=[0])
+    diff.denoise_fn.load_state_dict(wavenet_ref.seeded_wavenet_state(1234, **{k: v for k, v in c.items() if k != "dilation_cycle"}))
+    diff = diff.to(dev).eval()
+    lens = [861, 850, 840, 830, 820, 810, 800, 790]        # the longest eight of the bench's 64 lengths look like this
+    feats = torch.randn(len(lens), 861, 256, generator=g).to(dev)
+    run = lambda: diff(feats, sampler_interval=250, lengths=lens)   # noqa: E731
+else:
+    raise SystemExit(f"unknown config {cfg}")
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+print("done", cfg)
