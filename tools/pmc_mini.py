@@ -36,8 +36,11 @@ elif cfg == "sharded":
     diff = GaussianDiffusion(dict(type="WaveNetDenoiser", **c), spec_min=[-5], spec_max=[0])
     diff.denoise_fn.load_state_dict(wavenet_ref.seeded_wavenet_state(1234, **{k: v for k, v in c.items() if k != "dilation_cycle"}))
     diff = diff.to(dev).eval()
-    lens = [861, 850, 840, 830, 820, 810, 800, 790]        # the longest eight of the bench's 64 lengths look like this
-    feats = torch.randn(len(lens), 861, 256, generator=g).to(dev)
+    # exactly rank 0's share of `bench.py --config sharded` (64 seeded lengths dealt longest-first over 8 ranks: ONE exact-ragged micro-batch of 8)
+    from fish_diffusion_amd import dist as fdist
+    all_lens = torch.randint(516, 862, (64,), generator=torch.Generator().manual_seed(4)).tolist()
+    lens = [all_lens[i] for i in fdist.shard_utterances(all_lens, 0, 8)]
+    feats = torch.randn(len(lens), max(lens), 256, generator=g).to(dev)
     run = lambda: diff(feats, sampler_interval=250, lengths=lens)   # noqa: E731
 else:
     raise SystemExit(f"unknown config {cfg}")
