@@ -319,11 +319,13 @@ def roofline_entry(kernel_desc, n, avg_ms, flops, peak, sampling, traffic=None, 
             "peak_note": "nominal fp32 matrix peak at the 2.4 GHz boost clock.  tools/ubench/mfmaclk.hip on this part (profiles/r04_mfma_clock_ubench.txt): an "
                          "MFMA-only v_mfma_f32_16x16x4_f32 loop on 256 CUs sustains 155.1 TFLOP/s at 2.39 GHz, as one long launch and as a chain of 12 / 25 us "
                          "launches alike; with the residual-block K loop's load mix (6 dwordx4 per 16 MFMAs from L2) 116.5 at the SAME 2.39 GHz: operand delivery "
-                         "bounds the K loop.  The library's own kernels, same counters (s_memtime / s_memrealtime per wave, instrumented build, "
-                         "profiles/r04_ktrace_headline_fp32.txt), read 2.13 (conv + gate) / 2.19 GHz (out-projection) while sclk reports 2.38: the two "
-                         "instruments disagree for the real kernels and the cause is open (profiles/NOTES.md round 4 item 2) -- `peak` stays the nominal 157.3",
+                         "bounds the K loop.  The library's own kernels, same counters (s_memtime / s_memrealtime per wave, instrumented build, last two stamps "
+                         "taken back to back: profiles/r05_ktrace_headline_fp32_adjacent_stamps.txt), read 2.10 (conv + gate) / 2.18 GHz (out-projection) while sclk "
+                         "reports 2.38-2.40 at ~1100 W of board power (`clock_mhz`).  Round 5 ruled out wait states (a wave that only sleeps reads 2.397 GHz), barriers, "
+                         "LDS reductions, exp phases, cold-load waits, combined L2 + LDS + MFMA load (all 2.38-2.39, profiles/r05_clock_*_ubench.txt) and the stamps "
+                         "themselves; no cause is named (profiles/NOTES.md round 5 item 4) -- `peak` stays the nominal 157.3",
             "launches_timed": n, "sampling": sampling, "avg_launch_us": round(avg_ms * 1e3, 2),
-            "timing": "hipExtLaunchKernel start/stop events on the launch stream, timed region", "flops_per_launch": flops}
+            "timing": "hipExtLaunchKernel start/stop events on the launch stream", "flops_per_launch": flops}
 
 
 class SclkSampler:
