@@ -173,9 +173,10 @@ __host__ __device__ inline int attn_ksplit_of(int B, int Tq, int Tk, int forced)
 }
 
 // ------------------------------------------------------------------------------------------------ attention, query-split (round 5)
-// Round 4's kernel (k_attn, removed; git history / profiles/r05_attention_ubench_*.txt hold its numbers) gave a workgroup 32 queries and let its four waves split the KEY tiles: every wave streams its own K / V tiles from
-// global memory into registers, a workgroup reads the head's whole K and V (441 KB at T = 861) for 7 MFLOP, and the launch sits on the
-// global_load -> VGPR path (16 of the 18 B/clk/CU it delivers): 29 us, 33 % of the fp32 MFMA roof.  Here the four waves of a workgroup own
+// Round 4's kernel (k_attn, removed; git history and profiles/r05_attention_ubench_*.txt hold its numbers) gave a workgroup 32 queries and let
+// its four waves split the KEY tiles: every wave streamed its own K / V tiles from global memory into registers, a workgroup read the head's whole
+// K and V (441 KB at T = 861) for 7 MFLOP, and the launch sat on the global_load -> VGPR path (16 of the 18 B/clk/CU it delivers): 29 us, 33 % of
+// the fp32 MFMA roof (187 us at batch 8).  Measured here: 22.4 us + 5.4 us of combine at batch 1, 125 us at batch 8.  The four waves of a workgroup own
 // 32 QUERIES each and share every K / V tile through LDS (one cooperative 16-byte-per-lane fetch per tile, double-buffered, one barrier per
 // tile), so a tile is fetched once per 128 queries instead of once per 32; the chip is filled by splitting the KEY range over `ksplit`
 // workgroups (flash-decoding): each leaves (max, sum, un-normalised O^T) and k_attn_combine folds them in a fixed order.  Operand bytes per
