@@ -133,6 +133,20 @@ struct ProfEvents {
 
 }  // namespace fdx
 
+namespace fdx {
+constexpr int kHeads = 8;   // nn.TransformerDecoderLayer(nhead=8), convnext.py:300 (declayer.hip.h)
+// key splits of the query-split attention kernel (declayer.hip.h): enough workgroups for ~7/8 of the 256 CUs, never finer than one 32-key unit.
+// Host and device: an item of an exact-ragged row picks its own split from its own length; the sampler-graph key needs the largest one.
+__host__ __device__ inline int attn_ksplit_of(int B, int Tq, int Tk, int forced) {
+  const int units = (Tk + 31) / 32;
+  const long base = (long)B * kHeads * ((Tq + 127) / 128);
+  int ks = forced > 0 ? forced : (int)((224 + base - 1) / base);
+  ks = ks < 8 ? ks : 8;
+  ks = ks < units ? ks : units;
+  return ks > 1 ? ks : 1;
+}
+}  // namespace fdx
+
 struct fdx_ctx {
   int device = 0;
   std::string err;

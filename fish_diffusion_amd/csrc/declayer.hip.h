@@ -15,7 +15,6 @@
 namespace fdx {
 namespace {
 
-constexpr int kHeads = 8;   // nn.TransformerDecoderLayer(nhead=8), convnext.py:300
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TdLayer {
@@ -160,17 +159,6 @@ struct AttnArgs {
 #define FDX_ATTN_FINE(k) do { } while (0)
 #define FDX_ATTN_COARSE(k) FDX_ATTN_STAMP(k)
 #endif
-
-// key splits of the query-split kernel: enough workgroups for ~7/8 of the 256 CUs, never finer than one 32-key unit (host and device: an item of
-// an exact-ragged row picks its own split from its own length)
-__host__ __device__ inline int attn_ksplit_of(int B, int Tq, int Tk, int forced) {
-  const int units = (Tk + 31) / 32;
-  const long base = (long)B * kHeads * ((Tq + 127) / 128);
-  int ks = forced > 0 ? forced : (int)((224 + base - 1) / base);
-  ks = ks < 8 ? ks : 8;
-  ks = ks < units ? ks : units;
-  return ks > 1 ? ks : 1;
-}
 
 // ------------------------------------------------------------------------------------------------ attention, query-split (round 5)
 // Round 4's kernel (k_attn, removed; git history and profiles/r05_attention_ubench_*.txt hold its numbers) gave a workgroup 32 queries and let

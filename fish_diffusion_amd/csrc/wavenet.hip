@@ -1234,7 +1234,13 @@ extern "C" int fdx_sampler_set_items(fdx_handle h, const int* offsets, const int
     h->items_max_len = std::max(h->items_max_len, lens[i]);
   }
   h->items_T = T;
-  h->items_hash = fnv1a(h->items.data(), h->items.size() * sizeof(int), 0x9e3779b97f4a7c15ull) ^ (uint64_t)T;
+  // what a recorded sampler graph depends on: the launches' grids (number of items, query blocks of the longest, finest key split) -- NOT where
+  // the items lie or how long each is: the kernels read offsets / lengths from the device table, rewritten above before any replay.  (Keyed by
+  // the full layout, every micro-batch of a serving stream would have re-captured its 15 k-node graph.)
+  int ks_max = 1;
+  for (int i = 0; i < n_items; ++i) ks_max = std::max(ks_max, attn_ksplit_of(1, lens[i], lens[i], 0));
+  const int key_parts[4] = {n_items, (h->items_max_len + 63) / 64, ks_max, T};   // (64-query blocks: the combine kernel's grid; the attention's 128-query blocks follow)
+  h->items_hash = fnv1a(key_parts, sizeof key_parts, 0x9e3779b97f4a7c15ull);
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
   FDX_HIP(h, h->items_dev.ensure(packed.size() * sizeof(int), false, s));

@@ -181,3 +181,38 @@ def test_pipeline_exact_default_covers_the_three_denoisers(dev):
             alone = diff(feats[i][None], sampler_interval=200, x_init=x0[i][None])
             assert torch.equal(mel, alone[0]), (kind, i)
             assert wav.shape == (lens[i] * 512,) and torch.isfinite(wav).all()
+
+
+def test_ragged_layouts_of_one_shape_share_a_recorded_sampler_graph(dev):
+    """The recorded sampler graph of an exact-ragged row depends on the launches' grids (number of items, query blocks of the longest item, finest
+    key split, row length), not on where the items lie: the attention kernels read offsets and lengths from a device table that
+    `fdx_sampler_set_items` rewrites before every run.  Two different layouts of one shape: the second run must REPLAY the first's graph (no new
+    capture -- a serving stream would otherwise re-record a 15 k-node graph per micro-batch) and still give every item its batch-1 result bit for bit."""
+    import ctypes as C
+    from fish_diffusion_amd import _lib
+    from tests.helpers import TD_SMALL, tfdec_sd
+    diff = _diffusion_of("TransformerDecoderDenoiser", TD_SMALL, tfdec_sd(TD_SMALL, 35), dev)
+    g = torch.Generator().manual_seed(79)
+    T = 192
+
+    def captures():
+        c, n, k = C.c_long(), C.c_long(), C.c_int()
+        eng = diff.denoise_fn.engine(dev)
+        _lib.check(_lib.lib().fdx_graph_stats(eng.h, C.byref(c), C.byref(n), C.byref(k)), eng.h)
+        return c.value
+
+    seen = None
+    for lens in ([130, 64, 65, 1], [129, 70, 60, 3]):
+        feats = torch.randn(len(lens), T, 256, generator=g).to(dev)
+        x0 = torch.randn(len(lens), 128, T, generator=g).to(dev)
+        alone = [diff(feats[b:b + 1, :n].contiguous(), sampler_interval=100, x_init=x0[b:b + 1, :, :n].contiguous()) for b, n in enumerate(lens)]
+        before = captures()
+        got = diff(feats, sampler_interval=100, x_init=x0, lengths=lens)
+        new = captures() - before
+        if seen is None:
+            assert new == 1                     # the first layout records the row's graph
+        else:
+            assert new == 0, "a second layout of the same shape re-captured the sampler graph"
+        seen = lens
+        for b, n in enumerate(lens):
+            assert torch.equal(got[b, :n], alone[b][0]), (lens, b)

@@ -89,7 +89,7 @@ def test_load_checkpoint_schedule_buffers_warn_and_full_unpickler_fallback(lib_b
 
 # ------------------------------------------------------------------------------------------------ query-split attention: host-checkable logic
 def _ksplit_of(B, Tq, Tk, forced=0, heads=8):
-    """`attn_ksplit_of` (csrc/declayer.hip.h), restated: the formula is read against the source below."""
+    """`attn_ksplit_of` (csrc/common.hip.h), restated: the formula is read against the source below."""
     units = (Tk + 31) // 32
     base = B * heads * ((Tq + 127) // 128)
     ks = forced if forced > 0 else (224 + base - 1) // base
@@ -104,7 +104,8 @@ def test_attention_key_split_partition_and_combine_are_exact():
     used (the kernel's lazy maximum is any value within 2^8 of the true one); (c) the staged K tile's LDS order [ks][rb][half][n] is a
     bijection onto (channel, key) that hands lane (half, n) of k-step ks the MFMA A fragment K[2 ks + half][rb 32 + n]."""
     import os
-    src = open(os.path.join(os.path.dirname(__file__), "..", "fish_diffusion_amd", "csrc", "declayer.hip.h")).read()
+    csrc = os.path.join(os.path.dirname(__file__), "..", "fish_diffusion_amd", "csrc")
+    src = open(os.path.join(csrc, "declayer.hip.h")).read() + open(os.path.join(csrc, "common.hip.h")).read()
     assert "int ks = forced > 0 ? forced : (int)((224 + base - 1) / base);" in src and "const long base = (long)B * kHeads * ((Tq + 127) / 128);" in src
     assert "const int u0 = (int)((long)units * split / ksplit), u1 = (int)((long)units * (split + 1) / ksplit);" in src
     assert "(d >> 1) * 128 + (c >> 5) * 64 + (d & 1) * 32 + (c & 31)" in src
