@@ -195,6 +195,7 @@ struct fdx_ctx {
   const float* ragged_keep = nullptr;   // non-null only while such a run is being enqueued / recorded
   // item layout of an exact-ragged row (fdx_sampler_set_items): what the attention-based denoisers need beside the hole mask
   std::vector<int> items;               // host: {offset, length} per item; empty = dense batches
+  std::vector<int> items_packed;        // host image of items_dev (kept alive: the upload is asynchronous)
   fdx::DevBuf items_dev;                // int4 per item {offset, length, 0, 0}
   fdx::DevBuf pidx_dev;                 // int per column of the row: position inside its item (0 in holes)
   uint64_t items_hash = 0;              // part of the sampler-graph key (grids depend on the layout)

@@ -1223,7 +1223,8 @@ extern "C" int fdx_sampler_set_items(fdx_handle h, const int* offsets, const int
   h->items_hash = 0; h->items_max_len = 0; h->items_T = 0;
   if (n_items == 0) return FDX_OK;
   int end = 0;
-  std::vector<int> packed((size_t)n_items * 4, 0);
+  std::vector<int>& packed = h->items_packed;
+  packed.assign((size_t)n_items * 4, 0);
   for (int i = 0; i < n_items; ++i) {
     if (offsets[i] % 32 || offsets[i] < end || lens[i] <= 0 || offsets[i] + lens[i] > T)
       return fail(h, FDX_E_ARG, "fdx_sampler_set_items: item %d = [%d, %d) must start at a multiple of 32, follow item %d and end inside the row of %d frames",
@@ -1245,8 +1246,7 @@ extern "C" int fdx_sampler_set_items(fdx_handle h, const int* offsets, const int
   FDX_HIP(h, hipSetDevice(h->device));
   FDX_HIP(h, h->items_dev.ensure(packed.size() * sizeof(int), false, s));
   FDX_HIP(h, h->pidx_dev.ensure((size_t)T * sizeof(int), false, s));
-  FDX_HIP(h, hipMemcpyAsync(h->items_dev.p, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice, s));
-  FDX_HIP(h, hipStreamSynchronize(s));     // `packed` is a local
+  FDX_HIP(h, hipMemcpyAsync(h->items_dev.p, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice, s));   // (source owned by the handle)
   hipLaunchKernelGGL(k_items_pidx, dim3((T + 255) / 256), dim3(256), 0, s, static_cast<int*>(h->pidx_dev.p), static_cast<const int4*>(h->items_dev.p), n_items, T);
   FDX_HIP(h, hipGetLastError());
   return FDX_OK;
