@@ -48,6 +48,39 @@ def build_trace(verbose: bool = True) -> str:
     return out
 
 
+def asan_runtime() -> str:
+    """The AddressSanitizer runtime of hipcc's clang (to LD_PRELOAD into an uninstrumented python)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    return subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], check=True, capture_output=True, text=True).stdout.strip()
+
+
+def build_asan(out_dir: str, verbose: bool = False) -> str:
+    """Sanitizer build of the C ABI's HOST side (sanitizers): every translation unit with `-Xarch_host -fsanitize=address,undefined`
+    (the device code is compiled as usual and never runs in the CPU tests), linked into <out_dir>/libfishdx_asan.so.  tests/test_sanitizers.py
+    runs the host-side entry points (packing of every model family, filterbank, frame counts, descriptors' validation) through it."""
+    os.makedirs(out_dir, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function",
+             "-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer",
+             "-mllvm", "-amdgpu-kernarg-preload-count=14"]
+
+    def compile_one(name):
+        obj = os.path.join(out_dir, name[:-4] + ".o")
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, name), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    lib = os.path.join(out_dir, "libfishdx_asan.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-fsanitize=address,undefined", "-shared", "-fPIC", "-o", lib, *objs], check=True, cwd=CSRC)
+    return lib
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
