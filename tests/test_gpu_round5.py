@@ -216,3 +216,29 @@ def test_ragged_layouts_of_one_shape_share_a_recorded_sampler_graph(dev):
         seen = lens
         for b, n in enumerate(lens):
             assert torch.equal(got[b, :n], alone[b][0]), (lens, b)
+
+
+def test_transformer_denoiser_at_the_30_s_slice_limit_vs_oracle(dev):
+    """The caller slices audio into <= 30 s chunks (utils/audio.py:112-167): T = 2583 frames at hop 512.  The query-split attention then walks 21
+    query blocks and 41 key tiles per head with a 2-way key split (and an unsplit launch at batch 2): one forward of a small transformer denoiser
+    (heads of 16 and of 32 channels) against the pinned oracle, plain and with a padded tail."""
+    from fish_diffusion_amd import DENOISERS
+    from oracle import tfdec_ref
+    T = 2583
+    g = torch.Generator().manual_seed(80)
+    for dim, B in ((128, 1), (256, 2)):
+        cfg = dict(mel_channels=128, dim=dim, mlp_factor=2, condition_dim=256, num_layers=2)
+        sd = tfdec_ref.seeded_state(36 + dim, **cfg)
+        net = DENOISERS.build(dict(type="TransformerDecoderDenoiser", **cfg))
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        x, c, t = torch.randn(B, 128, T, generator=g), torch.randn(B, 256, T, generator=g), torch.rand(B, generator=g) * 999
+        m = torch.zeros(B, T, dtype=torch.bool)
+        m[-1, T - 417:] = True
+        with torch.no_grad():
+            ref = tfdec_ref.tfdec_forward(sd, x, t, c, None, None, num_layers=2)
+            ref_m = tfdec_ref.tfdec_forward(sd, x, t, c, m, m, num_layers=2)
+        got = net(x.to(dev), t.to(dev), c.to(dev)).cpu()
+        got_m = net(x.to(dev), t.to(dev), c.to(dev), x_masks=m.to(dev), cond_masks=m.to(dev)).cpu()
+        print(f"tfdec dim {dim} B {B} T {T}: rel err {rel_err(got, ref):.2e} / masked {rel_err(got_m, ref_m):.2e}")
+        assert rel_err(got, ref) < 2e-5 and rel_err(got_m, ref_m) < 2e-5, dim
