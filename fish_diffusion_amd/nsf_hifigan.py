@@ -95,6 +95,8 @@ class Generator(nn.Module):
         self._handle: Optional[_lib.Handle] = None
         self._arena = None
         self._sig = None
+        self._lanes: list = []       # [(Handle, torch.cuda.Stream)]: extra engines over the SAME packed arena, one stream each
+        self._lanes_arena = None
         self.rng = "torch"  # "torch": draw rand_ini / source noise with torch (reference RNG order); "philox": on device
 
     def remove_weight_norm(self):
@@ -159,20 +161,35 @@ class Generator(nn.Module):
         self._arena = arena
         self._sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def lanes(self, device: torch.device, n: int):
+        """`n` extra engines sharing this module's packed arena, each with a workspace and a HIP stream of its own: independent
+        utterances go through the generator side by side (a batch-1 pass leaves part of the chip idle in the small-grid stages;
+        every pass is still the batch-1 pass, so each waveform is bit-identical to a call alone).  A lane's engine is only ever
+        used on the lane's stream -- the workspace of a handle is ordered by its stream."""
+        primary = self.engine(torch.device(device))
+        if self._lanes_arena is not self._arena or (self._lanes and self._lanes[0][0].device != primary.device):
+            self._lanes, self._lanes_arena = [], self._arena
+        while len(self._lanes) < n:
+            hnd = _lib.Handle(primary.device)
+            _lib.check(_lib.lib().fdx_nsf_attach(hnd.h, C.byref(self._desc), _lib.ptr(self._arena), self._arena.numel()), hnd.h)
+            self._lanes.append((hnd, torch.cuda.Stream(device=primary.device)))
+        return self._lanes[:n]
+
     def packed_arena(self, device) -> torch.Tensor:
         self.engine(torch.device(device))
         return self._arena
 
     @torch.no_grad()
-    def forward(self, x, f0, rand_ini=None, src_noise=None, mel_scale: float = 1.0):
-        """x [B, num_mels, T] (natural-log mel), f0 [B, T] or [B, 1, T] -> wav [B, 1, T*hop] (models.py:407-438)."""
+    def forward(self, x, f0, rand_ini=None, src_noise=None, mel_scale: float = 1.0, engine: Optional[_lib.Handle] = None):
+        """x [B, num_mels, T] (natural-log mel), f0 [B, T] or [B, 1, T] -> wav [B, 1, T*hop] (models.py:407-438).
+        `engine`: one of `lanes()`'s handles (the caller is inside `torch.cuda.stream(lane_stream)`); default: the module's own."""
         _lib.require_gpu(x, "Generator input")
         if f0.dim() == 3:
             f0 = f0[:, 0]
         B, M, T = x.shape
         if M != self.h["num_mels"] or tuple(f0.shape) != (B, T):
             raise ValueError(f"mel {tuple(x.shape)} / f0 {tuple(f0.shape)} mismatch")
-        eng = self.engine(x.device)
+        eng = self.engine(x.device) if engine is None else engine
         L = T * self.h["hop_size"]
         mel = x.to(torch.float32).contiguous()
         f0c = f0.to(device=x.device, dtype=torch.float32).contiguous()

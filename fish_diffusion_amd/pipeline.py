@@ -17,13 +17,15 @@ this module does for a list of utterances per process:
     masked tail's activations instead of zero padding, exactly as in the reference, so they are not bit-identical to a
     one-by-one run;
   * the vocoder runs per utterance on the unpadded mel (the reference's Generator has no length masks: a padded batch
-    would leak the padding into the last few hundred samples), batch 1 is already efficient there;
+    would leak the padding into the last few hundred samples); the utterances of a micro-batch go through it on a few HIP
+    streams side by side (`vocoder_lanes`), each pass still the batch-1 pass, so every waveform is what a call alone gives;
   * results cut back to each utterance's own length.
 
 Host-side plumbing only -- all arithmetic is in libfishdx.so.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -81,7 +83,8 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
                sampler_interval: Optional[int] = None, noise_predictor: Optional[str] = None, rank: int = 0, world: int = 1,
                mel_scale: Optional[float] = None, x_init_fn: Optional[Callable] = None,
                source_noise_fn: Optional[Callable] = None, bucket: int = 64, exact: Optional[bool] = None,
-               on_error: str = "raise", failures: Optional[list] = None) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
+               on_error: str = "raise", failures: Optional[list] = None,
+               vocoder_lanes: Optional[int] = None) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
     """features[i]: [T_i, E] device tensors; f0s[i]: [T_i].  Returns [(index, mel [T_i, M], wav [T_i * hop])] for the
     utterances this rank owns.  `x_init_fn(idx_list, M, T)` / `source_noise_fn(idx_list, L)` let tests inject the random
     draws (initial x_T; (rand_ini, src_noise)) -- by default they are drawn on the device.  `bucket`: every micro-batch is padded
@@ -96,6 +99,9 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     reference's own padded-batch semantics with x_masks /
     cond_masks (the masked tail stays alive inside the receptive field: the last ~75 frames of every padded item differ slightly
     from a run alone).
+    `vocoder_lanes` (default 4, env FDX_VOC_LANES): the utterances of a micro-batch go through the generator on this many HIP streams side
+    by side (`Generator.lanes`): every pass is still the batch-1 pass on the unpadded mel -- bit-identical waveforms -- but the small-grid
+    stages of different utterances fill each other's idle CUs.  0 / 1: one after the other on the caller's stream.
     `on_error`: "raise" (default) lets the first exception out, as a plain loop would.  "isolate" is the reference's `safe_process`
     (tools/preprocessing/extract_features.py:175-217: one bad file is logged and the worker carries on): an utterance that fails validation
     is skipped; a micro-batch that raises is re-run one member at a time so that a bad member does not cost its batch-mates; whatever
@@ -145,6 +151,10 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
         den = getattr(diffusion, "denoise_fn", None)
         kind = getattr(den, "_KIND", "")
         exact = (kind == "wavenet" and getattr(den, "storage", "fp32") in ("fp32", "fp16x3")) or kind in ("convnext", "tfdec")
+    if vocoder_lanes is None:
+        vocoder_lanes = int(os.environ.get("FDX_VOC_LANES", "4"))
+    use_lanes = vocoder_lanes > 1 and hasattr(gen, "lanes")
+
     def run_group(idx: List[int]) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:
         T = max(lengths[i] for i in idx)
         if bucket and bucket > 1:
@@ -167,14 +177,27 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
             kw["x_masks"] = kw["cond_masks"] = masks
         mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
         res = []
-        for b, i in enumerate(idx):
-            n = lengths[i]
-            vkw = {}
-            if source_noise_fn is not None:
-                vkw["rand_ini"], vkw["src_noise"] = source_noise_fn([i], n * hop)
-            m_i = mel[b, :n]
-            wav = gen(m_i.T[None].contiguous(), f0[b:b + 1, :n].contiguous(), mel_scale=mel_scale, **vkw)[0, 0]   # [n*hop]
-            res.append((i, m_i, wav))
+        lanes = gen.lanes(dev, min(vocoder_lanes, B)) if use_lanes and B > 1 else []
+        cur = torch.cuda.current_stream(dev) if lanes else None
+        try:
+            for b, i in enumerate(idx):
+                n = lengths[i]
+                vkw = {}
+                if source_noise_fn is not None:
+                    vkw["rand_ini"], vkw["src_noise"] = source_noise_fn([i], n * hop)
+                m_i = mel[b, :n]
+                if lanes:
+                    eng, side = lanes[b % len(lanes)]
+                    side.wait_stream(cur)                      # the mel, f0 and any injected noise are the caller stream's work
+                    with torch.cuda.stream(side):
+                        wav = gen(m_i.T[None].contiguous(), f0[b:b + 1, :n].contiguous(), mel_scale=mel_scale, engine=eng, **vkw)[0, 0]
+                    wav.record_stream(cur)                     # allocated on the lane's stream, consumed on the caller's
+                else:
+                    wav = gen(m_i.T[None].contiguous(), f0[b:b + 1, :n].contiguous(), mel_scale=mel_scale, **vkw)[0, 0]   # [n*hop]
+                res.append((i, m_i, wav))
+        finally:
+            for _, side in lanes:                              # join: whatever the caller does next sees finished waveforms
+                cur.wait_stream(side)
         return res
 
     def guarded(idx: List[int]) -> List[Tuple[int, torch.Tensor, torch.Tensor]]:

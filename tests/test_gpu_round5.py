@@ -242,3 +242,42 @@ def test_transformer_denoiser_at_the_30_s_slice_limit_vs_oracle(dev):
         got_m = net(x.to(dev), t.to(dev), c.to(dev), x_masks=m.to(dev), cond_masks=m.to(dev)).cpu()
         print(f"tfdec dim {dim} B {B} T {T}: rel err {rel_err(got, ref):.2e} / masked {rel_err(got_m, ref_m):.2e}")
         assert rel_err(got, ref) < 2e-5 and rel_err(got_m, ref_m) < 2e-5, dim
+
+
+def test_vocoder_lanes_give_every_utterance_its_stand_alone_waveform(dev):
+    """`pipeline.synthesize(vocoder_lanes=4)`: the utterances of a micro-batch go through the generator on four HIP streams side by side, each
+    on an engine of its own over the shared packed arena.  Every pass is still the batch-1 pass: each waveform must be BIT-IDENTICAL to the
+    one-after-the-other run (`vocoder_lanes=0`) and to a direct `Generator` call on that utterance's mel alone -- on a second job too (the
+    lanes' workspaces are reused at other lengths, the streams re-joined)."""
+    from fish_diffusion_amd import NsfHifiGAN, pipeline
+    from oracle import nsf_hifigan_ref
+    from tests.helpers import WN_SMALL, synth_f0, wavenet_sd
+    h = dict(nsf_hifigan_ref.CONFIG_V1)
+    voc = NsfHifiGAN.from_state(h, nsf_hifigan_ref.seeded_generator_state(58, h)).to(dev)
+    diff = _diffusion_of("WaveNetDenoiser", WN_SMALL, wavenet_sd(WN_SMALL, 8), dev)
+    g = torch.Generator().manual_seed(15)
+    for lens in ([90, 41, 133, 64, 77, 120, 33], [57, 140, 96]):
+        feats = [torch.randn(n, 256, generator=g).to(dev) for n in lens]
+        f0s = [synth_f0(n).to(dev) for n in lens]
+        x0 = {i: torch.randn(128, n, generator=g).to(dev) for i, n in enumerate(lens)}
+        noise = {i: (torch.rand(1, 9, generator=g).to(dev), torch.randn(1, n * 512, 9, generator=g).to(dev)) for i, n in enumerate(lens)}
+
+        def x_init_fn(idx, M, T):
+            out = torch.zeros(len(idx), M, T, device=dev)
+            for b, i in enumerate(idx):
+                out[b, :, :lens[i]] = x0[i]
+            return out
+
+        def source_noise_fn(idx, L):
+            return noise[idx[0]]
+        kw = dict(max_batch=8, sampler_interval=250, x_init_fn=x_init_fn, source_noise_fn=source_noise_fn)
+        side = {i: (m, w) for i, m, w in pipeline.synthesize(diff, voc, feats, f0s, vocoder_lanes=4, **kw)}
+        torch.cuda.synchronize()
+        serial = {i: (m, w) for i, m, w in pipeline.synthesize(diff, voc, feats, f0s, vocoder_lanes=0, **kw)}
+        assert sorted(side) == sorted(serial) == list(range(len(lens)))
+        for i in side:
+            assert torch.equal(side[i][0], serial[i][0]), i
+            assert torch.equal(side[i][1], serial[i][1]), i
+            alone = voc.model(side[i][0].T[None].contiguous(), f0s[i][None], rand_ini=noise[i][0], src_noise=noise[i][1])[0, 0]
+            assert torch.equal(side[i][1], alone), i
+    assert len(voc.model._lanes) == 4
