@@ -195,7 +195,6 @@ struct fdx_ctx {
   const float* ragged_keep = nullptr;   // non-null only while such a run is being enqueued / recorded
   // item layout of an exact-ragged row (fdx_sampler_set_items): what the attention-based denoisers need beside the hole mask
   std::vector<int> items;               // host: {offset, length} per item; empty = dense batches
-  std::vector<int> items_packed;        // host image of items_dev (kept alive: the upload is asynchronous)
   fdx::DevBuf items_dev;                // int4 per item {offset, length, 0, 0}
   fdx::DevBuf pidx_dev;                 // int per column of the row: position inside its item (0 in holes)
   uint64_t items_hash = 0;              // part of the sampler-graph key (grids depend on the layout)
@@ -243,6 +242,7 @@ struct GenScope {   // first statement of every entry point that may (re)allocat
 
 void fdx_rg_free(void* p);   // refinegan.hip
 void fdx_cn_free(void* p);   // convnext.hip
+bool fdx_cn_has_attention(fdx_ctx* h);   // cross_attention > 0: an exact-ragged run needs the item layout
 // convnext.hip: the two hooks fdx_sampler_run needs (same contracts as wn_embed / wn_forward_core in wavenet.hip)
 int fdx_cn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s);
 int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,

@@ -248,6 +248,7 @@ static fdx_cn_state* cn(fdx_ctx* h) {
   return static_cast<fdx_cn_state*>(h->cn);
 }
 void fdx_cn_free(void* p) { delete static_cast<fdx_cn_state*>(p); }
+bool fdx_cn_has_attention(fdx_ctx* h) { return h->cn && static_cast<fdx_cn_state*>(h->cn)->ok && static_cast<fdx_cn_state*>(h->cn)->d.cross_attention > 0; }
 
 extern "C" int fdx_convnext_num_weights(const fdx_convnext_desc* d) {
   if (cn_validate(d)) return FDX_E_ARG;

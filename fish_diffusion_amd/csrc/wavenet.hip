@@ -1188,6 +1188,10 @@ extern "C" int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* tab, 
   if (h->den_kind != 0 && h->n_items() && (B != 1 || h->items_T != T))
     return fail(h, FDX_E_STATE, "fdx_sampler_run_ragged: the item layout (fdx_sampler_set_items) describes a row of %d frames, the prepared batch is %d x %d",
                 h->items_T, B, T);
+  // Attention does not stop at holes and positions count per item: without the layout the result would silently not be the per-item one
+  // fishdx.h promises.  (prepare cannot know a ragged run follows, so the check lives here.)
+  if ((h->den_kind == 2 || (h->den_kind == 1 && fdx_cn_has_attention(h))) && h->n_items() == 0)
+    return fail(h, FDX_E_STATE, "fdx_sampler_run_ragged: the prepared denoiser has attention layers: describe the row's items with fdx_sampler_set_items (before prepare) first");
   hipStream_t s = as_stream(st);
   FDX_HIP(h, hipSetDevice(h->device));
   FDX_HIP(h, h->keepbuf.ensure((size_t)B * ld * sizeof(float), true, s));
@@ -1195,11 +1199,17 @@ extern "C" int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* tab, 
   // the conv's input must read 0 wherever no frame exists: what earlier runs (other masks) left there is cleared
   if (h->den_kind == 0) FDX_HIP(h, hipMemsetAsync(h->Y.p, 0, (size_t)B * h->wd.residual_channels * ld * sizeof(float), s));
   // (ConvNext / transformer: every per-frame op is column-local and the depthwise conv masks its own input, convnext.hip k_dwconv_stats; the
-  // attention layers need the item layout -- their prepare refuses a ragged run without it)
+  // attention layers need the item layout -- refused above without it)
   h->ragged_keep = h->keepbuf.f() + kHalo;
   const int rc = fdx_sampler_run(h, kind, tab, n_rows, x, step_noise, seed, x_mask, st);
   h->ragged_keep = nullptr;
   return rc;
+}
+
+struct ItemChunk { static constexpr int kN = 32; int base, n; int v[2 * kN]; };
+static __global__ void k_items_fill(int4* __restrict__ items, ItemChunk c) {
+  const int i = threadIdx.x;
+  if (i < c.n) items[c.base + i] = make_int4(c.v[2 * i], c.v[2 * i + 1], 0, 0);
 }
 
 // pidx[t] = t - offset of the item frame t belongs to (0 in holes)
@@ -1222,18 +1232,20 @@ extern "C" int fdx_sampler_set_items(fdx_handle h, const int* offsets, const int
   h->items.clear();
   h->items_hash = 0; h->items_max_len = 0; h->items_T = 0;
   if (n_items == 0) return FDX_OK;
-  int end = 0;
-  std::vector<int>& packed = h->items_packed;
-  packed.assign((size_t)n_items * 4, 0);
+  // validated into locals and committed only when every item passed: a failure at item i > 0 must not leave half a layout behind
+  int end = 0, max_len = 0;
+  std::vector<int> items_new, packed((size_t)n_items * 4, 0);
   for (int i = 0; i < n_items; ++i) {
     if (offsets[i] % 32 || offsets[i] < end || lens[i] <= 0 || offsets[i] + lens[i] > T)
       return fail(h, FDX_E_ARG, "fdx_sampler_set_items: item %d = [%d, %d) must start at a multiple of 32, follow item %d and end inside the row of %d frames",
                   i, offsets[i], offsets[i] + lens[i], i - 1, T);
     end = offsets[i] + lens[i];
-    h->items.push_back(offsets[i]); h->items.push_back(lens[i]);
+    items_new.push_back(offsets[i]); items_new.push_back(lens[i]);
     packed[4 * i] = offsets[i]; packed[4 * i + 1] = lens[i];
-    h->items_max_len = std::max(h->items_max_len, lens[i]);
+    max_len = std::max(max_len, lens[i]);
   }
+  h->items.swap(items_new);
+  h->items_max_len = max_len;
   h->items_T = T;
   // what a recorded sampler graph depends on: the launches' grids (number of items, query blocks of the longest, finest key split) -- NOT where
   // the items lie or how long each is: the kernels read offsets / lengths from the device table, rewritten above before any replay.  (Keyed by
@@ -1246,7 +1258,14 @@ extern "C" int fdx_sampler_set_items(fdx_handle h, const int* offsets, const int
   FDX_HIP(h, hipSetDevice(h->device));
   FDX_HIP(h, h->items_dev.ensure(packed.size() * sizeof(int), false, s));
   FDX_HIP(h, h->pidx_dev.ensure((size_t)T * sizeof(int), false, s));
-  FDX_HIP(h, hipMemcpyAsync(h->items_dev.p, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice, s));   // (source owned by the handle)
+  // The table travels as KERNEL ARGUMENTS (copied at launch, 32 items per launch): no host buffer whose lifetime an asynchronous copy
+  // would depend on, and no synchronisation in a call the serving loop makes per micro-batch.
+  for (int i0 = 0; i0 < n_items; i0 += ItemChunk::kN) {
+    ItemChunk c{};
+    c.base = i0; c.n = std::min(ItemChunk::kN, n_items - i0);
+    for (int i = 0; i < c.n; ++i) { c.v[2 * i] = packed[4 * (i0 + i)]; c.v[2 * i + 1] = packed[4 * (i0 + i) + 1]; }
+    hipLaunchKernelGGL(k_items_fill, dim3(1), dim3(64), 0, s, static_cast<int4*>(h->items_dev.p), c);
+  }
   hipLaunchKernelGGL(k_items_pidx, dim3((T + 255) / 256), dim3(256), 0, s, static_cast<int*>(h->pidx_dev.p), static_cast<const int4*>(h->items_dev.p), n_items, T);
   FDX_HIP(h, hipGetLastError());
   return FDX_OK;

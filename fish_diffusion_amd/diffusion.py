@@ -167,11 +167,11 @@ class GaussianDiffusion(nn.Module):
         smin = self.spec_min.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         smax = self.spec_max.detach().reshape(-1).to("cpu", torch.float32).contiguous()
         with eng.lock:
-            if needs_items:
-                oa, la = (C.c_int * B)(*offs), (C.c_int * B)(*lens)
-                _lib.check(_lib.lib().fdx_sampler_set_items(eng.h, oa, la, B, Tc, st), eng.h)
-                self.denoise_fn._prep_sig = None
             try:
+                if needs_items:      # inside the try: a refused layout is cleared by the finally like any other failure
+                    oa, la = (C.c_int * B)(*offs), (C.c_int * B)(*lens)
+                    self.denoise_fn._prep_sig = None
+                    _lib.check(_lib.lib().fdx_sampler_set_items(eng.h, oa, la, B, Tc, st), eng.h)
                 self.denoise_fn.prepare(cond_c, None)
                 for r0 in range(0, n_rows, chunk):
                     r1 = min(n_rows, r0 + chunk)

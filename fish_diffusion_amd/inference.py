@@ -87,17 +87,21 @@ def _uncovered(model: nn.Module, loaded: Iterable[str]) -> list:
 
 def _torch_load(path: str, weights_only: Optional[bool]):
     """The reference's environment (torch < 2.6) unpickles whatever a Lightning `.ckpt` holds; torch >= 2.6 defaults to `weights_only=True`
-    and refuses optimizer / callback state with non-allowlisted classes.  `None`: try the safe loader first and fall back to the full
-    unpickler WITH a warning (a checkpoint is code: only load files you trust); `True` / `False`: exactly that."""
-    if weights_only is not None:
-        return torch.load(path, map_location="cpu", weights_only=weights_only)
+    and refuses optimizer / callback state with non-allowlisted classes.  A checkpoint is code, so the full unpickler is OPT-IN:
+    `None` / `True` use the safe loader only (a refusal is re-raised with a hint); `weights_only=False`, or the environment variable
+    `FISHDX_UNSAFE_LOAD=1` with `None`, unpickle as the reference's `torch.load` does.  Only `pickle.UnpicklingError` is treated as a
+    refusal -- I/O errors and corrupt files propagate as they are."""
+    import pickle
+    if weights_only is None and os.environ.get("FISHDX_UNSAFE_LOAD", "") == "1":
+        weights_only = False
+    if weights_only is False:
+        return torch.load(path, map_location="cpu", weights_only=False)
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:  # pickle.UnpicklingError and friends
-        import warnings
-        warnings.warn(f"{path}: the weights-only loader refused this checkpoint ({type(e).__name__}: {str(e).splitlines()[0][:120]}); "
-                      "falling back to the full unpickler as the reference's torch.load does -- pass weights_only=True to forbid this")
-        return torch.load(path, map_location="cpu", weights_only=False)
+    except pickle.UnpicklingError as e:
+        raise pickle.UnpicklingError(
+            f"{path}: the weights-only loader refused this checkpoint ({str(e).splitlines()[0][:160]}).  If you trust the file, pass "
+            "weights_only=False (or set FISHDX_UNSAFE_LOAD=1) to unpickle it in full, as the reference's torch.load does") from e
 
 
 def load_checkpoint(config, checkpoint, device="cuda", model_cls=SVCModel, allow_missing: bool = False, report: Optional[dict] = None,

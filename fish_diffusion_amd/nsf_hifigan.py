@@ -165,7 +165,10 @@ class Generator(nn.Module):
         """`n` extra engines sharing this module's packed arena, each with a workspace and a HIP stream of its own: independent
         utterances go through the generator side by side (a batch-1 pass leaves part of the chip idle in the small-grid stages;
         every pass is still the batch-1 pass, so each waveform is bit-identical to a call alone).  A lane's engine is only ever
-        used on the lane's stream -- the workspace of a handle is ordered by its stream."""
+        used on the lane's stream -- the workspace of a handle is ordered by its stream.
+        Memory: a lane's workspace grows to the longest utterance it has vocoded (~0.9 GB per 10 s at hop 512: every stage's activations
+        live at once), so `n` lanes hold ~n times the vocoder workspace until `release_lanes()`; `pipeline.synthesize` sizes `n` from the
+        micro-batch and from free device memory."""
         primary = self.engine(torch.device(device))
         if self._lanes_arena is not self._arena or (self._lanes and self._lanes[0][0].device != primary.device):
             self._lanes, self._lanes_arena = [], self._arena
@@ -174,6 +177,10 @@ class Generator(nn.Module):
             _lib.check(_lib.lib().fdx_nsf_attach(hnd.h, C.byref(self._desc), _lib.ptr(self._arena), self._arena.numel()), hnd.h)
             self._lanes.append((hnd, torch.cuda.Stream(device=primary.device)))
         return self._lanes[:n]
+
+    def release_lanes(self):
+        """Drop the extra engines `lanes()` created (their workspaces and streams); the next `lanes()` call builds them again."""
+        self._lanes, self._lanes_arena = [], None
 
     def packed_arena(self, device) -> torch.Tensor:
         self.engine(torch.device(device))

@@ -79,6 +79,19 @@ def make_batches(lengths: Sequence[int], max_batch: int, max_pad_ratio: Optional
 
 
 @torch.no_grad()
+def _lane_count(requested: int, B: int, samples: int, dev) -> int:
+    """Vocoder lanes for one micro-batch: never more than its utterances, and never more than free device memory holds -- a lane's
+    workspace is every stage's activations of one utterance at once (~2 kB per output sample for config_v1: 0.9 GB per 10 s), cached on
+    the Generator until `release_lanes()`.  Keeps half of what is free for the denoiser's next micro-batch."""
+    n = min(requested, B)
+    try:
+        free, _ = torch.cuda.mem_get_info(dev)
+        n = min(n, int(free // 2 // max(1, 2048 * samples)))
+    except Exception:        # no such query on this build: the caller's number stands
+        pass
+    return max(0, n)
+
+
 def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequence[torch.Tensor], *, max_batch: int = 8,
                sampler_interval: Optional[int] = None, noise_predictor: Optional[str] = None, rank: int = 0, world: int = 1,
                mel_scale: Optional[float] = None, x_init_fn: Optional[Callable] = None,
@@ -101,7 +114,9 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
     from a run alone).
     `vocoder_lanes` (default 4, env FDX_VOC_LANES): the utterances of a micro-batch go through the generator on this many HIP streams side
     by side (`Generator.lanes`): every pass is still the batch-1 pass on the unpadded mel -- bit-identical waveforms -- but the small-grid
-    stages of different utterances fill each other's idle CUs.  0 / 1: one after the other on the caller's stream.
+    stages of different utterances fill each other's idle CUs.  0 / 1: one after the other on the caller's stream.  Each lane keeps a
+    vocoder workspace of its own (~0.9 GB per 10 s of audio) cached on the Generator: the count is capped by the micro-batch size and by
+    free device memory (`_lane_count`), `Generator.release_lanes()` frees them.
     `on_error`: "raise" (default) lets the first exception out, as a plain loop would.  "isolate" is the reference's `safe_process`
     (tools/preprocessing/extract_features.py:175-217: one bad file is logged and the worker carries on): an utterance that fails validation
     is skipped; a micro-batch that raises is re-run one member at a time so that a bad member does not cost its batch-mates; whatever
@@ -177,7 +192,9 @@ def synthesize(diffusion, vocoder, features: Sequence[torch.Tensor], f0s: Sequen
             kw["x_masks"] = kw["cond_masks"] = masks
         mel = diffusion(feat, sampler_interval=sampler_interval, noise_predictor=noise_predictor, **kw)     # [B, T, M]
         res = []
-        lanes = gen.lanes(dev, min(vocoder_lanes, B)) if use_lanes and B > 1 else []
+        lanes = gen.lanes(dev, _lane_count(vocoder_lanes, B, T * hop, dev)) if use_lanes and B > 1 else []
+        if len(lanes) < 2:
+            lanes = []
         cur = torch.cuda.current_stream(dev) if lanes else None
         try:
             for b, i in enumerate(idx):

@@ -57,7 +57,7 @@ class _Opaque:                       # a class the weights-only unpickler does n
 def test_load_checkpoint_schedule_buffers_warn_and_full_unpickler_fallback(lib_built, tmp_path):
     """A reference checkpoint saved without the predictor sub-modules' buffers loads in the reference (strict=False) and samples with the
     schedule `__init__` computes from the config: here that is a warning + `report["missing_schedule_buffers"]`, while a missing weight or
-    `spec_min` still raises.  A Lightning file whose extra state needs the full unpickler loads with a warning unless `weights_only=True`."""
+    `spec_min` still raises.  A Lightning file whose extra state needs the full unpickler is refused unless the caller opts in (`weights_only=False` / FISHDX_UNSAFE_LOAD=1)."""
     from fish_diffusion_amd.inference import SVCModel, load_checkpoint
     from oracle import features_ref
     from tests.helpers import WN_SMALL, wavenet_sd
@@ -79,10 +79,21 @@ def test_load_checkpoint_schedule_buffers_warn_and_full_unpickler_fallback(lib_b
         load_checkpoint(cfg, {"state_dict": no_spec}, device="cpu")
     # non-allowlisted object beside the weights
     torch.save({"state_dict": sd, "callbacks": {"x": _Opaque()}}, tmp_path / "opaque.ckpt")
-    with pytest.raises(Exception):
+    import pickle
+    with pytest.raises(pickle.UnpicklingError):
         load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu", weights_only=True)
-    with pytest.warns(UserWarning, match="full unpickler"):
-        m2 = load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu", report=rep)
+    # the default is the safe loader too: the full unpickler is opt-in, and an I/O error is not a "refusal"
+    with pytest.raises(pickle.UnpicklingError, match="weights_only=False"):
+        load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu")
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint(cfg, str(tmp_path / "absent.ckpt"), device="cpu")
+    monkey = pytest.MonkeyPatch()
+    monkey.setenv("FISHDX_UNSAFE_LOAD", "1")
+    try:
+        load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu")
+    finally:
+        monkey.undo()
+    m2 = load_checkpoint(cfg, str(tmp_path / "opaque.ckpt"), device="cpu", report=rep, weights_only=False)
     assert rep["missing"] == [] and rep["missing_schedule_buffers"] == []
     assert torch.equal(m2.model.text_encoder.projection.weight, sd["model.text_encoder.projection.weight"])
 
