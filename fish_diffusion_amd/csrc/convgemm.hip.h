@@ -535,6 +535,37 @@ struct EpiScaleRes {  // convnext.py:84-92: x = residual + gamma * (pwconv2(.) +
   }
 };
 
+// Post-norm residual of nn.TransformerDecoderLayer with the LayerNorms FOLDED AWAY (round 6; tfdec.hip, declayer.hip.h run_declayer_ln):
+//   r' = LN_pending(r) + (W in + bias)                       x = norm(x + sublayer(x)), one sublayer later
+// The residual stream X is kept UN-normalised, with the means and centred sums of squares of its 32-row groups per frame in ST [item][T][2][16]
+// (what PRE_LNP consumers combine into mean / rstd).  `old` is normalised on the fly from its own statistics (-mean and rstd arrive from the
+// kernel's column-statistics stage, PRE_RESLN), the new value's group statistics are formed across the workgroup's four waves and written
+// next to it.  lnw == null: `old` carries no pending norm (the first sublayer of the first layer).
+// Only for convgemm_kernel<1, true, PRE_RESLN, EpiResLN>: the kernel calls value() and stores X / ST itself.
+struct EpiResLN {
+  static constexpr bool kPaired = false;
+  float* X; long bs; int ld;
+  const float* bias; int bias_ld, bias_bs;     // bias of (row, item) at bias[row * bias_ld + item * bias_bs]
+  const float* lnw; const float* lnb;          // the pending LayerNorm's affine parameters, or null
+  float* st_out;                               // [item][T][2][16]; never the buffer the kernel's col_stats point at (other row groups still read it)
+  int M, T;
+  struct Pre { f2 old; float bias, w, b; };
+  __device__ __forceinline__ Pre load(int b, int row, int t, bool two) const {
+    Pre p;
+    const int r = min(row, M - 1);
+    p.old = ld2(X + b * bs + (long)r * ld + t, two);
+    p.bias = bias[(long)r * bias_ld + b * bias_bs];
+    p.w = *(lnw ? lnw + r : bias + (long)r * bias_ld);
+    p.b = *(lnw ? lnb + r : bias + (long)r * bias_ld);
+    return p;
+  }
+  __device__ __forceinline__ f2 value(f2 v, const Pre& p, f2 neg_mean, f2 rstd) const {
+    const f2 o = lnw ? ((p.old + neg_mean) * rstd) * p.w + p.b : p.old;
+    return o + (v + p.bias);
+  }
+  __device__ __forceinline__ void store(int, int, int, bool, f2, const Pre&) const {}   // (unused: see above)
+};
+
 struct EpiResblock {  // models.py:103-110 conv2: x = xt + x; plus the MRF mean of :426-432
   static constexpr bool kPaired = false;
   float* out; const float* resid; long bs; int ld;
@@ -640,7 +671,13 @@ struct EpiLogMel {  // audio.py:11-18 + nsf_hifigan.py:104-105
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 constexpr int OPK_F32 = 0, OPK_BF16 = 1;   // operand kind: fp32 rows (32x32x2 MFMA) / C8-blocked bf16 (32x32x16 MFMA)
-constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2;   // operand / result transforms (a bool converts: false/true = none/lrelu)
+constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2, PRE_RESLN = 3, PRE_LNP = 4;   // operand / result transforms (a bool converts: false/true = none/lrelu)
+// PRE_LNP ("plain"): LayerNorm over K folded into the GEMM with the B operand left as it is: result = rstd[t] (acc - mean[t] rowsum[row]);
+//   `ln_R` = [rows] row sums of the (affine-folded) weights.  One multiply-subtract per output instead of PRE_LN's 16-term group correction (which cost
+//   the transformer's consumers 2-3 us per launch, round 6); exact to rounding while |mean| is not orders of magnitude above the deviation -- a
+//   post-norm transformer's residual stream (LayerNorm output + sublayer); ConvNext's depthwise-conv output keeps the centred form.
+// PRE_RESLN (EpiResLN only): the column statistics belong to the epilogue's RESIDUAL operand, not to the GEMM's B operand -- same combine stage,
+//   no row-sum correction; the epilogue emits the new value with its own group statistics.
 
 // (PRE_LN keeps its statistics in registers across the K loop: the second launch-bounds argument holds that instantiation to
 // the 256 VGPRs that let two workgroups share a CU, like every other instantiation already does unprompted.)
@@ -696,11 +733,16 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
     return row_base + rb * 32 + acc_row(r, half);
   };
   typename Epi::Pre pre[NS];
+  float ln_rsum[PRE == PRE_LNP ? NS : 1];     // PRE_LNP: row sums of the folded weights at this wave's sites (rows padded to the tile: always in range)
   auto prefetch_epilogue = [&]() {
     if constexpr (SPLITK) {
       if (col_ok) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) pre[i] = epi.load(item, site_row(wave * NS + i), tc, col_two);
+      }
+      if constexpr (PRE == PRE_LNP) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) ln_rsum[i] = a.ln_R[site_row(wave * NS + i)];
       }
     }
   };
@@ -719,26 +761,35 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
   // and var = (sum_g M2_g + 32 sum_g delta_g^2) / K (Chan et al.) -- every term is a product of centred quantities, there is
   // no E[u^2] - mean^2 or acc - mean*rowsum cancellation.  The K loop is untouched; the statistics' loads are issued with the
   // epilogue prefetch and consumed after the reduction.
-  static_assert(PRE != PRE_LN || (SPLITK && !Epi::kPaired), "PRE_LN: split-K, unpaired epilogues");
-  static_assert(PRE != PRE_LN || ROWS * 4 == NW * 64, "PRE_LN: one float4 of the tile's row sums per thread");
+  constexpr bool kColStats = PRE == PRE_LN || PRE == PRE_RESLN || PRE == PRE_LNP;
+  constexpr bool kColMean = PRE == PRE_RESLN || PRE == PRE_LNP;      // the combine stage leaves (mean, rstd) per column instead of (delta_g[16], rstd)
+  static_assert(!kColStats || (SPLITK && !Epi::kPaired), "PRE_LN / PRE_RESLN / PRE_LNP: split-K, unpaired epilogues");
+  static_assert(PRE != PRE_LN || ROWS * 4 <= NW * 64, "PRE_LN: at most one float4 of the tile's row sums per thread");
+  static_assert(PRE != PRE_RESLN || (RB == 1 && std::is_same<Epi, EpiResLN>::value), "PRE_RESLN: 32-row tiles (one statistics group) with EpiResLN");
   __shared__ float ln_rows[PRE == PRE_LN ? ROWS * 16 : 1];   // this tile's rows of ln_R (weights: they come from HBM / MALL)
-  __shared__ float ln_cols[PRE == PRE_LN ? 64 * 17 : 1];          // per column of the tile: delta_g[16], rstd
+  __shared__ float ln_cols[kColStats ? 64 * 17 : 1];          // per column of the tile: delta_g[16], rstd
+  __shared__ float4 ln_gs[PRE == PRE_RESLN ? NW * 32 : 1];   // PRE_RESLN: per wave and column pair {mean8.x, mean8.y, M2_8.x, M2_8.y} of the new value
   // The statistics are combined ONCE per workgroup, 4 threads per column (thread = column tid >> 2, groups 4q .. 4q+3): two
   // coalesced float4 loads per thread.  (Every lane loading its own two frames' 2 x 128 B -- 16 loads touching 64 different
   // lines each -- kept the CU's L1 tag pipe busy for ~4 us per launch: 29.4 vs 24.7 us for the same GEMM without it.)
   float4 rq{0.f, 0.f, 0.f, 0.f}, sq_mean{0.f, 0.f, 0.f, 0.f}, sq_m2{0.f, 0.f, 0.f, 0.f};
   auto ln_prefetch = [&]() {
-    if constexpr (PRE == PRE_LN) {
-      rq = reinterpret_cast<const float4*>(a.ln_R + (long)row_base * 16)[threadIdx.x];
-      const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
-      const float4* p = reinterpret_cast<const float4*>(a.col_stats + ((long)item * a.T + min(tile_in_item * 64 + c, a.T - 1)) * 32);
-      sq_mean = p[q];
-      sq_m2 = p[4 + q];
+    if constexpr (PRE == PRE_LN)   // (32-row tiles: the upper half of the workgroup re-reads the lower half's row sums, unused)
+      rq = reinterpret_cast<const float4*>(a.ln_R + (long)row_base * 16)[ROWS * 4 == NW * 64 ? threadIdx.x : threadIdx.x & (ROWS * 4 - 1)];
+    if constexpr (kColStats) {
+      if (PRE != PRE_RESLN || a.col_stats) {    // (PRE_RESLN without statistics: a plain residual, wave-uniform)
+        const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const float4* p = reinterpret_cast<const float4*>(a.col_stats + ((long)item * a.T + min(tile_in_item * 64 + c, a.T - 1)) * 32);
+        sq_mean = p[q];
+        sq_m2 = p[4 + q];
+      }
     }
   };
   auto ln_publish = [&]() {   // after the K loop, before the reduction's barrier
     if constexpr (PRE == PRE_LN) {
-      reinterpret_cast<float4*>(ln_rows)[threadIdx.x] = rq;
+      if (ROWS * 4 == NW * 64 || threadIdx.x < ROWS * 4) reinterpret_cast<float4*>(ln_rows)[threadIdx.x] = rq;
+    }
+    if constexpr (kColStats) {
       const int c = threadIdx.x >> 2, q = threadIdx.x & 3;
       const float mg[4] = {sq_mean.x, sq_mean.y, sq_mean.z, sq_mean.w};
       const float m2g[4] = {sq_m2.x, sq_m2.y, sq_m2.z, sq_m2.w};
@@ -753,11 +804,14 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float d = 4 * q + k < a.n_groups ? mg[k] - mean : 0.f;
-        ln_cols[c * 17 + 4 * q + k] = d;
+        if constexpr (!kColMean) ln_cols[c * 17 + 4 * q + k] = d;
         dev2 += d * d;
       }
       dev2 += __shfl_xor(dev2, 1); dev2 += __shfl_xor(dev2, 2);
-      if (q == 0) ln_cols[c * 17 + 16] = 1.f / sqrtf((m2 + 32.f * dev2) / (float)(32 * a.n_groups) + a.ln_eps);
+      if (q == 0) {
+        ln_cols[c * 17 + 16] = 1.f / sqrtf((m2 + 32.f * dev2) / (float)(32 * a.n_groups) + a.ln_eps);
+        if constexpr (kColMean) ln_cols[c * 17] = mean;
+      }
     }
   };
 
@@ -948,6 +1002,47 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
     FDX_STAMP(3);
     __syncthreads();
     FDX_STAMP(4);
+    if constexpr (PRE == PRE_RESLN) {
+      // ---- EpiResLN: new residual value and its 32-row group statistics across the four waves.  A wave holds 8 of the
+      // group's rows per column (4 per lane half): two-pass (mean8, M2_8) inside the wave, ONE exchange, Chan's combination in wave order.
+      static_assert(NS == 4, "a wave's four sites = four consecutive rows per lane half");
+      const float* lc = ln_cols + (2 * li) * 17;
+      const int g = mtg;                                   // ROWS == 32: the tile's rows are statistics group mtg
+      const f2 dl{-lc[0], -lc[17]}, rstd{lc[16], lc[17 + 16]};   // (old - mean) rstd
+      f2 v[NS];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int r = (wave * NS + i) & 15;
+        f2 sum = *reinterpret_cast<const f2*>(red + ridx(0, r));
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum += *reinterpret_cast<const f2*>(red + ridx(w, r));
+        v[i] = epi.value(sum, pre[i], dl, rstd);
+      }
+      f2 s8 = (v[0] + v[1]) + (v[2] + v[3]);
+      s8.x += __shfl_xor(s8.x, 32); s8.y += __shfl_xor(s8.y, 32);
+      const f2 mean8 = s8 * 0.125f;
+      f2 m8{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NS; ++i) { const f2 d = v[i] - mean8; m8 += d * d; }
+      m8.x += __shfl_xor(m8.x, 32); m8.y += __shfl_xor(m8.y, 32);
+      if (half == 0) ln_gs[wave * 32 + li] = float4{mean8.x, mean8.y, m8.x, m8.y};
+      __syncthreads();
+      const float4 p0 = ln_gs[li], p1 = ln_gs[32 + li], p2 = ln_gs[64 + li], p3 = ln_gs[96 + li];
+      const f2 mean_g = f2{((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y} * 0.25f;
+      const f2 e0 = f2{p0.x, p0.y} - mean_g, e1 = f2{p1.x, p1.y} - mean_g, e2 = f2{p2.x, p2.y} - mean_g, e3 = f2{p3.x, p3.y} - mean_g;
+      const f2 M2 = ((f2{p0.z, p0.w} + f2{p1.z, p1.w}) + f2{p2.z, p2.w}) + f2{p3.z, p3.w} + 8.f * (((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3);
+      if (!col_ok) return;
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+        st2p_keep(epi.X + item * epi.bs + (long)site_row(wave * NS + i) * epi.ld + tc, v[i], col_two);
+      if (wave == 0 && half == 0) {
+        float* st = epi.st_out + ((long)item * epi.T + tc) * 32 + g;
+        st[0] = mean_g.x; st[16] = M2.x;
+        if (col_two) { st[32] = mean_g.y; st[48] = M2.y; }
+      }
+      FDX_STAMP(5);
+      return;
+    }
     if (!col_ok) return;
     if constexpr (Epi::kPaired) {
       f4 sum[NS];
@@ -977,6 +1072,12 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
         sum[i] = *reinterpret_cast<const f2*>(red + ridx(0, r) + 2 * blk);
 #pragma unroll
         for (int w = 1; w < NW; ++w) sum[i] += *reinterpret_cast<const f2*>(red + ridx(w, r) + 2 * blk);
+      }
+      if constexpr (PRE == PRE_LNP) {
+        const float* lc = ln_cols + (2 * li) * 17;
+        const f2 mean{lc[0], lc[17]}, rstd{lc[16], lc[17 + 16]};
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sum[i] = (sum[i] - mean * ln_rsum[i]) * rstd;
       }
       if constexpr (PRE == PRE_LN) {
         f2 delta[16];

@@ -20,9 +20,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TdLayer {
   PackedW sa_in, sa_out, ca_q, ca_kv, ca_out, lin1, lin2;
   size_t n1w, n1b, n2w, n2b, n3w, n3b;
+  // LayerNorms folded into their consumers (run_declayer_ln): row sums [round_up(rows, 64)] of the folded weights (PRE_LNP)
+  bool folded = false;
+  size_t sa_in_R = 0, ca_q_R = 0, lin1_R = 0;
 };
 
-inline void plan_declayer(size_t& cur, TdLayer& y, int D, int H) {
+inline void plan_declayer(size_t& cur, TdLayer& y, int D, int H, bool folded = false) {
   y.sa_in = plan64(cur, 3 * D, D);
   y.sa_out = plan32(cur, D, D);
   y.ca_q = plan32(cur, D, D);
@@ -31,18 +34,50 @@ inline void plan_declayer(size_t& cur, TdLayer& y, int D, int H) {
   y.lin1 = plan64(cur, H, D);
   y.lin2 = plan32(cur, D, H);
   for (size_t* p : {&y.n1w, &y.n1b, &y.n2w, &y.n2b, &y.n3w, &y.n3b}) { *p = cur; cur += round_up(D, 64); }
+  y.folded = folded;
+  if (folded) {
+    y.sa_in_R = cur; cur += (size_t)round_up(3 * D, 64);
+    y.ca_q_R = cur; cur += (size_t)round_up(D, 64);
+    y.lin1_R = cur; cur += (size_t)round_up(H, 64);
+  }
+}
+
+// A Linear behind a LayerNorm, with the norm's affine part folded in (as convnext.hip does for pwconv1):
+//   W (((u - mean) rstd) w + b) + b1  =  rstd ((W diag(w)) u - mean R) + (W b + b1);   R[r] = row sum of W diag(w)
+// (fp64 sums, rounded once).  lnw == null: packed as it is, R untouched.
+inline void pack_lin_ln(float* A, const PackedW& p, size_t R_off, const float* W, int rows, int cin, const float* bias, const float* lnw,
+                        const float* lnb) {
+  if (!lnw) { pack_lin(A, p, W, rows, cin, bias); return; }
+  std::vector<float> Wf((size_t)rows * cin), bf(rows);
+  for (int r = 0; r < rows; ++r) {
+    double acc = bias ? bias[r] : 0.0;
+    for (int c = 0; c < cin; ++c) { Wf[(size_t)r * cin + c] = W[(size_t)r * cin + c] * lnw[c]; acc += (double)W[(size_t)r * cin + c] * (double)lnb[c]; }
+    bf[r] = (float)acc;
+  }
+  pack_lin(A, p, Wf.data(), rows, cin, bf.data());
+  for (int r = 0; r < rows; ++r) {
+    double acc = 0;
+    for (int c = 0; c < cin; ++c) acc += (double)Wf[(size_t)r * cin + c];
+    A[R_off + r] = (float)acc;
+  }
 }
 
 // 18 tensors in nn.TransformerDecoderLayer's state_dict order: self_attn.{in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias},
 // multihead_attn.(same four), linear1.{weight, bias}, linear2.{weight, bias}, norm1.{weight, bias}, norm2.*, norm3.*.  Returns 18.
-inline int pack_declayer(float* A, const TdLayer& y, const float* const* w, int D, int H) {
+// Folded layers: ca_q carries norm1, linear1 norm2, and the self-attention in-projection the PREVIOUS layer's norm3 (`prev_n3w/b`; null for the
+// first layer, whose input is a plain tensor) -- this layer's norm3 goes into whatever consumes the layer's output.
+inline int pack_declayer(float* A, const TdLayer& y, const float* const* w, int D, int H, const float* prev_n3w = nullptr,
+                         const float* prev_n3b = nullptr) {
+  const bool f = y.folded;
+  const float* n1w = f ? w[12] : nullptr; const float* n1b = f ? w[13] : nullptr;
+  const float* n2w = f ? w[14] : nullptr; const float* n2b = f ? w[15] : nullptr;
   int k = 0;
-  pack_lin(A, y.sa_in, w[k], 3 * D, D, w[k + 1]); k += 2;
+  pack_lin_ln(A, y.sa_in, y.sa_in_R, w[k], 3 * D, D, w[k + 1], f ? prev_n3w : nullptr, prev_n3b); k += 2;
   pack_lin(A, y.sa_out, w[k], D, D, w[k + 1]); k += 2;
-  pack_lin(A, y.ca_q, w[k], D, D, w[k + 1]);                                        // in_proj rows [0, D): the query projection
+  pack_lin_ln(A, y.ca_q, y.ca_q_R, w[k], D, D, w[k + 1], n1w, n1b);                  // in_proj rows [0, D): the query projection
   pack_lin(A, y.ca_kv, w[k] + (size_t)D * D, 2 * D, D, w[k + 1] + D); k += 2;       // rows [D, 3D): key and value
   pack_lin(A, y.ca_out, w[k], D, D, w[k + 1]); k += 2;
-  pack_lin(A, y.lin1, w[k], H, D, w[k + 1]); k += 2;
+  pack_lin_ln(A, y.lin1, y.lin1_R, w[k], H, D, w[k + 1], n2w, n2b); k += 2;
   pack_lin(A, y.lin2, w[k], D, H, w[k + 1]); k += 2;
   for (size_t off : {y.n1w, y.n1b, y.n2w, y.n2b, y.n3w, y.n3b}) memcpy(A + off, w[k++], D * sizeof(float));
   return k;
@@ -561,6 +596,72 @@ inline hipError_t run_declayer(const float* A, const TdLayer& y, int B, int T, i
   if ((e = gemm(A, y.lin1, B, T, X, bsD, ld, bias_epi(sc.G, bsH, ld, A + y.lin1.b_off, H, ACT_GELU), s)) != hipSuccess) return e;
   if ((e = residual(y.lin2, sc.G, bsH)) != hipSuccess) return e;
   launch_layernorm(X, bsD, ld, A + y.n3w, A + y.n3b, B, D, T, s);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ the same layer without LayerNorm launches
+// Round 6.  Post-norm makes every LayerNorm's output both the next sublayer's input AND its residual; rounds 4-5 ran k_td_layernorm three times
+// per layer (36 launches of 5.8 us = 10 % of a transformer-denoiser call, none of it matrix work).  Here the residual stream X stays
+// UN-normalised with the statistics of its 32-channel groups per frame in `st[cur]`:
+//   consumers (self-attention in-projection, cross-attention query projection, linear1) read it through PRE_LNP with the pending norm's affine
+//     part folded into their weights at pack time (pack_declayer);
+//   the three residual GEMMs normalise the OLD value on the fly, add their result, and emit the new value with new statistics
+//     (EpiResLN / PRE_RESLN, convgemm.hip.h) into the other statistics buffer (other row groups of the same columns still read the old one).
+// `ln` carries the pending norm between sublayers and across layers; after the last layer the caller's next GEMM consumes it the same way.
+struct LnStream {
+  float* st[2] = {nullptr, nullptr};     // [B][T][2][16] each
+  int cur = 0;
+  const float* pw = nullptr; const float* pb = nullptr;   // pending LayerNorm of X (null: X is a plain tensor)
+};
+
+template <class Epi>
+inline hipError_t gemm_ln(const float* A, const PackedW& p, size_t R_off, int B, int T, int D, const float* X, long x_bs, int ldx, const LnStream& ln,
+                          const Epi& e, hipStream_t s) {
+  if (!ln.pw) return gemm(A, p, B, T, X, x_bs, ldx, e, s);
+  ConvGeom g{B, T, p.cin8, 1, 0, 0, p.n_mtiles};
+  const float4* Wp = reinterpret_cast<const float4*>(A + p.w_off);
+  if (p.RB == 1) return launch_convgemm<1, true, PRE_LNP, Epi>(g, Wp, X, x_bs, ldx, 1.f, e, s, nullptr, nullptr, ln.st[ln.cur], A + R_off, D / 32, 1e-5f);
+  return launch_convgemm<2, true, PRE_LNP, Epi>(g, Wp, X, x_bs, ldx, 1.f, e, s, nullptr, nullptr, ln.st[ln.cur], A + R_off, D / 32, 1e-5f);
+}
+
+inline hipError_t run_declayer_ln(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV, long kv_bs,
+                                  const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s, ProfEvents* prof,
+                                  const float* ca_bias, int ca_bias_ld, int ca_bias_bs, const AttnItems& items, LnStream& ln) {
+  const long bsD = (long)D * ld, bsH = (long)H * ld;
+  const int DH = D / kHeads;
+  // X = LN_pending(X) + W in + b, un-normalised and centred, statistics to the other buffer; `nw / nb` = the norm that follows this sublayer
+  auto residual = [&](const PackedW& p, const float* in, long in_bs, const float* nw, const float* nb, const float* bias = nullptr, int b_ld = 1,
+                      int b_bs = 0) {
+    EpiResLN e{};
+    e.X = X; e.bs = bsD; e.ld = ld; e.bias = bias ? bias : A + p.b_off; e.bias_ld = b_ld; e.bias_bs = b_bs;
+    e.lnw = ln.pw; e.lnb = ln.pb; e.st_out = ln.st[ln.cur ^ 1]; e.M = D; e.T = T;
+    ConvGeom g{B, T, p.cin8, 1, 0, 0, p.n_mtiles};
+    const hipError_t rc = launch_convgemm<1, true, PRE_RESLN, EpiResLN>(g, reinterpret_cast<const float4*>(A + p.w_off), in, in_bs, ld, 1.f, e, s, nullptr,
+                                                                         nullptr, ln.pw ? ln.st[ln.cur] : nullptr, nullptr, D / 32, 1e-5f);
+    ln.cur ^= 1; ln.pw = nw; ln.pb = nb;
+    return rc;
+  };
+  hipError_t e;
+  AttnArgs at{};
+  at.O = sc.O; at.o_bs = bsD; at.ldo = ld; at.Tq = T; at.Tk = T; at.scale = 1.f / sqrtf((float)DH);
+  at.P = sc.P; at.ML = sc.ML;
+  // ---- self-attention block
+  if ((e = gemm_ln(A, y.sa_in, y.sa_in_R, B, T, D, X, bsD, ld, ln, bias_epi(sc.QKV, 3 * bsD, ld, A + y.sa_in.b_off, 3 * D, ACT_NONE), s)) != hipSuccess) return e;
+  at.Q = sc.QKV; at.q_bs = 3 * bsD; at.ldq = ld;
+  at.K = sc.QKV + (size_t)D * ld; at.k_bs = 3 * bsD; at.ldk = ld;
+  at.V = sc.QKV + (size_t)2 * D * ld; at.v_bs = 3 * bsD; at.ldv = ld;
+  at.kmask = tgt_kpm;
+  if ((e = launch_attn(DH, at, B, s, prof, items)) != hipSuccess) return e;
+  if ((e = residual(y.sa_out, sc.O, bsD, A + y.n1w, A + y.n1b)) != hipSuccess) return e;
+  // ---- cross-attention block
+  if ((e = gemm_ln(A, y.ca_q, y.ca_q_R, B, T, D, X, bsD, ld, ln, bias_epi(sc.QKV, 3 * bsD, ld, A + y.ca_q.b_off, D, ACT_NONE), s)) != hipSuccess) return e;
+  at.K = KV; at.k_bs = kv_bs; at.V = KV + (size_t)D * ld; at.v_bs = kv_bs;
+  at.kmask = mem_kpm;
+  if ((e = launch_attn(DH, at, B, s, prof, items)) != hipSuccess) return e;
+  if ((e = residual(y.ca_out, sc.O, bsD, A + y.n2w, A + y.n2b, ca_bias, ca_bias_ld, ca_bias_bs)) != hipSuccess) return e;
+  // ---- feed-forward block
+  if ((e = gemm_ln(A, y.lin1, y.lin1_R, B, T, D, X, bsD, ld, ln, bias_epi(sc.G, bsH, ld, A + y.lin1.b_off, H, ACT_GELU), s)) != hipSuccess) return e;
+  if ((e = residual(y.lin2, sc.G, bsH, A + y.n3w, A + y.n3b)) != hipSuccess) return e;
   return hipGetLastError();
 }
 

@@ -32,8 +32,16 @@ struct TdLayout {
   size_t pos = 0;            // positional_embedding [n_positions][D], raw
   size_t scale_q = 0, scale_k = 0;
   std::vector<TdLayer> layers;
+  bool folded = false;       // LayerNorms folded into their consumers (declayer.hip.h run_declayer_ln)
+  size_t out0_R = 0;         // row sums of output_projection.0 with the last layer's norm3 folded in
   size_t total_floats = 0;
 };
+
+// FDX_TD_LNFOLD=0: the k_td_layernorm launches of rounds 4-5 (A/B).  Decides the arena layout: read once per process.
+bool td_fold_ln() {
+  static const bool v = [] { const char* e = getenv("FDX_TD_LNFOLD"); return !e || atoi(e) != 0; }();
+  return v;
+}
 
 int td_validate(const fdx_tfdec_desc* d) {
   if (!d) return fail(nullptr, FDX_E_ARG, "null tfdec desc");
@@ -58,9 +66,11 @@ void td_layout(const fdx_tfdec_desc& d, TdLayout& l) {
   l.emb3 = plan64(cur, D, H);
   l.cond0 = plan64(cur, H, d.condition_dim);
   l.cond2 = plan32(cur, D, H);
+  l.folded = td_fold_ln();
   l.layers.assign(d.num_layers, TdLayer{});
-  for (auto& y : l.layers) plan_declayer(cur, y, D, H);
+  for (auto& y : l.layers) plan_declayer(cur, y, D, H, l.folded);
   l.out0 = plan32(cur, D, D);
+  if (l.folded) { l.out0_R = cur; cur += (size_t)round_up(D, 64); }
   l.out2 = plan64(cur, d.mel_channels, D);
   l.total_floats = cur;
 }
@@ -69,6 +79,7 @@ void td_layout(const fdx_tfdec_desc& d, TdLayout& l) {
 struct TdBufs {
   DevBuf X, QKV, KVh, O, G, Hin, H2, C0, condp, c1, cmask;   // KVh: [B][L][2D][ld] hoisted cross-attention keys / values
   DevBuf AP, AML;   // attention: partial O^T and (max, sum) of the key splits (declayer.hip.h k_attn_qs)
+  DevBuf ST;              // folded LayerNorms: two buffers of per-frame group statistics [B][T][2][16] (run_declayer_ln)
   DevBuf E, Hm, S0, SV, CB;   // per sampler run: step embeddings [D][n]; Wv step [D][n] (scratch); cross-attention out-projection bias [L][D][n]
   int ldn = 0;
 };
@@ -126,8 +137,13 @@ extern "C" int fdx_tfdec_pack(const fdx_tfdec_desc* d, const float* const* w, in
   pack_lin(A, l.emb3, w[k], D, H, w[k + 1]); k += 2;
   pack_lin(A, l.cond0, w[k], H, E, w[k + 1]); k += 2;
   pack_lin(A, l.cond2, w[k], D, H, w[k + 1]); k += 2;
-  for (auto& y : l.layers) k += pack_declayer(A, y, w + k, D, H);
-  pack_lin(A, l.out0, w[k], D, D, w[k + 1]); k += 2;
+  const float* n3w = nullptr; const float* n3b = nullptr;       // the previous layer's norm3: folded into the next consumer of the stream
+  for (auto& y : l.layers) {
+    const float* const* wl = w + k;
+    k += pack_declayer(A, y, wl, D, H, n3w, n3b);
+    n3w = wl[16]; n3b = wl[17];
+  }
+  pack_lin_ln(A, l.out0, l.out0_R, w[k], D, D, w[k + 1], l.folded ? n3w : nullptr, n3b); k += 2;
   pack_lin(A, l.out2, w[k], M, D, w[k + 1]); k += 2;
   return FDX_OK;
 }
@@ -180,6 +196,7 @@ extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, 
   FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s));
   FDX_HIP(h, b.AP.ensure(attn_part_floats(B, T, D, ld, h->n_items()) * sizeof(float), false, s));
   FDX_HIP(h, b.AML.ensure(attn_ml_floats(B, T, h->n_items(), h->items_max_len) * sizeof(float), false, s));
+  if (l.folded) FDX_HIP(h, b.ST.ensure((size_t)2 * B * T * 32 * sizeof(float), geom, s));
   // C0 = condition_projection(conditioner) + positional_embedding[:T] * position_scale_key   (convnext.py:348,353-357)
   hipLaunchKernelGGL(k_copy_rows, ew_grid(T, B * E), dim3(kEwBlock), 0, s, b.condp.f() + kHalo, (long)E * ld, ld, cond, (long)E * T, T, E, T,
                      1.f, (const uint8_t*)nullptr);
@@ -265,10 +282,20 @@ int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
   // memory = mask(C0 + diffusion_step) (:353,359-360) is never formed: its keys / values are the hoisted ones of C0, the step's share is the
   // per-step bias of each layer's cross-attention out-projection (column col0 of CB; sb_bs = its stride between batch items)
   const DecScratch sc{QKV, O, G, b.AP.f() + kHalo, b.AML.f()};
-  for (int i = 0; i < L; ++i)
-    FDX_HIP(h, run_declayer(A, l.layers[i], B, T, D, H, ld, X, KVh + (size_t)i * 2 * D * ld, (long)L * 2 * bsD, sc, mask, cmask, s, &h->prof,
-                            b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs, items));
-  FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
+  if (l.folded) {
+    LnStream ln;
+    ln.st[0] = b.ST.f(); ln.st[1] = b.ST.f() + (size_t)B * T * 32;
+    for (int i = 0; i < L; ++i)
+      FDX_HIP(h, run_declayer_ln(A, l.layers[i], B, T, D, H, ld, X, KVh + (size_t)i * 2 * D * ld, (long)L * 2 * bsD, sc, mask, cmask, s, &h->prof,
+                                 b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs, items, ln));
+    // output_projection.0 reads the stream through the last layer's norm3 like every other consumer
+    FDX_HIP(h, gemm_ln(A, l.out0, l.out0_R, B, T, D, X, bsD, ld, ln, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
+  } else {
+    for (int i = 0; i < L; ++i)
+      FDX_HIP(h, run_declayer(A, l.layers[i], B, T, D, H, ld, X, KVh + (size_t)i * 2 * D * ld, (long)L * 2 * bsD, sc, mask, cmask, s, &h->prof,
+                              b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs, items));
+    FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
+  }
   {
     EpiBias e = bias_epi(eps_out, o_bs, ldo, A + l.out2.b_off, M, ACT_NONE);
     e.mask = mask; e.mask_ld = T;

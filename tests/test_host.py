@@ -490,22 +490,58 @@ def test_tfdec_contract_and_packing(lib):
         return o
     for rows, cin, RB in ((H, M, 2), (D, H, 1), (H, D, 2), (D, H, 2), (H, E, 2), (D, H, 1)):   # in0 in2 emb1 emb3 cond0 cond2
         plan(rows, cin, RB)
-    sa_in, sa_out, ca_q, ca_kv = plan(3 * D, D, 2), plan(D, D, 1), plan(D, D, 1), plan(2 * D, D, 2)
+    def plan_layer():
+        nonlocal cur
+        y = dict(sa_in=plan(3 * D, D, 2), sa_out=plan(D, D, 1), ca_q=plan(D, D, 1), ca_kv=plan(2 * D, D, 2), ca_out=plan(D, D, 1),
+                 lin1=plan(H, D, 2), lin2=plan(D, H, 1))
+        for k in ("n1w", "n1b", "n2w", "n2b", "n3w", "n3b"):
+            y[k] = cur
+            cur += r64(D)
+        for k, rows in (("sa_in_R", 3 * D), ("ca_q_R", D), ("lin1_R", H)):     # row sums of the LayerNorm-folded weights (round 6)
+            y[k] = cur
+            cur += r64(rows)
+        return y
+    L0, L1 = plan_layer(), plan_layer()
+    out0 = plan(D, D, 1)
+    out0_R = cur
     g = torch.Generator().manual_seed(0)
     T, halo = 9, 32
-    xv = torch.randn(D, T, generator=g)
+    xv = torch.randn(D, T, generator=g) * 1.5 + 0.3
     Xp = np.zeros((D, halo + 64 + halo), np.float32)
     Xp[:, halo:halo + T] = xv.numpy()
 
     def run(o):
         acc = emulate_convgemm(arena[o["w"]:o["b"]], Xp, n_mtiles=o["mt"], RB=o["RB"], cin8=o["cin8"], taps=1, shift0=0, dshift=0, T=T)
         full = np.concatenate([acc[(mt, rb)] for mt in range(o["mt"]) for rb in range(o["RB"])])[:o["rows"]]
-        return full + arena[o["b"]:o["b"] + o["rows"]][:, None]
+        return full, arena[o["b"]:o["b"] + o["rows"]][:, None]
+
+    def run_ln(o, R_off):
+        """What convgemm_kernel<.., PRE_LNP, ..> computes: rstd (W' x - mean R) + b' on the PLAIN operand."""
+        acc, bias = run(o)
+        mean = Xp[:, halo:halo + T].mean(0, keepdims=True)
+        rstd = 1.0 / np.sqrt(Xp[:, halo:halo + T].var(0, keepdims=True) + 1e-5)
+        R = arena[R_off:R_off + o["rows"]][:, None]
+        return rstd * (acc - mean * R) + bias
+
+    def ln(x, w, b):
+        return torch.nn.functional.layer_norm(x.T, (D,), w, b, 1e-5).T
+    # layer 0: the self-attention in-projection reads a plain tensor; key / value projection of the memory is never folded
     W, b = sd["layers.0.multihead_attn.in_proj_weight"], sd["layers.0.multihead_attn.in_proj_bias"]
-    np.testing.assert_allclose(run(ca_q), (W[:D] @ xv + b[:D, None]).numpy(), rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(run(ca_kv), (W[D:] @ xv + b[D:, None]).numpy(), rtol=1e-4, atol=1e-5)
+    acc, bias = run(L0["ca_kv"])
+    np.testing.assert_allclose(acc + bias, (W[D:] @ xv + b[D:, None]).numpy(), rtol=1e-4, atol=1e-5)
     Ws, bs = sd["layers.0.self_attn.in_proj_weight"], sd["layers.0.self_attn.in_proj_bias"]
-    np.testing.assert_allclose(run(sa_in), (Ws @ xv + bs[:, None]).numpy(), rtol=1e-4, atol=1e-5)
+    acc, bias = run(L0["sa_in"])
+    np.testing.assert_allclose(acc + bias, (Ws @ xv + bs[:, None]).numpy(), rtol=1e-4, atol=1e-5)
+    # folded consumers: query projection behind norm1, linear1 behind norm2, the NEXT layer's in-projection and output_projection.0 behind norm3
+    for o, R_off, Wk, bk, nk in ((L0["ca_q"], L0["ca_q_R"], W[:D], b[:D], "layers.0.norm1"),
+                                 (L0["lin1"], L0["lin1_R"], sd["layers.0.linear1.weight"], sd["layers.0.linear1.bias"], "layers.0.norm2"),
+                                 (L1["sa_in"], L1["sa_in_R"], sd["layers.1.self_attn.in_proj_weight"], sd["layers.1.self_attn.in_proj_bias"], "layers.0.norm3"),
+                                 (out0, out0_R, sd["output_projection.0.weight"][:, :, 0], sd["output_projection.0.bias"], "layers.1.norm3")):
+        want = Wk @ ln(xv, sd[nk + ".weight"], sd[nk + ".bias"]) + bk[:, None]
+        np.testing.assert_allclose(run_ln(o, R_off), want.numpy(), rtol=2e-4, atol=2e-5, err_msg=nk)
+    # the norms' own parameters stay in the arena: the residual epilogue (EpiResLN) applies them to the old value
+    np.testing.assert_array_equal(arena[L0["n2w"]:L0["n2w"] + D], sd["layers.0.norm2.weight"].numpy())
+    np.testing.assert_array_equal(arena[L1["n3b"]:L1["n3b"] + D], sd["layers.1.norm3.bias"].numpy())
 
 
 # ------------------------------------------------------------------ opt-in bf16 storage mode: packing + blocked operand layout
