@@ -91,25 +91,36 @@ struct ConvArgsCold {
 //     workgroups of an XCD cover ALL its row tiles (their weights, 3.1 MB for the dilated conv, stay L2-resident by constant re-use)
 //     and a few column tiles at a time (the activations stream through once).  Batch 16 x 10 s, dilated conv + gate: 625 MB of HBM
 //     traffic per launch with row runs (every XCD streams all 28 MB of activations twice) against 119 MB algorithmic.
-//   The host only sets `xcd_rect` when n_mt is even and n_tiles_n % 4 == 0.
-__device__ __forceinline__ void conv_tile_of_block(int n_tiles_n, int n_mt, int rect, int bid, int& mt, int& nt) {
-  const int G = n_tiles_n * n_mt, xcd = bid & 7, slot = bid >> 3;     // G == gridDim.x, from preloaded arguments
+//   The host only sets `xcd_rect` when the row tiles divide by the row groups.  The column tiles need not divide (round 6: the exact-ragged
+//   serving micro-batches are 93-104 column tiles wide and ran row runs, 252 MB per launch for 53 MB of work): every column group is
+//   ceil(n / groups) tiles wide, the launch is PADDED to 8 equal rectangles (conv_rect_grid) and a workgroup whose tile falls off the end
+//   returns at once -- at most (groups - 1) x (row tiles per group) idle workgroups, 16 of 1504 at 93 x 16.  Returns false for those.
+__device__ __forceinline__ bool conv_tile_of_block(int n_tiles_n, int n_mt, int rect, int bid, int& mt, int& nt) {
+  const int G = n_tiles_n * n_mt, xcd = bid & 7, slot = bid >> 3;     // G == gridDim.x (row runs), from preloaded arguments
   if (rect) {
     const int rs = rect == 2 ? 2 : 1;                                  // log2(row groups)
-    const int MH = n_mt >> rs, NQ = n_tiles_n >> (3 - rs);
+    const int MH = n_mt >> rs, QC = 8 >> rs, NQ = (n_tiles_n + QC - 1) / QC;
     const int ntl = slot / MH;
     mt = (xcd & ((1 << rs) - 1)) * MH + (slot - ntl * MH);
     nt = (xcd >> rs) * NQ + ntl;
-  } else {
-    const int q8 = G >> 3, r8 = G & 7;
-    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    mt = L / n_tiles_n;
-    nt = L - mt * n_tiles_n;
+    return nt < n_tiles_n;
   }
+  const int q8 = G >> 3, r8 = G & 7;
+  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  mt = L / n_tiles_n;
+  nt = L - mt * n_tiles_n;
+  return true;
 }
-// Grids of at least this many workgroups take the rectangle map (FDX_XCD_RECT=<n>; 0: never).
+// workgroups to launch for a tile grid under map `rect` (0: exactly the tiles)
+inline int conv_rect_grid(int n_tiles_n, int n_mt, int rect) {
+  if (!rect) return n_tiles_n * n_mt;
+  const int rs = rect == 2 ? 2 : 1, QC = 8 >> rs;
+  return 8 * (n_mt >> rs) * ((n_tiles_n + QC - 1) / QC);
+}
+// Grids of at least this many workgroups take the rectangle map (FDX_XCD_RECT=<n>; 0: never).  1024 = four rounds of the chip: below that the
+// activations of a launch fit the L2s and row runs fetch the weights once chip-wide (the batch-1 headline: 256 workgroups).
 inline long xcd_rect_min_grid() {
-  static const long v = [] { const char* e = getenv("FDX_XCD_RECT"); return e ? atol(e) : 2048L; }();
+  static const long v = [] { const char* e = getenv("FDX_XCD_RECT"); return e ? atol(e) : 1024L; }();
   return v;
 }
 // Row split by measurement (batch 16 x 10 s, HBM bytes per launch from rocprofv3 PMC passes, profiles/r03_ddpm1000_pmc_traffic*.json;
@@ -121,7 +132,7 @@ inline int use_xcd_rect(int n_tiles_n, int n_mt, int taps) {
   static const int rows = [] { const char* e = getenv("FDX_XCD_RECT_ROWS"); return e ? atoi(e) : 0; }();
   const long g = (long)n_tiles_n * n_mt, m = xcd_rect_min_grid();
   if (m <= 0 || g < m) return 0;
-  const bool ok2 = (n_mt & 1) == 0 && (n_tiles_n & 3) == 0, ok4 = (n_mt & 3) == 0 && (n_tiles_n & 1) == 0;
+  const bool ok2 = (n_mt & 1) == 0 && n_tiles_n >= 4, ok4 = (n_mt & 3) == 0 && n_tiles_n >= 2;
   if (rows == 2) return ok2 ? 1 : 0;
   if (rows == 4) return ok4 ? 2 : 0;
   if (taps > 1) return ok4 ? 2 : (ok2 ? 1 : 0);
@@ -706,7 +717,7 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
   // ---- XCD-aware logical tile id (block b runs on XCD b % 8): row runs, or -- when the activation operand outweighs the weights (round 5:
   // ConvNext pwconv2 at batch 1 fetched its 7 MB of activations into all eight L2s, 64.8 MB per launch) -- 4 row quarters x 2 column halves
   int mtg, nt;                                // packed m-tile, column tile
-  conv_tile_of_block(a.n_tiles_n, a.n_mtiles, a.xcd_rect, blockIdx.x, mtg, nt);
+  if (!conv_tile_of_block(a.n_tiles_n, a.n_mtiles, a.xcd_rect, blockIdx.x, mtg, nt)) return;   // (padding of an uneven rectangle map)
   const int item = nt / a.tiles_per_item;
   const int tile_in_item = nt - item * a.tiles_per_item;
   constexpr int COLS = SPLITK ? 64 : 256;
@@ -1174,7 +1185,7 @@ inline hipError_t launch_convgemm(const ConvGeom& g, const float4* Wp, const flo
   a.xcd_rect = SPLITK ? splitk_xcd_rect(a.n_tiles_n, a.n_mtiles, 32 * RB * a.n_mtiles, (long)g.B * g.T) : 0;
   a.in_slope = in_slope;
   a.col_stats = col_stats; a.ln_R = ln_R; a.n_groups = n_groups; a.ln_eps = ln_eps;
-  const int grid = a.n_tiles_n * a.n_mtiles;
+  const int grid = conv_rect_grid(a.n_tiles_n, a.n_mtiles, a.xcd_rect);
   if (grid <= 0) return hipSuccess;
 #ifdef FDX_KTRACE
   a.trace = nullptr;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
   FDX_STAMP_RT0();
 
   int mt, nt;
-  conv_tile_of_block(a.n_tiles_n, a.n_mtiles, a.xcd_rect, blockIdx.x, mt, nt);
+  if (!conv_tile_of_block(a.n_tiles_n, a.n_mtiles, a.xcd_rect, blockIdx.x, mt, nt)) return;   // (padding of an uneven rectangle map)
   const int item = nt / a.tiles_per_item;
   const int t0 = (nt - item * a.tiles_per_item) * COLS;
   const int tc = t0 + NM * lj;                                        // this lane's first column
@@ -359,7 +359,7 @@ inline hipError_t launch_convgemm16s(const ConvGeom& g, const void* Wp, const fl
   a.xcd_rect = use_xcd_rect(a.n_tiles_n, a.n_mtiles, a.taps);
   a.in_slope = 1.f;
   a.col_stats = nullptr; a.ln_R = nullptr; a.n_groups = 0; a.ln_eps = 0.f;
-  const int grid = a.n_tiles_n * a.n_mtiles;
+  const int grid = conv_rect_grid(a.n_tiles_n, a.n_mtiles, a.xcd_rect);
   if (grid <= 0) return hipSuccess;
 #ifdef FDX_KTRACE
   a.trace = nullptr;

@@ -611,30 +611,53 @@ def test_wavenet_bf16_packing_and_blocked_layout_match_kernel_index_math(lib):
 
 
 def test_xcd_rect_tile_map_is_a_bijection():
-    """csrc/convgemm.hip.h `conv_tile_of_block` (mirrored here): block b runs on XCD b % 8; with a rectangle map XCD x owns one of
-    2 row halves x 4 column quarters (mode 1) or 4 row quarters x 2 column halves (mode 2), walked row-fastest.  Every logical tile
-    exactly once, every XCD inside its rectangle, and the tiles an XCD has in flight at once (32 consecutive slots) cover all of its
-    row tiles."""
+    """csrc/convgemm.hip.h `conv_tile_of_block` / `conv_rect_grid` (mirrored here, and the mirror is read against the source): block b runs
+    on XCD b % 8; with a rectangle map XCD x owns one of 2 row halves x 4 column quarters (mode 1) or 4 row quarters x 2 column halves
+    (mode 2), walked row-fastest.  Every logical tile exactly once, every XCD inside its rectangle, and the tiles an XCD has in flight at
+    once (32 consecutive slots) cover all of its row tiles.  Round 6: the column tiles need not divide by the column groups -- the launch
+    is padded to 8 equal rectangles and the workgroups past the end return (the serving micro-batches' 93 x 16 grids)."""
+    src = open(f"{ROOT}/fish_diffusion_amd/csrc/convgemm.hip.h").read()
+    for line in ("const int MH = n_mt >> rs, QC = 8 >> rs, NQ = (n_tiles_n + QC - 1) / QC;", "nt = (xcd >> rs) * NQ + ntl;", "return nt < n_tiles_n;",
+                 "return 8 * (n_mt >> rs) * ((n_tiles_n + QC - 1) / QC);"):
+        assert line in src, line
+
+    def rect_grid(n_tiles_n, n_mt, rect):
+        if not rect:
+            return n_tiles_n * n_mt
+        rs = 2 if rect == 2 else 1
+        QC = 8 >> rs
+        return 8 * (n_mt >> rs) * ((n_tiles_n + QC - 1) // QC)
+
     def tile_of_block(n_tiles_n, n_mt, rect, bid):
         G, xcd, slot = n_tiles_n * n_mt, bid & 7, bid >> 3
         if rect:
             rs = 2 if rect == 2 else 1
-            MH, NQ = n_mt >> rs, n_tiles_n >> (3 - rs)
+            MH, QC = n_mt >> rs, 8 >> rs
+            NQ = (n_tiles_n + QC - 1) // QC
             ntl = slot // MH
-            return (xcd & ((1 << rs) - 1)) * MH + (slot - ntl * MH), (xcd >> rs) * NQ + ntl
+            m, n = (xcd & ((1 << rs) - 1)) * MH + (slot - ntl * MH), (xcd >> rs) * NQ + ntl
+            return (m, n) if n < n_tiles_n else None
         q8, r8 = G >> 3, G & 7
         L = (xcd * (q8 + 1) if xcd < r8 else r8 * (q8 + 1) + (xcd - r8) * q8) + slot
         return L // n_tiles_n, L % n_tiles_n
     for rect in (1, 2):
         rs = rect
-        for n_tiles_n, n_mt in ((224, 16), (128, 32), (4, 4), (12, 16)):
-            G = n_tiles_n * n_mt
-            seen = {tile_of_block(n_tiles_n, n_mt, rect, b) for b in range(G)}
-            assert seen == {(m, n) for m in range(n_mt) for n in range(n_tiles_n)}
-            for b in range(G):
-                m, n = tile_of_block(n_tiles_n, n_mt, rect, b)
+        QC = 8 >> rs
+        for n_tiles_n, n_mt in ((224, 16), (128, 32), (4, 4), (12, 16), (93, 16), (104, 16), (7, 4), (5, 8), (2, 4), (33, 12)):
+            if n_tiles_n < QC:
+                continue
+            G = rect_grid(n_tiles_n, n_mt, rect)
+            NQ = (n_tiles_n + QC - 1) // QC
+            tiles = [tile_of_block(n_tiles_n, n_mt, rect, b) for b in range(G)]
+            live = [t for t in tiles if t is not None]
+            assert len(live) == len(set(live)) == n_tiles_n * n_mt and set(live) == {(m, n) for m in range(n_mt) for n in range(n_tiles_n)}
+            assert G - len(live) == (QC * NQ - n_tiles_n) * n_mt        # the padding: whole column tiles of the last group(s)
+            for b, t in enumerate(tiles):
+                if t is None:
+                    continue
+                m, n = t
                 x = b & 7
-                assert m // (n_mt >> rs) == (x & ((1 << rs) - 1)) and n // (n_tiles_n >> (3 - rs)) == (x >> rs)
+                assert m // (n_mt >> rs) == (x & ((1 << rs) - 1)) and n // NQ == (x >> rs)
             if G // 8 >= 32 and (n_mt >> rs) <= 32:
                 first = {tile_of_block(n_tiles_n, n_mt, rect, 8 * s)[0] for s in range(32)}
                 assert first == set(range(n_mt >> rs))
