@@ -33,7 +33,8 @@ namespace {
 struct CnLayout {
   PackedW in_proj, emb1, emb3, cond0, cond2, dsp, cproj, out0, out2;   // dsp / cproj: all layers concatenated along rows
   std::vector<PackedW> pw1, pw2, pw2w;   // pw2: 32-row tiles (small grids), pw2w: the same weights in 64-row tiles (large grids)
-  std::vector<size_t> dw_w, dw_b, gamma, lnR;   // (norm.weight / norm.bias live folded inside pw1; lnR: [round_up(H, 64)][16] group row sums)
+  std::vector<size_t> dw_w, dw_b, gamma, lnR, lnRs;   // lnRs: [round_up(H, 64)] whole-row sums (PRE_LNP)
+  //   // (norm.weight / norm.bias live folded inside pw1; lnR: [round_up(H, 64)][16] group row sums)
   std::vector<int> dil;
   // cross-attention variant: one entry per CrossAttentionBlock, in front of ConvNeXt block `at_layer`
   struct Cross { TdLayer dec; size_t scale_q, scale_k; int at_layer; };
@@ -44,6 +45,14 @@ struct CnLayout {
 constexpr int kCnPositions = 4096;   // CrossAttentionBlock.get_embedding(num_embeddings=4096), convnext.py:114
 constexpr int kCrossTensors = 3 + 18 + 2;
 
+// pwconv1's LayerNorm fold and tile height (round 6, tools/cnbench.py at T = 861, us per denoiser call, batch 1 | batch 8):
+//   round 5: depthwise-conv output stored group-centred, PRE_LN's 16-term group correction, 64-row tiles      1043 | 6119
+//   stored as it is, PRE_LNP (rstd (acc - mean rowsum): one multiply-subtract per output), 64-row tiles        1032
+//   PRE_LN with 32-row tiles (twice the workgroups, each paying the correction)                                 1089
+//   PRE_LNP with 32-row tiles (896 workgroups, four co-resident per CU instead of 448 at 1.75 per CU)            1001 | 5783   <- default
+// A/B switches (decide the arena layout / the operand form: read once per process): FDX_CN_PW1_RB=2 (64-row tiles), FDX_CN_LNP=0 (centred form).
+int cn_pw1_rb() { static const int v = [] { const char* e = getenv("FDX_CN_PW1_RB"); const int k = e ? atoi(e) : 0; return k == 2 ? 2 : 1; }(); return v; }
+bool cn_lnp() { static const bool v = [] { const char* e = getenv("FDX_CN_LNP"); return !e || atoi(e) != 0; }(); return v; }
 int cn_n_cross(const fdx_convnext_desc& d) { return d.cross_attention > 0 ? (d.num_layers + d.cross_attention - 1) / d.cross_attention : 0; }
 
 int cn_validate(const fdx_convnext_desc* d) {
@@ -71,14 +80,15 @@ void cn_layout(const fdx_convnext_desc& d, CnLayout& l) {
   const int NC = cn_n_cross(d);
   l.dsp = plan64(cur, (L + NC) * D, D);      // rows [L*D, (L+NC)*D): the cross blocks' own diffusion_step_projection
   l.cproj = plan64(cur, L * D, D);
-  l.pw1.clear(); l.pw2.clear(); l.pw2w.clear(); l.dw_w.clear(); l.dw_b.clear(); l.gamma.clear(); l.lnR.clear(); l.dil.clear();
+  l.pw1.clear(); l.pw2.clear(); l.pw2w.clear(); l.dw_w.clear(); l.dw_b.clear(); l.gamma.clear(); l.lnR.clear(); l.lnRs.clear(); l.dil.clear();
   for (int i = 0; i < L; ++i) {
-    l.pw1.push_back(plan64(cur, H, D));
+    l.pw1.push_back(cn_pw1_rb() == 1 ? plan32(cur, H, D) : plan64(cur, H, D));
     l.pw2.push_back(plan32(cur, D, H));
     l.pw2w.push_back(plan64(cur, D, H));
     l.dw_w.push_back(cur); cur += round_up(D * 7, 64);
     for (auto* v : {&l.dw_b, &l.gamma}) { v->push_back(cur); cur += round_up(D, 64); }
     l.lnR.push_back(cur); cur += (size_t)round_up(H, 64) * 16;
+    l.lnRs.push_back(cur); cur += (size_t)round_up(H, 64);
     l.dil.push_back(1 << (i % d.dilation_cycle));
   }
   l.cross.clear();
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256) void k_dwconv_stats(const float* __restrict__ 
                                                       const float* __restrict__ CP, long cp_bs,            // layer slab [D][ld]
                                                       const float* __restrict__ SB, int sb_ld, int sb_bs,  // [D][sb_ld], column = step
                                                       const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-                                                      const uint8_t* __restrict__ mask, float* __restrict__ U, float* __restrict__ ST) {
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ U, float* __restrict__ ST, int centre) {
   __shared__ float v[kCnCh][kCnMaxW];
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -221,8 +231,9 @@ __global__ __launch_bounds__(256) void k_dwconv_stats(const float* __restrict__ 
     st[16] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
   }
   float* ub = U + b * bs + t;
+  const float sub = centre ? mean_g : 0.f;       // group-centred (PRE_LN) or as it is (PRE_LNP)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ub[(long)(g * kCnCh + wv * 8 + j) * ld] = u[j] - mean_g;   // group-centred (see PRE_LN)
+  for (int j = 0; j < 8; ++j) ub[(long)(g * kCnCh + wv * 8 + j) * ld] = u[j] - sub;
 }
 
 struct CnBufs {
@@ -317,6 +328,11 @@ extern "C" int fdx_convnext_pack(const fdx_convnext_desc* d, const float* const*
           for (int c = g * kCnCh; c < (g + 1) * kCnCh; ++c) acc += (double)Wf[(size_t)r * D + c];
           A[l.lnR[i] + (size_t)r * 16 + g] = (float)acc;
         }
+      for (int r = 0; r < H; ++r) {
+        double acc = 0;
+        for (int c = 0; c < D; ++c) acc += (double)Wf[(size_t)r * D + c];
+        A[l.lnRs[i] + r] = (float)acc;
+      }
     }
     pack_lin(A, l.pw2[i], w[k], D, H, w[k + 1]);
     pack_lin(A, l.pw2w[i], w[k], D, H, w[k + 1]); k += 2;
@@ -503,17 +519,23 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
     }
     const dim3 grid((T + 63) / 64, D / kCnCh, B);
     hipLaunchKernelGGL(k_dwconv_stats, grid, dim3(256), 0, s, X, bsD, ld, T, l.dil[i], D, CP ? CP + (size_t)i * D * ld : nullptr, (long)L * D * ld,
-                       SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, A + l.dw_w[i], A + l.dw_b[i], mask, N, b.ST.f());
+                       SB + (size_t)i * D * b.ldn, b.ldn, sb_bs, A + l.dw_w[i], A + l.dw_b[i], mask, N, b.ST.f(), cn_lnp() ? 0 : 1);
     {  // pwconv1 over LayerNorm(u): centring + rstd inside the GEMM, affine folded into the packed weights
       const PackedW& p = l.pw1[i];
       ConvGeom gg{B, T, p.cin8, 1, 0, 0, p.n_mtiles};
       hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: the denoiser's dominant kernel
-      h->prof.note(PROF_CN_PWCONV1, "convgemm_kernel<2, true, PRE_LN, EpiBias> (v_mfma_f32_32x32x2_f32; 64 x 64 split-K workgroup tile, LayerNorm folded in, GELU epilogue; %ld workgroups)",
-                   (long)B * ((T + 63) / 64) * p.n_mtiles);
+      h->prof.note(PROF_CN_PWCONV1, "convgemm_kernel<%d, true, %s, EpiBias> (v_mfma_f32_32x32x2_f32; %d x 64 split-K workgroup tile, LayerNorm folded in, GELU epilogue; %ld workgroups)",
+                   p.RB, cn_lnp() ? "PRE_LNP" : "PRE_LN", 32 * p.RB, (long)B * ((T + 63) / 64) * p.n_mtiles);
       h->prof.take(PROF_CN_PWCONV1, 2.0 * (double)H * D * (double)B * T, ev0, ev1);
-      FDX_HIP(h, (launch_convgemm<2, true, PRE_LN, EpiBias>(gg, reinterpret_cast<const float4*>(A + p.w_off), N, bsD, ld, 1.f,
-                                                            bias_epi(G, bsH, ld, A + p.b_off, H, ACT_GELU), s, ev0, ev1,
-                                                            b.ST.f(), A + l.lnR[i], D / kCnCh, 1e-6f)));
+      const float4* Wp = reinterpret_cast<const float4*>(A + p.w_off);
+      const EpiBias eb = bias_epi(G, bsH, ld, A + p.b_off, H, ACT_GELU);
+      if (cn_lnp()) {
+        if (p.RB == 1) FDX_HIP(h, (launch_convgemm<1, true, PRE_LNP, EpiBias>(gg, Wp, N, bsD, ld, 1.f, eb, s, ev0, ev1, b.ST.f(), A + l.lnRs[i], D / kCnCh, 1e-6f)));
+        else FDX_HIP(h, (launch_convgemm<2, true, PRE_LNP, EpiBias>(gg, Wp, N, bsD, ld, 1.f, eb, s, ev0, ev1, b.ST.f(), A + l.lnRs[i], D / kCnCh, 1e-6f)));
+      } else {
+        if (p.RB == 1) FDX_HIP(h, (launch_convgemm<1, true, PRE_LN, EpiBias>(gg, Wp, N, bsD, ld, 1.f, eb, s, ev0, ev1, b.ST.f(), A + l.lnR[i], D / kCnCh, 1e-6f)));
+        else FDX_HIP(h, (launch_convgemm<2, true, PRE_LN, EpiBias>(gg, Wp, N, bsD, ld, 1.f, eb, s, ev0, ev1, b.ST.f(), A + l.lnR[i], D / kCnCh, 1e-6f)));
+      }
     }
     EpiScaleRes e{};
     e.X = X; e.bs = bsD; e.ld = ld; e.bias = A + l.pw2[i].b_off; e.gamma = A + l.gamma[i]; e.M = D; e.mask = mask; e.mask_ld = T;

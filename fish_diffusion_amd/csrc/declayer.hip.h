@@ -25,13 +25,25 @@ struct TdLayer {
   size_t sa_in_R = 0, ca_q_R = 0, lin1_R = 0;
 };
 
+// Tile height of the self-attention in-projection and of linear1: 32-row tiles (RB = 1).  Round 6, tools/tdbench.py at T = 861: with 64-row
+// tiles the two GEMMs are 336 / 448 workgroups -- 1.3 / 1.75 per CU, so the CUs that hold two set the time; 32-row tiles (672 / 896 workgroups,
+// four co-resident per CU) balance: 1903 -> 1836 -> 1791 us per denoiser call at batch 1, 9540 -> 9130 at batch 8.
+// FDX_TD_SAIN_RB / FDX_TD_LIN1_RB = 2: the 64-row tiles of rounds 4-5 (A/B; decides the arena layout, read once per process).
+inline int declayer_sa_in_rb() {
+  static const int v = [] { const char* e = getenv("FDX_TD_SAIN_RB"); const int k = e ? atoi(e) : 0; return k == 2 ? 2 : 1; }();
+  return v;
+}
+inline int declayer_lin1_rb() {
+  static const int v = [] { const char* e = getenv("FDX_TD_LIN1_RB"); const int k = e ? atoi(e) : 0; return k == 2 ? 2 : 1; }();
+  return v;
+}
 inline void plan_declayer(size_t& cur, TdLayer& y, int D, int H, bool folded = false) {
-  y.sa_in = plan64(cur, 3 * D, D);
+  y.sa_in = declayer_sa_in_rb() == 1 ? plan32(cur, 3 * D, D) : plan64(cur, 3 * D, D);
   y.sa_out = plan32(cur, D, D);
   y.ca_q = plan32(cur, D, D);
   y.ca_kv = plan64(cur, 2 * D, D);
   y.ca_out = plan32(cur, D, D);
-  y.lin1 = plan64(cur, H, D);
+  y.lin1 = declayer_lin1_rb() == 1 ? plan32(cur, H, D) : plan64(cur, H, D);
   y.lin2 = plan32(cur, D, H);
   for (size_t* p : {&y.n1w, &y.n1b, &y.n2w, &y.n2b, &y.n3w, &y.n3b}) { *p = cur; cur += round_up(D, 64); }
   y.folded = folded;

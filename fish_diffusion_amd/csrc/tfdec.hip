@@ -60,7 +60,7 @@ void td_layout(const fdx_tfdec_desc& d, TdLayout& l) {
   l.scale_q = cur; cur += 64;
   l.scale_k = cur; cur += 64;
   l.pos = cur; cur += (size_t)round_up(d.n_positions * D, 64);
-  l.in0 = plan64(cur, H, d.mel_channels);
+  l.in0 = plan32(cur, H, d.mel_channels);      // (32-row tiles: see plan_declayer)
   l.in2 = plan32(cur, D, H);
   l.emb1 = plan64(cur, H, D);
   l.emb3 = plan64(cur, D, H);

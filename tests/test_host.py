@@ -345,13 +345,14 @@ def _cn_offsets(D, Hf, L, M, E):
                             ("cproj", L * D, D)):
         out[name], cur = plan(cur, rows, cin, RB=1 if name == "in_proj" else 2)
     for i in range(L):
-        out[f"pw1_{i}"], cur = plan(cur, H, D)
+        out[f"pw1_{i}"], cur = plan(cur, H, D, RB=1)        # 32-row tiles since round 6
         out[f"pw2_{i}"], cur = plan(cur, D, H, RB=1)
         out[f"pw2w_{i}"], cur = plan(cur, D, H, RB=2)
         out[f"dw_w{i}"] = cur; cur += r64(D * 7)
         for nm in ("dw_b", "gamma"):
             out[f"{nm}{i}"] = cur; cur += r64(D)
         out[f"lnR{i}"] = cur; cur += r64(H) * 16
+        out[f"lnRs{i}"] = cur; cur += r64(H)               # whole-row sums (PRE_LNP)
     out["out0"], cur = plan(cur, D, D, RB=1)
     out["out2"], cur = plan(cur, M, D, RB=1)
     out["total"] = cur
@@ -418,7 +419,12 @@ def test_convnext_arena_forward_emulation_matches_oracle(lib):
         np.testing.assert_allclose(var2, var[0], rtol=1e-5)
         R = arena[off[f"lnR{i}"]:off[f"lnR{i}"] + H * 16].reshape(H, 16)[:, :D // 32]
         acc = gemm(f"pw1_{i}", (ug - mean_g[:, None]).reshape(D, T).astype(np.float32), bias=False) + R @ delta
-        hid = gelu((acc / np.sqrt(var2 + 1e-6) + arena[o1["b"]:o1["b"] + H][:, None]).astype(np.float32))
+        # round 6 default (PRE_LNP): the operand stays as it is, rstd (W' u - mean rowsum); both forms from the same arena agree
+        Rs = arena[off[f"lnRs{i}"]:off[f"lnRs{i}"] + H][:, None]
+        np.testing.assert_allclose(Rs[:, 0], R.sum(1), rtol=1e-5, atol=1e-6)
+        acc_p = gemm(f"pw1_{i}", u.astype(np.float32), bias=False) - mu * Rs
+        np.testing.assert_allclose(acc_p, acc, rtol=1e-4, atol=1e-4)
+        hid = gelu((acc_p / np.sqrt(var2 + 1e-6) + arena[o1["b"]:o1["b"] + H][:, None]).astype(np.float32))
         y = gemm(f"pw2_{i}", hid)                                             # includes the bias
         np.testing.assert_allclose(gemm(f"pw2w_{i}", hid), y, rtol=1e-5, atol=1e-6)   # the 64-row-tile packing of the same weights
         X = ((X + arena[off[f"gamma{i}"]:off[f"gamma{i}"] + D][:, None] * y) * keep).astype(np.float32)
@@ -488,12 +494,12 @@ def test_tfdec_contract_and_packing(lib):
         o = dict(w=cur, b=cur + w, mt=mt, cin8=(cin + 7) // 8, RB=RB, rows=rows)
         cur += w + r64(rows)
         return o
-    for rows, cin, RB in ((H, M, 2), (D, H, 1), (H, D, 2), (D, H, 2), (H, E, 2), (D, H, 1)):   # in0 in2 emb1 emb3 cond0 cond2
+    for rows, cin, RB in ((H, M, 1), (D, H, 1), (H, D, 2), (D, H, 2), (H, E, 2), (D, H, 1)):   # in0 in2 emb1 emb3 cond0 cond2
         plan(rows, cin, RB)
     def plan_layer():
         nonlocal cur
-        y = dict(sa_in=plan(3 * D, D, 2), sa_out=plan(D, D, 1), ca_q=plan(D, D, 1), ca_kv=plan(2 * D, D, 2), ca_out=plan(D, D, 1),
-                 lin1=plan(H, D, 2), lin2=plan(D, H, 1))
+        y = dict(sa_in=plan(3 * D, D, 1), sa_out=plan(D, D, 1), ca_q=plan(D, D, 1), ca_kv=plan(2 * D, D, 2), ca_out=plan(D, D, 1),
+                 lin1=plan(H, D, 1), lin2=plan(D, H, 1))       # sa_in / lin1: 32-row tiles since round 6
         for k in ("n1w", "n1b", "n2w", "n2b", "n3w", "n3b"):
             y[k] = cur
             cur += r64(D)
