@@ -509,131 +509,3 @@ def test_exact_ragged_batches_equal_batch_one_runs_bit_for_bit(dev, net):
         diff(feats, lengths=lens, x_masks=torch.zeros(B, T, dtype=torch.bool, device=dev))
     with pytest.raises(ValueError):
         diff(feats, lengths=[T + 1] * B)
-
-
-# ------------------------------------------------------------------------------------------------ bf16 storage mode: the error table
-def test_bf16_storage_error_table_full_size_net(dev):
-    """BASELINE configs[4]'s opt-in bf16 storage mode on the FULL-SIZE net (diff_svc_v2: C = 512, 20 layers; 10 s): the mel's distance
-    from the fp32 path after 100 UniPC steps and after 1000 DDPM steps, written as an artefact (gpurun_out/bf16_error_table.json ->
-    profiles/) instead of prose.  The mode is not parity-grade and says so: what is asserted is the regime -- 100-step UniPC inside the
-    1e-3 mel bar on this net, 1000-step DDPM bf16-class (a few 1e-3, rms an order below) -- so that a rounding-policy regression
-    (e.g. the residual stream dropping to bf16) fails loudly."""
-    sd = wavenet_sd(WN_FULL, 1234)
-    diff = _diffusion(WN_FULL, sd, dev)
-    g = torch.Generator().manual_seed(2024)
-    T = 861
-    feats, x0 = torch.randn(1, T, 256, generator=g).to(dev), torch.randn(1, 128, T, generator=g).to(dev)
-    noise = torch.randn(1000, 1, 128, T, generator=g).to(dev)
-    rows = []
-    for name, kw in (("unipc_100", dict(sampler_interval=10, noise_predictor="unipc")),
-                     ("ddpm_1000", dict(sampler_interval=1, noise_predictor="naive", step_noise=noise))):
-        diff.denoise_fn.storage = "fp32"
-        a = diff(feats, x_init=x0, **kw).double()
-        diff.denoise_fn.storage = "bf16"
-        b = diff(feats, x_init=x0, **kw).double()
-        diff.denoise_fn.storage = "fp32"
-        d = (a - b).abs()
-        rows.append({"run": name, "max_abs": float(d.max()), "max_rel_of_peak": float(d.max() / a.abs().max()), "rms_rel_of_peak": float(d.pow(2).mean().sqrt() / a.abs().max()),
-                     "mel_peak": float(a.abs().max())})
-        print(rows[-1])
-    out = {"net": "diff_svc_v2 WaveNet C=512 x 20 layers, seeded weights (seed 1234)", "frames": T, "mode": "bf16 storage / fp32 accumulate (opt-in)",
-           "reference": "the same library's fp32 path, same inputs and noise", "rows": rows}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "bf16_error_table.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    assert rows[0]["max_rel_of_peak"] < 1e-3                      # 100-step UniPC: inside the mel bar on this net (no margin claimed)
-    assert rows[1]["max_rel_of_peak"] < 2e-2 and rows[1]["rms_rel_of_peak"] < 2e-3   # 1000-step DDPM: bf16-class, as SURVEY F4 predicted
-
-
-# ------------------------------------------------------------------------------------------------ bf16 mode: LDS-tiled kernels
-# The forced-mode sweeps below re-run parity subsets in a subprocess (the library reads its tuning switches once), at BOTH tile widths of the
-# LDS-tiled kernels (128 and 256 columns) since round 4 -- the whole `-m gpu` run stays at about half of the driver's 1200 s limit.
-# FDX_TEST_FAST=1 drops the 128-column width again.
-FAST = os.environ.get("FDX_TEST_FAST", "") not in ("", "0")
-WIDTHS = [pytest.param("2", marks=pytest.mark.skipif(FAST, reason="128-column tile width skipped: FDX_TEST_FAST=1")), "4"]
-SWEEP_FILES = [os.path.join(ROOT, "tests", f) for f in ("test_gpu_parity.py", "test_gpu_round2.py", "test_gpu_round3.py")]
-
-
-@pytest.mark.parametrize("wn", WIDTHS)
-def test_bf16_lds_tiled_kernels_hold_the_same_bounds(dev, wn):
-    """csrc/bf16lds.hip.h (128 x 128 and 128 x 256 tiles, operands brought into LDS by DMA, the conv's three taps reading one staged
-    window) is what the opt-in bf16 mode runs at large column counts (BASELINE configs[4]).  FDX_BF16_LDS=1 forces it for every
-    geometry and FDX_BF16_WN the tile width: the bf16 tests of tests/test_gpu_parity.py -- agreement with the CPU model of the rounding
-    policy, bounded by that model's own rounding cost; the sampler runs; bit-identical fp32 results after switching back -- must hold
-    unchanged (small / full net, ragged T, masks, batch 2)."""
-    env = dict(os.environ, FDX_BF16_LDS="1", FDX_BF16_WN=wn)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-s", "-k", "bf16"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    print(r.stdout[-3000:])
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-# ------------------------------------------------------------------------------------------------ fp16-split mode ("past the fp32 roof")
-FP16X3_SUBSET = ("(wavenet or sampler or config4 or baseline_configs or chained or exact_ragged or end_to_end or segment_loop or shallow or chunked "
-                 "or ragged_batch or pipeline or svc_inference or long_utterance or q_sample or ddpm1000 or ragged_ddpm) "
-                 "and not bf16 and not fp16 and not convnext and not tfdec and not transformer")
-
-
-@pytest.mark.parametrize("wn", WIDTHS)
-def test_fp16_split_mode_holds_the_fp32_parity_bars(dev, wn):
-    """`net.storage = "fp16x3"` (csrc/bf16lds.hip.h, F16S): every operand of the two residual-block GEMMs as an fp16 pair hi + lo, each
-    product block as hi.lo + lo.hi + hi.hi on v_mfma_f32_32x32x16_f16, fp32 accumulate.  The claim is "fp32-class", so the bar is the
-    fp32 path's own: the WaveNet / sampler / chained-parity / exact-ragged tests of this suite -- goldens from the real reference, 2e-5
-    per call, 1e-3 rel on the sampled mel, 1e-4 abs on the chained waveform, bit-identical ragged batches -- re-run unchanged with the
-    mode switched on for every WaveNet (FDX_WAVENET_STORAGE) and forced for every geometry (FDX_BF16_LDS=1), at both tile widths."""
-    env = dict(os.environ, FDX_WAVENET_STORAGE="fp16x3", FDX_BF16_LDS="1", FDX_BF16_WN=wn)
-    r = subprocess.run([sys.executable, "-m", "pytest", *SWEEP_FILES, "-m", "gpu", "-q", "-x", "-k", FP16X3_SUBSET], env=env, capture_output=True,
-                       text=True, timeout=1500, cwd=ROOT)
-    print(r.stdout[-3000:])
-    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
-
-
-def test_fp16_split_error_table_full_size_net(dev):
-    """Full-size net, 6 x 10 s (enough LDS tiles for the mode's own threshold): the fp16-split mode against the library's fp32 path on the
-    same inputs -- one denoiser call, 100-step UniPC, 100 DDPM steps -- written as an artefact (gpurun_out/fp16x3_error_table.json); the
-    fp32 path's own distance to the reference (1.5e-6 rel on the 100-step mel) is the yardstick."""
-    sd = wavenet_sd(WN_FULL, 1234)
-    B, T = 6, 861
-    g = torch.Generator().manual_seed(4)
-    feats, x0 = torch.randn(B, T, 256, generator=g).to(dev), torch.randn(B, 128, T, generator=g).to(dev)
-    from fish_diffusion_amd import DENOISERS, GaussianDiffusion
-    diff = GaussianDiffusion(dict(type="WaveNetDenoiser", **WN_FULL), spec_min=[-5], spec_max=[0])
-    diff.denoise_fn.load_state_dict(sd, strict=True)
-    diff = diff.to(dev).eval()
-    net = diff.denoise_fn
-    rows = []
-    t = torch.tensor([500.0], device=dev)
-    cond = feats.transpose(1, 2).contiguous()
-    outs = {}
-    for mode in ("fp32", "fp16x3"):
-        net.storage = mode
-        outs[mode] = dict(call=net(x0, t, cond).clone(), unipc=diff(feats, sampler_interval=10, x_init=x0).clone(),
-                          ddpm=diff(feats, sampler_interval=10, noise_predictor="naive", x_init=x0,
-                                    step_noise=torch.randn(100, B, 128, T, generator=torch.Generator().manual_seed(9)).to(dev)).clone())
-    net.storage = "fp32"
-    for run in ("call", "unipc", "ddpm"):
-        a, b = outs["fp32"][run], outs["fp16x3"][run]
-        peak = float(a.abs().max())
-        rows.append(dict(run={"call": "one denoiser call (t = 500)", "unipc": "unipc_100", "ddpm": "ddpm_100_of_1000"}[run], max_abs=float((a - b).abs().max()),
-                         max_rel_of_peak=float((a - b).abs().max()) / peak, rms_rel_of_peak=float((a - b).pow(2).mean().sqrt()) / peak, peak=peak))
-        print(rows[-1])
-    out = dict(net="diff_svc_v2 WaveNet C=512 x 20 layers, seeded weights (seed 1234)", batch=B, frames=T,
-               mode="fp16 hi+lo split operands, 3 MFMAs per product block, fp32 accumulate (opt-in)", reference="the same library's fp32 path, same inputs and noise",
-               rows=rows)
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "fp16x3_error_table.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    assert rows[0]["max_rel_of_peak"] < 2e-5 and rows[1]["max_rel_of_peak"] < 1e-4 and rows[2]["max_rel_of_peak"] < 1e-4
-
-
-def test_fp16_split_small_tile_kernel_holds_the_fp32_parity_bars(dev):
-    """csrc/f16s64.hip.h: the fp16-split mode on 64 x 64 tiles (v_mfma_f32_16x16x32_f16) -- what `storage="fp16x3"` runs below the
-    wide-tile threshold, i.e. on the HEADLINE geometry (batch 1 x 10 s: 224 workgroups; 27 vs 37 ms per 50 denoiser calls against the
-    fp32 kernels).  The same broad subset the wide tiles are held to -- reference goldens at 2e-5 per call, 1e-3 on the sampled mel
-    (incl. the full-size 1000-step DDPM fixtures), 1e-4-class chained waveforms, exact-ragged batches -- with this kernel forced for
-    every geometry (FDX_F16S_SMALL=2: from two tiles; FDX_BF16_LDS huge: never the 128-wide tiles)."""
-    env = dict(os.environ, FDX_WAVENET_STORAGE="fp16x3", FDX_F16S_SMALL="2", FDX_BF16_LDS="1000000000")
-    r = subprocess.run([sys.executable, "-m", "pytest", *SWEEP_FILES, "-m", "gpu", "-q", "-x", "-k", FP16X3_SUBSET], env=env, capture_output=True,
-                       text=True, timeout=1500, cwd=ROOT)
-    print(r.stdout[-3000:])
-    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
