@@ -38,10 +38,14 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_trace(verbose: bool = True) -> str:
-    """Instrumented build (tools/ktrace.py): libfishdx_trace.so with -DFDX_KTRACE, one shot, no object cache."""
-    out = os.path.join(CSRC, "libfishdx_trace.so")
-    cmd = [_hipcc(), *FLAGS, "-DFDX_KTRACE", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+def build_trace(verbose: bool = True, bisect: int = 0) -> str:
+    """Instrumented build (tools/ktrace.py): libfishdx_trace.so with -DFDX_KTRACE, one shot, no object cache.  `bisect` = 1 | 2 | 3:
+    libfishdx_trace_b<N>.so with one component of the residual-block kernels removed (-DFDX_BISECT=N, convgemm16s.hip.h: 1 = the gate
+    epilogue's exp / rcp replaced by an add, 2 = non-temporal stores replaced by plain ones, 3 = the split-K LDS reduction stubbed) -- timing
+    experiments only, the results are wrong by construction."""
+    out = os.path.join(CSRC, f"libfishdx_trace_b{bisect}.so" if bisect else "libfishdx_trace.so")
+    extra = [f"-DFDX_BISECT={bisect}"] if bisect else []
+    cmd = [_hipcc(), *FLAGS, "-DFDX_KTRACE", *extra, "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -99,6 +103,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or _stale(LIB, objs):
+        for name in os.listdir(CSRC):      # instrumented libraries of an older source state must not outlive it (tools/ktrace.py would load them)
+            if name.startswith("libfishdx_trace") and name.endswith(".so"):
+                os.remove(os.path.join(CSRC, name))
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -107,4 +114,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build_trace() if "--trace" in sys.argv else build(force="--force" in sys.argv))
+    if "--trace" in sys.argv:
+        b = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--bisect=")]
+        print(build_trace(bisect=b[0] if b else 0))
+    else:
+        print(build(force="--force" in sys.argv))

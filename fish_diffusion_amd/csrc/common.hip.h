@@ -27,6 +27,7 @@ inline thread_local uint64_t* tl_alloc_gen = nullptr;
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool in_graphs = true;   // false: per-call scratch no recorded sampler graph ever reads -- its (re)allocation does not re-key the recordings
   ~DevBuf() { release(); }
   void release() {
     if (p) (void)hipFree(p);
@@ -40,7 +41,7 @@ struct DevBuf {
       hipError_t e = hipMalloc(&p, bytes);
       if (e != hipSuccess) { p = nullptr; return e; }
       cap = bytes;
-      if (tl_alloc_gen) ++*tl_alloc_gen;
+      if (tl_alloc_gen && in_graphs) ++*tl_alloc_gen;
     }
     if (zero && bytes) return hipMemsetAsync(p, 0, bytes, s);
     return hipSuccess;
@@ -222,11 +223,21 @@ struct fdx_ctx {
   // ---- mel
   bool mel_ok = false;
   fdx_mel_desc md{};
-  fdx::DevBuf mel_basis_packed, dft_packed, frames, spec;
-  float dft_key = 1e30f; int dft_nfft = 0, dft_win = 0;   // cache key of dft_packed
+  fdx::DevBuf mel_basis_packed, frames, spec;
+  // DFT matrix + Hann window per STFT geometry (n_fft, win): a key shift changes both (pitch_adjustable_mel.py:34-37).  Round 6: one arena per
+  // geometry, built once and uploaded ASYNCHRONOUSLY from a pinned host image that lives as long as the entry (rounds 1-5 kept ONE arena and
+  // synchronised the stream whenever the key shift changed).  LRU of kMelTables: the reference's +-12-semitone augmentation set is 25.
+  struct MelTable { int n_fft = 0, win = 0; fdx::DevBuf dev; void* host = nullptr; size_t floats = 0, dft_floats = 0; uint64_t last_use = 0; };
+  static constexpr int kMelTables = 32;
+  std::vector<MelTable*> mel_tables;
+  uint64_t mel_clock = 0;
+  long mel_builds = 0, mel_syncs = 0;    // fdx_mel_stats: tables built; stream synchronisations the mel path performed (0 unless the LRU evicts)
 
   // ---- debug / profiling
-  fdx::DevBuf scratch_a, scratch_b;   // small per-call scratch of the product paths (spec stats, rand_ini copies)
+  // small per-call scratch of the product paths (spec stats, rand_ini copies): eager launches only, never inside a recorded sampler body --
+  // so allocating it (fdx_denorm_spec right behind a handle's first sampler run) must not invalidate that run's recording (round 6: every handle
+  // recorded its first shape twice)
+  fdx::DevBuf scratch_a{nullptr, 0, false}, scratch_b{nullptr, 0, false};
   fdx::DevBuf dbg_w, dbg_x, dbg_b;    // fdx_debug_conv1d only
   fdx::ProfEvents prof;
   uint64_t alloc_gen = 0;             // see fdx::tl_alloc_gen
@@ -241,6 +252,7 @@ struct GenScope {   // first statement of every entry point that may (re)allocat
 }  // namespace fdx
 
 void fdx_rg_free(void* p);   // refinegan.hip
+void fdx_mel_free_tables(fdx_ctx* h);   // mel.hip
 void fdx_cn_free(void* p);   // convnext.hip
 bool fdx_cn_has_attention(fdx_ctx* h);   // cross_attention > 0: an exact-ragged run needs the item layout
 // convnext.hip: the two hooks fdx_sampler_run needs (same contracts as wn_embed / wn_forward_core in wavenet.hip)

@@ -72,7 +72,12 @@ template <int N, bool NT> __device__ __forceinline__ void stNp(float* p, VecN<N>
   typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
   typedef float f3nt __attribute__((ext_vector_type(3), aligned(4)));
   typedef float f2nt __attribute__((ext_vector_type(2), aligned(4)));
-  if constexpr (NT) {
+#if defined(FDX_BISECT) && FDX_BISECT == 2
+  constexpr bool kNT = false;                                          // (clock bisect: plain stores everywhere)
+#else
+  constexpr bool kNT = NT;
+#endif
+  if constexpr (kNT) {
     __builtin_nontemporal_store(f4nt{v.v[0], v.v[1], v.v[2], v.v[3]}, reinterpret_cast<f4nt*>(p));
     if constexpr (N == 5) __builtin_nontemporal_store(v.v[4], p + 4);
     if constexpr (N == 6) __builtin_nontemporal_store(f2nt{v.v[4], v.v[5]}, reinterpret_cast<f2nt*>(p + 4));
@@ -105,7 +110,11 @@ template <int NM> struct EpiGate16S {  // wavenet.py:112-115 (EpiGate16 for NM c
   __device__ __forceinline__ void store(int b, int row, int t, int nvalid, const VecN<NM>& g, const VecN<NM>& f, const Pre& p) const {
     VecN<NM> z;
 #pragma unroll
+#if defined(FDX_BISECT) && FDX_BISECT == 1
+    for (int m = 0; m < NM; ++m) z.v[m] = (g.v[m] + p.pg.v[m]) + (f.v[m] + p.pf.v[m]);     // (clock bisect: no exp / rcp)
+#else
     for (int m = 0; m < NM; ++m) z.v[m] = EpiGate::gate1(g.v[m] + p.pg.v[m], f.v[m] + p.pf.v[m]);
+#endif
     stNp<NM, true>(out + b * o_bs + (long)row * ldo + t, z, nvalid);
   }
 };
@@ -305,6 +314,12 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
   // ---- cross-wave K reduction through LDS, fixed order w0 + w1 + w2 + w3
   f4* redv = reinterpret_cast<f4*>(red);
   constexpr int Q = STR / 4;                                            // float4 slots per (row, lane)
+#if defined(FDX_BISECT) && FDX_BISECT == 3
+  constexpr bool kReduce = false;                                       // (clock bisect: no LDS writes, no barrier, every wave keeps its own partial sums)
+#else
+  constexpr bool kReduce = true;
+#endif
+  if constexpr (kReduce)
 #pragma unroll
   for (int x = 0; x < NR; ++x)
 #pragma unroll
@@ -319,11 +334,16 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
       if constexpr (NM > 4) redv[base + 1] = f4{t[4], t[5], t[6], t[7]};
     }
   FDX_STAMP(3);
-  __syncthreads();
+  if constexpr (kReduce) __syncthreads();
   FDX_STAMP(4);
   if (nvalid <= 0) return;
   auto rsum = [&](int s) {   // s = x*4 + reg
     VecN<NM> out;
+    if constexpr (!kReduce) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m) out.v[m] = acc[(s >> 2) % NR][m][s & 3];
+      return out;
+    }
     f4 lo = redv[((0 * (NR * 4) + s) * kWave + lane) * Q];
     f4 hi = f4{0.f, 0.f, 0.f, 0.f};
     if constexpr (NM > 4) hi = redv[((0 * (NR * 4) + s) * kWave + lane) * Q + 1];

@@ -47,6 +47,7 @@ extern "C" int fdx_destroy(fdx_handle h) {
   if (h->rg) fdx_rg_free(h->rg);
   if (h->cn) fdx_cn_free(h->cn);
   if (h->td) fdx_td_free(h->td);
+  fdx_mel_free_tables(h);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   for (auto e : h->prof.start) (void)hipEventDestroy(e);

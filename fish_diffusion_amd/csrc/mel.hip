@@ -103,7 +103,23 @@ extern "C" int fdx_mel_config(fdx_handle h, const fdx_mel_desc* d) {
   FDX_HIP(h, hipMemcpy(h->mel_basis_packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
   h->md = *d;
   h->mel_ok = true;
-  h->dft_nfft = 0;
+  fdx_mel_free_tables(h);        // tables of another base geometry (bins cropped at the base resolution) are stale
+  return FDX_OK;
+}
+
+void fdx_mel_free_tables(fdx_ctx* h) {
+  for (auto* t : h->mel_tables) {
+    if (t->host) (void)hipHostFree(t->host);
+    delete t;
+  }
+  h->mel_tables.clear();
+}
+
+extern "C" int fdx_mel_stats(fdx_handle h, long* table_builds, long* stream_syncs, int* cached) {
+  if (!h) return FDX_E_ARG;
+  if (table_builds) *table_builds = h->mel_builds;
+  if (stream_syncs) *stream_syncs = h->mel_syncs;
+  if (cached) *cached = (int)h->mel_tables.size();
   return FDX_OK;
 }
 
@@ -121,28 +137,53 @@ __global__ void k_frames(float* __restrict__ FR, long fr_bs, int ldf, const floa
 }
 
 // ================================================================================================ forward
-static int ensure_dft(fdx_ctx* h, const StftGeom& g, hipStream_t s) {
-  if (h->dft_nfft == g.n_fft && h->dft_win == g.win) return FDX_OK;
+// The DFT matrix (packed for the GEMM) and the Hann window of one STFT geometry, from the handle's cache.  A new geometry is built on the host
+// into PINNED memory owned by the cache entry and uploaded with hipMemcpyAsync on the caller's stream: no stream synchronisation, and a caller
+// alternating key shifts (the reference's augmentation path) pays the build once per shift.  Only evicting the least recently used of
+// kMelTables geometries waits for the stream (its arena may still be read by queued launches) -- counted in mel_syncs.
+static int ensure_dft(fdx_ctx* h, const StftGeom& g, hipStream_t s, const fdx_ctx::MelTable*& out) {
+  for (auto* t : h->mel_tables)
+    if (t->n_fft == g.n_fft && t->win == g.win) { t->last_use = ++h->mel_clock; out = t; return FDX_OK; }
   const int bins_out = std::min(g.bins, 1 + h->md.n_fft / 2);   // bins beyond the base resolution are cropped (:91)
   const int n_mtiles = (bins_out + 31) / 32, cin8 = (g.n_fft + 7) / 8;
   const double w0 = 2.0 * 3.14159265358979323846 / g.n_fft;
-  std::vector<float> packed(packed_floats(n_mtiles, 2, cin8, 1));
-  pack_convgemm(packed.data(), n_mtiles, 2, cin8, 1, [&](int mt, int rb, int i, int c, int) -> float {
+  const size_t dft_floats = packed_floats(n_mtiles, 2, cin8, 1), win_floats = (size_t)round_up(g.n_fft, 8);
+  if ((int)h->mel_tables.size() >= fdx_ctx::kMelTables) {
+    size_t lru = 0;
+    for (size_t i = 1; i < h->mel_tables.size(); ++i) if (h->mel_tables[i]->last_use < h->mel_tables[lru]->last_use) lru = i;
+    FDX_HIP(h, hipStreamSynchronize(s));   // the evicted arena's last readers
+    ++h->mel_syncs;
+    if (h->mel_tables[lru]->host) (void)hipHostFree(h->mel_tables[lru]->host);
+    delete h->mel_tables[lru];
+    h->mel_tables.erase(h->mel_tables.begin() + lru);
+  }
+  auto* t = new fdx_ctx::MelTable();
+  t->n_fft = g.n_fft; t->win = g.win; t->dft_floats = dft_floats; t->floats = dft_floats + win_floats;
+  hipError_t e = hipHostMalloc(&t->host, t->floats * sizeof(float), hipHostMallocDefault);
+  if (e == hipSuccess) e = t->dev.ensure(t->floats * sizeof(float), false, s);
+  if (e != hipSuccess) {
+    if (t->host) (void)hipHostFree(t->host);
+    delete t;
+    return fail(h, FDX_E_HIP, "mel tables for n_fft = %d: %s", g.n_fft, hipGetErrorString(e));
+  }
+  float* packed = static_cast<float*>(t->host);
+  pack_convgemm(packed, n_mtiles, 2, cin8, 1, [&](int mt, int rb, int i, int c, int) -> float {
     const int f = mt * 32 + i;
     if (f >= bins_out || c >= g.n_fft) return 0.f;
     const long m = ((long)f * c) % g.n_fft;   // exact angle reduction
     return rb == 0 ? (float)std::cos(w0 * m) : (float)-std::sin(w0 * m);
   });
   // torch.hann_window(win) (periodic), fp32 arithmetic: cos(n * (2 pi / win)) * -0.5 + 0.5; centred in n_fft when shorter
-  std::vector<float> window(round_up(g.n_fft, 8), 0.f);
+  float* window = packed + dft_floats;
+  for (size_t n = 0; n < win_floats; ++n) window[n] = 0.f;
   const float step = (float)(3.14159265358979323846 * 2 / g.win);
   const int left = (g.n_fft - g.win) / 2;
   for (int n = 0; n < g.win; ++n) window[left + n] = std::cos((float)n * step) * -0.5f + 0.5f;
-  FDX_HIP(h, hipStreamSynchronize(s));   // previous users of the cached matrices
-  FDX_HIP(h, h->dft_packed.ensure((packed.size() + window.size()) * 4, false, s));
-  FDX_HIP(h, hipMemcpy(h->dft_packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
-  FDX_HIP(h, hipMemcpy(h->dft_packed.f() + packed.size(), window.data(), window.size() * 4, hipMemcpyHostToDevice));
-  h->dft_nfft = g.n_fft; h->dft_win = g.win;
+  FDX_HIP(h, hipMemcpyAsync(t->dev.p, t->host, t->floats * sizeof(float), hipMemcpyHostToDevice, s));   // (pinned source owned by the entry)
+  t->last_use = ++h->mel_clock;
+  ++h->mel_builds;
+  h->mel_tables.push_back(t);
+  out = t;
   return FDX_OK;
 }
 
@@ -158,7 +199,8 @@ extern "C" int fdx_mel_forward(fdx_handle h, const float* wav, int B, int N, flo
   const auto& d = h->md;
   StftGeom g;
   if (stft_geom(d, N, key_shift, speed, g)) return fail(h, FDX_E_ARG, "input of %d samples is too short for this STFT geometry", N);
-  if (int rc = ensure_dft(h, g, s)) return rc;
+  const fdx_ctx::MelTable* tab = nullptr;
+  if (int rc = ensure_dft(h, g, s, tab)) return rc;
   const int T = g.T, ldt = padded_ld(T, 64);
   const int Kp = round_up(g.n_fft, 8);
   const int base_bins = 1 + d.n_fft / 2, rows_spec = round_up(base_bins, 8);
@@ -166,8 +208,7 @@ extern "C" int fdx_mel_forward(fdx_handle h, const float* wav, int B, int N, flo
   FDX_HIP(h, h->frames.ensure((size_t)B * Kp * ldt * 4, true, s));
   FDX_HIP(h, h->spec.ensure((size_t)B * rows_spec * ldt * 4, true, s));
   const int cin8 = Kp / 8;
-  const size_t dft_floats = packed_floats((bins_out + 31) / 32, 2, cin8, 1);
-  const float* window = h->dft_packed.f() + dft_floats;
+  const float* window = tab->dev.f() + tab->dft_floats;
   hipLaunchKernelGGL(k_frames, dim3((T + 255) / 256, g.n_fft, B), dim3(256), 0, s, h->frames.f() + kHalo, (long)Kp * ldt, ldt, wav, N,
                      window, g.n_fft, g.hop, g.pad, T);
   {
@@ -175,7 +216,7 @@ extern "C" int fdx_mel_forward(fdx_handle h, const float* wav, int B, int N, flo
     e.out = h->spec.f() + kHalo; e.o_bs = (long)rows_spec * ldt; e.ldo = ldt; e.n_bins = bins_out; e.n_rows = base_bins;
     if (key_shift != 0.f) { e.mul = (float)d.win_size; e.div = (float)g.win; }   // spec * win_size / win_size_new (:91)
     ConvGeom cg{B, T, cin8, 1, 0, 0, (bins_out + 31) / 32};
-    FDX_HIP(h, (launch_convgemm<2, true, false, EpiMag>(cg, reinterpret_cast<const float4*>(h->dft_packed.p), h->frames.f() + kHalo,
+    FDX_HIP(h, (launch_convgemm<2, true, false, EpiMag>(cg, reinterpret_cast<const float4*>(tab->dev.p), h->frames.f() + kHalo,
                                                           (long)Kp * ldt, ldt, 1.f, e, s)));
   }
   {

@@ -1129,12 +1129,15 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
   if (!graphable) {
     if (int rc = sampler_body(h, kind, tab, n_rows, step_noise, seed, x_mask, s)) return rc;
   } else {
-    uint64_t key = fnv1a(tab, (size_t)n_rows * FDX_ROW * sizeof(float));
-    const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
-                              (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, h->alloc_gen,
-                              (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn, (uint64_t)(uintptr_t)h->td,
-                              (uint64_t)(uintptr_t)h->ragged_keep, h->items_hash};
-    key = fnv1a(parts, sizeof parts, key);
+    const uint64_t tab_hash = fnv1a(tab, (size_t)n_rows * FDX_ROW * sizeof(float));
+    auto make_key = [&]() {
+      const uint64_t parts[] = {(uint64_t)kind, (uint64_t)n_rows, (uint64_t)B, (uint64_t)T, (uint64_t)(x_mask != nullptr),
+                                (uint64_t)(uintptr_t)h->wn_arena, (uint64_t)h->cond_masked, h->alloc_gen,
+                                (uint64_t)h->den_kind, (uint64_t)(uintptr_t)h->cn, (uint64_t)(uintptr_t)h->td,
+                                (uint64_t)(uintptr_t)h->ragged_keep, h->items_hash};
+      return fnv1a(parts, sizeof parts, tab_hash);
+    };
+    uint64_t key = make_key();
     fdx_ctx::GraphEntry* hit = nullptr;
     for (auto& g : h->graphs) if (g.key == key) hit = &g;
     if (!hit) {
@@ -1148,6 +1151,10 @@ extern "C" int fdx_sampler_run(fdx_handle h, int kind, const float* tab, int n_r
       hipGraphExec_t exec = nullptr;
       FDX_HIP(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
+      // Workspaces first touched INSIDE the body (a handle's very first run) were allocated while recording: the recording holds their final
+      // addresses, so it is filed under the allocation generation AFTER the capture -- round 5 filed it under the one before, and the second
+      // run of every handle recorded the same 4 k (transformer: 13 k) nodes once more (bench.py `first_call_ms.sampler_graphs`: 2 -> 1).
+      key = make_key();
       // LRU cache.  Keys change with geometry / schedule / reallocation; ragged serving (pipeline.synthesize pads every micro-batch
       // to a 64-frame bucket) cycles through (batch size, bucket) pairs -- a few dozen for 6-10 s utterances in batches of <= 8 --
       // so the cache holds that many (an instantiated sampler graph is ~4 k kernel nodes of host memory, no device memory).

@@ -206,7 +206,10 @@ int fdx_sampler_run_ragged(fdx_handle h, int kind, const float* host_table, int 
  * ConvNext with cross-attention) must be told where the items of the ONE row (B == 1) lie: call this BEFORE fdx_*_prepare with host arrays of
  * n_items offsets (multiples of 32, ascending, non-overlapping) and lengths; self- and cross-attention then run per item over its own frames
  * and positions restart at each offset.  n_items == 0 clears the layout (dense batches).  T = length of the row the items lie in.  Every item
- * comes out bit-identical to a batch-1 run of it alone (the key split of an item's attention depends on its own length only). */
+ * comes out bit-identical to a batch-1 run of it alone (the key split of an item's attention depends on its own length only).
+ * fdx_sampler_run_ragged REFUSES (FDX_E_STATE) to run an attention-based denoiser without a layout: the result would silently not be the
+ * per-item one.  A rejected layout (FDX_E_ARG) leaves the handle with NO layout, never half of one.  The offsets / lengths are copied
+ * during the call (they travel to the device as kernel arguments): the host arrays may be freed on return, nothing synchronises. */
 int fdx_sampler_set_items(fdx_handle h, const int* host_offsets, const int* host_lens, int n_items, int T, fdx_stream s);
 /* The start of shallow diffusion, diffusion.py:223-232: out = q_sample(norm_spec(src), t, noise).
  *   normalise != 0: v = (src - spec_min) / (spec_max - spec_min) * 2 - 1 (diffusion.py:315-316).  spec_min/max are host arrays of
@@ -325,6 +328,11 @@ enum { FDX_MEL_LINEAR = 0, FDX_MEL_LN = 1, FDX_MEL_LOG10 = 2 };
 /* wav: dev [B][N]; mel: dev [B][n_mels][T] with T = fdx_mel_num_frames(...). */
 int fdx_mel_forward(fdx_handle h, const float* wav, int B, int N, float key_shift, float speed,
                     int log_mode, float* mel, fdx_stream s);
+/* The DFT matrix + window of every STFT geometry (key shift: pitch_adjustable_mel.py:34-37) are cached per handle and uploaded
+ * asynchronously on the caller's stream: fdx_mel_forward never synchronises the stream unless more than 32 geometries are
+ * alive (LRU eviction).  table_builds = geometries built so far, stream_syncs = synchronisations performed (0 in normal use),
+ * cached = geometries held. */
+int fdx_mel_stats(fdx_handle h, long* table_builds, long* stream_syncs, int* cached);
 
 /* ------------------------------------------------------------------------------------------------
  * Condition front end -- replaces DiffSinger.forward_features,

@@ -54,7 +54,7 @@ def save(name, **arrays):
 FIXTURE_SECTIONS = (("convnext_cross", "convnext_cross"), ("convnext", "convnext"), ("frontend_expand", "frontend_expand"), ("frontend_svs", "frontend_svs"),
                     ("tfdec", "tfdec"), ("refinegan_sine", "refinegan_sine"), ("nsf_v1_256_full", "round2"), ("chain_c1", "round2"), ("chain_c2", "round2"),
                     ("chain_", "round3"), ("ddpm1000_", "round3"), ("sampler_buffers", "round4"), ("svc_caller", "round4"),
-                    ("nsf_rb2_", "round5"), ("mel_filterbank_hf", "round5"))
+                    ("nsf_rb2_", "round5"), ("mel_filterbank_hf", "round5"), ("sharded_c3_microbatch", "round6"))
 
 
 def write_manifest():
@@ -725,6 +725,54 @@ def golden_round5(R):
 
 
 @torch.no_grad()
+def golden_round6(R):
+    """Round 6: BASELINE configs[3] at bench scale IN ONE PIECE.  `sharded_c3_microbatch`: rank 0's first micro-batch of the sharded bench job
+    (bench.py --config sharded: 64 seeded lengths in [516, 861] dealt longest-first over 8 ranks, micro-batches of <= 8) -- 8 utterances
+    through the REAL reference, one at a time (an exact-ragged micro-batch is defined as every utterance's batch-1 result): features ->
+    GaussianDiffusion (full 20-layer WaveNet, 100-step UniPC) -> mel for each of the 8; and for three of them (shortest, median, longest)
+    mel -> `* 2.30259` -> NSF-HiFiGAN Generator -> waveform.  Inputs are regenerated from the stored seeds (SHA-1 checked)."""
+    print("round 6: configs[3] micro-batch, full size (8 reference runs of 100 UniPC steps: minutes)")
+    all_lens = torch.randint(516, 862, (64,), generator=torch.Generator().manual_seed(4)).tolist()      # benchkit/workloads.py, `sharded`
+    order = sorted(range(64), key=lambda i: (-all_lens[i], i))                                         # dist.shard_utterances: longest first, dealt round-robin
+    mine = order[0::8]
+    lens = [all_lens[i] for i in mine]                                                                 # rank 0's 8 utterances = its one micro-batch
+    sd = wavenet_ref.seeded_wavenet_state(1234, **{k: v for k, v in WN_FULL.items() if k != "dilation_cycle"})
+    diff = build_ref_diffusion(R, WN_FULL, sd)
+    hv = nsf_hifigan_ref.CONFIG_V1
+    vsd = nsf_hifigan_ref.seeded_generator_state(55, hv)
+    gen = R["Generator"](R["AttrDict"](hv))
+    gen.remove_weight_norm()
+    gen.eval()
+    gen.load_state_dict(vsd, strict=True)
+    by_len = sorted(range(8), key=lambda b: lens[b])
+    voc_items = [by_len[0], by_len[4], by_len[7]]
+    arrays = dict(lens=np.array(lens, np.int64), utterance_ids=np.array(mine, np.int64), interval=np.int64(10), voc_items=np.array(voc_items, np.int64),
+                  wn_sha1=np.array(state_sha1(sd)), voc_sha1=np.array(state_sha1(vsd)))
+    feat_sha, noise_sha = [], []
+    for b, n in enumerate(lens):
+        feats = torch.randn(1, n, 256, generator=torch.Generator().manual_seed(6000 + b))
+        torch.manual_seed(6100 + b)
+        mel_ref = diff(feats, sampler_interval=10)                            # [1, n, 128]
+        arrays[f"mel_{b}"] = mel_ref[0]
+        feat_sha.append(sha1_of([feats]))
+        print(f"  utterance {b}: {n} frames, mel range [{float(mel_ref.min()):.2f}, {float(mel_ref.max()):.2f}]")
+        if b in voc_items:
+            f0 = synth_f0(n)[None]
+            torch.manual_seed(6200 + b)
+            wav = gen(2.30259 * mel_ref.transpose(1, 2), f0)
+            torch.manual_seed(6200 + b)
+            rand_ini = torch.rand(1, 9)
+            rand_ini[:, 0] = 0
+            src_noise = torch.randn(1, n * hv["hop_size"], 9)
+            assert torch.equal(nsf_hifigan_ref.generator_forward(vsd, hv, 2.30259 * mel_ref.transpose(1, 2), f0, rand_ini, src_noise), wav)
+            arrays[f"wav_{b}"] = wav[0, 0]
+            arrays[f"rand_ini_{b}"] = rand_ini
+            noise_sha.append(sha1_of([src_noise]))
+    arrays["features_sha1"] = np.array(feat_sha)
+    arrays["src_noise_sha1"] = np.array(noise_sha)
+    save("sharded_c3_microbatch", **arrays)
+
+
 def golden_round4(R):
     """Round-4 fixtures.
     (a) sampler_buffers: in the reference the DDPM / PLMS coefficients are `register_buffer`s of the predictor modules
@@ -1183,6 +1231,7 @@ def main():
     golden_round3(R)
     golden_round4(R)
     golden_round5(R)
+    golden_round6(R)
 
     write_manifest()
     print("done")
@@ -1190,7 +1239,7 @@ def main():
 
 if __name__ == "__main__":
     SECTIONS = {"convnext": golden_convnext, "frontend_expand": golden_frontend_expand, "tfdec": golden_tfdec, "round2": golden_round2, "convnext_cross": golden_convnext_cross, "refinegan_sine": golden_refinegan_sine,
-                "frontend_svs": golden_frontend_svs, "round3": golden_round3, "round4": golden_round4, "round5": golden_round5}
+                "frontend_svs": golden_frontend_svs, "round3": golden_round3, "round4": golden_round4, "round5": golden_round5, "round6": golden_round6}
     if len(sys.argv) == 2 and sys.argv[1] == "manifest":   # re-index the fixtures on disk (no reference needed)
         write_manifest()
     elif len(sys.argv) == 2 and sys.argv[1] in SECTIONS:   # regenerate one section only

@@ -22,6 +22,13 @@ def dev(lib_built):
     return torch.device("cuda", 0)
 
 
+def _diffusion(cfg, sd, dev, **kw):
+    from fish_diffusion_amd import DIFFUSIONS
+    d = DIFFUSIONS.build(dict(type="GaussianDiffusion", denoiser=dict(type="WaveNetDenoiser", **cfg), spec_min=[-5], spec_max=[0], **kw))
+    d.denoise_fn.load_state_dict(sd, strict=True)
+    return d.to(dev).eval()
+
+
 # ------------------------------------------------------------------------------------------------ bf16 storage mode: the error table
 def test_bf16_storage_error_table_full_size_net(dev):
     """BASELINE configs[4]'s opt-in bf16 storage mode on the FULL-SIZE net (diff_svc_v2: C = 512, 20 layers; 10 s): the mel's distance
@@ -145,11 +152,11 @@ def test_fp16_split_error_table_full_size_net(dev):
 def test_fp16_split_small_tile_kernel_holds_the_fp32_parity_bars(dev):
     """csrc/f16s64.hip.h: the fp16-split mode on 64 x 64 tiles (v_mfma_f32_16x16x32_f16) -- what `storage="fp16x3"` runs below the
     wide-tile threshold, i.e. on the HEADLINE geometry (batch 1 x 10 s: 224 workgroups; 27 vs 37 ms per 50 denoiser calls against the
-    fp32 kernels).  The same broad subset the wide tiles are held to -- reference goldens at 2e-5 per call, 1e-3 on the sampled mel
-    (incl. the full-size 1000-step DDPM fixtures), 1e-4-class chained waveforms, exact-ragged batches -- with this kernel forced for
+    fp32 kernels).  The core subset (FP16X3_CORE) -- reference goldens at 2e-5 per call, 1e-3 on the sampled mel of the BASELINE fixtures and
+    the full-size 1000-step DDPM fixtures, exact-ragged batches -- with this kernel forced for
     every geometry (FDX_F16S_SMALL=2: from two tiles; FDX_BF16_LDS huge: never the 128-wide tiles)."""
     env = dict(os.environ, FDX_WAVENET_STORAGE="fp16x3", FDX_F16S_SMALL="2", FDX_BF16_LDS="1000000000")
-    r = subprocess.run([sys.executable, "-m", "pytest", *SWEEP_FILES, "-m", "gpu", "-q", "-x", "-k", FP16X3_SUBSET], env=env, capture_output=True,
+    r = subprocess.run([sys.executable, "-m", "pytest", *SWEEP_FILES, "-m", "gpu", "-q", "-x", "-k", FP16X3_CORE], env=env, capture_output=True,
                        text=True, timeout=1500, cwd=ROOT)
     print(r.stdout[-3000:])
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]

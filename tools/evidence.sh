@@ -14,10 +14,11 @@ sub=$1; tag=$2; shift 2
 out=gpurun_out/$tag; mkdir -p "$out"
 envs=(); 
 take_envs() { envs=(); rest=(); local seen=0; for a in "$@"; do if [ $seen = 0 ] && [[ "$a" == *=* ]] && [[ "$a" != -* ]]; then envs+=("$a"); elif [ "$a" = "--" ] && [ $seen = 0 ]; then seen=1; else seen=1; rest+=("$a"); fi; done; }
-suffix() { local s=""; for e in "${envs[@]:-}"; do [ -n "$e" ] && s="${s}_${e//=/-}"; done; echo "$s"; }
+suffix() { local s=""; for e in "${envs[@]:-}"; do [ -n "$e" ] && [[ "$e" != FDX_LIB_PATH=* ]] && s="${s}_${e//=/-}"; done; s="${s//\//_}"; echo "${s:0:80}"; }
 case $sub in
   tests)
-    timeout ${FDX_TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q "$@" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; tail -4 $out/tests.log ;;
+    where=tests; for a in "$@"; do [[ "$a" == tests/* ]] && where=""; done      # a file / node id among the arguments replaces the whole directory
+    timeout ${FDX_TEST_TIMEOUT:-1500} python -m pytest $where -m gpu -q "$@" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; tail -4 $out/tests.log ;;
   bench)
     cfg=$1; shift; take_envs "$@"
     args="--steps ${FDX_STEPS:-3} --warmup 1 --no-cpu-baseline --no-pcie --no-extras"; [ "$cfg" != default ] && args="--config $cfg $args"

@@ -59,3 +59,15 @@ for l in range(NL):
     rt = rt[(rt > 0) & (rt < 10 ** 7)]
     clk = f"  {d.sum(1).mean() / (rt.mean() * 10e-9) / 1e9:5.2f} GHz ({rt.mean() * 10:.0f} ns per wave)" if len(rt) else ""
     print(f"{l:>6} {len(w):>6} {span:>8} | " + " ".join(f"{d[:, i].mean():>14.0f}" for i in range(5)) + f" | {d.sum(1).mean():>10.0f} {first.mean() if len(first) else 0:>10.0f}{clk}")
+
+# board power and sclk while the same forward runs back to back for ~1 s (which component of the real kernels draws the extra
+# 200 W / reads 2.1 GHz?) -- the sampler bench.py uses
+from benchkit.timing import SclkSampler  # noqa: E402
+lib.fdx_debug_trace(None, 0, 0)
+smp = SclkSampler(0)
+with smp:
+    for _ in range(400):
+        net(x, t, cond)
+    torch.cuda.synchronize()
+rep = smp.report()
+print("sclk / board power over 400 back-to-back forwards:", rep.get("mean"), "MHz,", (rep.get("board_power_w") or {}).get("mean"), "W")
