@@ -138,6 +138,10 @@ def dry_run(args, cfg, steps, warmup, rank, world):
 
 
 
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes", "launches_timed", "sampling",
+                 "avg_launch_us", "flops_per_launch")
+
+
 def compact(w, m, cpu=None):
     """A sub-result of the default line: the same accounting as the main line, without the per-rank legs; `cpu` = its bounded CPU leg."""
     r = m.roofline
@@ -148,8 +152,7 @@ def compact(w, m, cpu=None):
             "workload": w.workload, "config": dict({"name": w.name}, **w.cfg_extra),
             "end_to_end": {"tflops": round(m.e2e_alg, 3), "frac_of_peak": round(m.e2e_alg / w.peak, 4), "tflops_executed": round(m.e2e_exe, 3),
                            "frac_of_peak_executed": round(m.e2e_exe / w.peak, 4), "peak_tflops": w.peak, "algorithmic_flops_per_step": m.alg},
-            "roofline": (None if r is None else {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes",
-                                                                    "launches_timed", "sampling", "avg_launch_us", "flops_per_launch")})}
+            "roofline": (None if r is None else {k: r[k] for k in ROOFLINE_KEYS})}
 
 
 def release(w):

@@ -158,9 +158,11 @@ def cpu_baseline_leg(w, cfg, args, value, quick=False):
     else:
         raise ValueError(cfg)
     cb = {"value": round(cpu_audio / (td + tv), 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-          "sample": sample + f"; torch {torch.__version__} CPU, {cores} threads; 1 warm-up pass + " + (f"median of {len(runs)} timed passes" if len(runs) > 1 else "1 timed pass"),
+          "sample": (sample + f"; torch {torch.__version__} CPU, {cores} threads; 1 warm-up pass + "
+                     + (f"median of {len(runs)} timed passes" if len(runs) > 1 else "1 timed pass")),
           "denoise_s": round(td, 4), "vocoder_s": round(tv, 4),
-          "protocol": "BASELINE.md section 3: 1 warm-up + 3 timed, median" if not quick else "bounded: 1 warm-up + 1 timed pass (the full protocol runs under `--config <name>`)",
+          "protocol": ("BASELINE.md section 3: 1 warm-up + 3 timed, median" if not quick else
+                       "bounded: 1 warm-up + 1 timed pass (the full protocol runs under `--config <name>`)"),
           "note": REF_VS_PORT_NOTE,
           "runs_s": [[round(a, 4), round(b, 4)] for a, b in runs],
           "runs_value": [round(cpu_audio / (a + b), 4) for a, b in runs]}

@@ -295,8 +295,10 @@ def build_work(cfg, args, dev, rank, world, n_total, extra=False):
         per_frame, hoist = convnext_flops_per_frame(mc) if cfg == "convnext" else tfdec_flops_per_frame(T, mc)
         w.alg = per_frame * B * T * n_steps
         w.exe = w.alg - hoist * B * T * (n_steps - 1)
-        w.metric = f"audio-seconds/sec/GPU ({n_steps}-step UniPC over the {'ConvNext' if cfg == 'convnext' else 'TransformerDecoder'} denoiser, mel only, 44.1 kHz / hop 512)"
-        w.workload = (f"SURVEY 8(f) row 4: {'ConvNextDenoiser (dim 512 x 20 blocks, mlp 4)' if cfg == 'convnext' else 'TransformerDecoderDenoiser (dim 512 x 12 layers, 8 heads, mlp 4)'}"
+        fam = "ConvNext" if cfg == "convnext" else "TransformerDecoder"
+        what = "ConvNextDenoiser (dim 512 x 20 blocks, mlp 4)" if cfg == "convnext" else "TransformerDecoderDenoiser (dim 512 x 12 layers, 8 heads, mlp 4)"
+        w.metric = f"audio-seconds/sec/GPU ({n_steps}-step UniPC over the {fam} denoiser, mel only, 44.1 kHz / hop 512)"
+        w.workload = (f"SURVEY 8(f) row 4: {what}"
                       f" behind the DENOISERS contract, {n_steps}-step UniPC, batch={B} x {seconds:g} s (T={T}), fresh features every step; features -> mel "
                       "(no vocoder pass)")
         w.cfg_extra = {"batch_per_gpu": B, "frames": T, "sampler": "unipc", "sampler_steps": n_steps}

@@ -257,13 +257,14 @@ void fdx_cn_free(void* p);   // convnext.hip
 bool fdx_cn_has_attention(fdx_ctx* h);   // cross_attention > 0: an exact-ragged run needs the item layout
 // convnext.hip: the two hooks fdx_sampler_run needs (same contracts as wn_embed / wn_forward_core in wavenet.hip)
 int fdx_cn_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s);
+// `fuse` (optional): the UniPC corrector (+ next predictor) applied in the last projection's epilogue instead of storing eps (EpiUniPC, convgemm.hip.h)
 int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
-                        hipStream_t s, bool unmasked_cond);
+                        hipStream_t s, bool unmasked_cond, const fdx::EpiUniPC* fuse = nullptr);
 int fdx_cn_plms_setup(fdx_ctx* h, hipStream_t s);   // PLMS + cond_masks: projections of the unmasked condition
 void fdx_td_free(void* p);   // tfdec.hip, same hooks
 int fdx_td_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s);
 int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
-                        hipStream_t s, bool unmasked_cond);
+                        hipStream_t s, bool unmasked_cond, const fdx::EpiUniPC* fuse = nullptr);
 
 namespace fdx {
 

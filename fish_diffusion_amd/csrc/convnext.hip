@@ -481,7 +481,7 @@ int fdx_cn_plms_setup(fdx_ctx* h, hipStream_t s) {
 
 // ================================================================================================ forward
 int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
-                        hipStream_t s, bool unmasked_cond) {
+                        hipStream_t s, bool unmasked_cond, const EpiUniPC* fuse) {
   fdx_cn_state* S = cn(h);
   const auto& d = S->d;
   const auto& l = S->l;
@@ -542,7 +542,11 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
     FDX_HIP(h, gemm(A, wide_pw2 ? l.pw2w[i] : l.pw2[i], B, T, G, bsH, ld, e, s));
   }
   FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
-  {
+  if (fuse) {   // UniPC: eps is consumed in the epilogue (corrector + the next step's predictor), bit-identical to the separate launch
+    EpiUniPC e = *fuse;
+    e.bias = A + l.out2.b_off; e.M = M; e.mask = mask; e.mask_ld = T;
+    FDX_HIP(h, gemm(A, l.out2, B, T, H2, bsD, ld, e, s));
+  } else {
     EpiBias e = bias_epi(eps_out, o_bs, ldo, A + l.out2.b_off, M, ACT_NONE);
     e.mask = mask; e.mask_ld = T;
     e.tight = ldo != ld;

@@ -257,7 +257,7 @@ int fdx_td_embed(fdx_ctx* h, const float* t_dev, int n, hipStream_t s) {
 
 // ================================================================================================ forward
 int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const uint8_t* mask, float* eps_out, long o_bs, int ldo,
-                        hipStream_t s, bool unmasked_cond) {
+                        hipStream_t s, bool unmasked_cond, const EpiUniPC* fuse) {
   fdx_td_state* S = td(h);
   const auto& d = S->d;
   const auto& l = S->l;
@@ -296,7 +296,11 @@ int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
                               b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs, items));
     FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
   }
-  {
+  if (fuse) {   // UniPC: eps is consumed in the epilogue (corrector + the next step's predictor), bit-identical to the separate launch
+    EpiUniPC e = *fuse;
+    e.bias = A + l.out2.b_off; e.M = M; e.mask = mask; e.mask_ld = T;
+    FDX_HIP(h, gemm(A, l.out2, B, T, H2, bsD, ld, e, s));
+  } else {
     EpiBias e = bias_epi(eps_out, o_bs, ldo, A + l.out2.b_off, M, ACT_NONE);
     e.mask = mask; e.mask_ld = T;
     e.tight = ldo != ld;

@@ -967,14 +967,14 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
   const dim3 grid = ew_grid(T, B * M), blk(kEwBlock);
   float* sx = h->sx.f() + kHalo;
   float* eps = h->EPS.f() + kHalo;
-  // WaveNet + UniPC: the corrector (and the next predictor) ride in the last projection's epilogue (EpiUniPC): one launch less per step
+  // UniPC: the corrector (and the next predictor) ride in the denoiser's last projection's epilogue (EpiUniPC): one launch less per step
   static const bool fuse_unipc = [] { const char* e = getenv("FDX_UNIPC_FUSED"); return !e || atoi(e) != 0; }();
   auto model = [&](const float* xin, int col, bool masked, const EpiUniPC* fuse = nullptr) {
     // the one unmasked call of PLMS uses the conditioner slab of the UNMASKED conditioner (built in the set-up phase)
     // (exact-mask mode: the mask marks frames that do not exist, for an item run alone as well -- PLMS's unmasked call keeps it)
     const bool keep_mask = masked || h->ragged_keep;
-    if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, keep_mask ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked);
-    if (h->den_kind == 2) return fdx_td_forward_core(h, xin, col, 0, keep_mask ? x_mask : nullptr, eps, bs, ld, s, !masked);
+    if (h->den_kind == 1) return fdx_cn_forward_core(h, xin, col, 0, keep_mask ? x_mask : nullptr, eps, bs, ld, s, !masked && h->cond_masked, fuse);
+    if (h->den_kind == 2) return fdx_td_forward_core(h, xin, col, 0, keep_mask ? x_mask : nullptr, eps, bs, ld, s, !masked, fuse);
     const float* P = (!masked && h->cond_masked) ? h->P2.f() : nullptr;
     // (exact-mask mode: the mask marks frames that do not exist, for an item run alone as well -- PLMS's unmasked call keeps it)
     return wn_forward_core(h, xin, col, 0, (masked || h->ragged_keep) ? x_mask : nullptr, eps, bs, ld, s, P, fuse);
@@ -993,7 +993,7 @@ static int sampler_body(fdx_ctx* h, int kind, const float* tab, int n_rows, cons
       if (!pre_done)
         hipLaunchKernelGGL(k_unipc_pre, grid, blk, 0, s, xb, xt, sx, m0, m1, bs, ld, M, T, c_x, c_m, aB, rk, order);
       pre_done = false;
-      if (corr && fuse_unipc && h->den_kind == 0) {
+      if (corr && fuse_unipc) {   // (every denoiser since round 6: ConvNext's and the transformer's last projection take the same epilogue)
         EpiUniPC e{};
         e.x = sx; e.mt = mt; e.xbase = xb; e.xt = xt; e.m0 = m0; e.m1 = m1; e.bs = bs; e.ld = ld;
         e.sigma = sigma; e.alpha = alpha; e.aB = aB; e.rk = rk; e.rho0 = row[9]; e.rho1 = row[10]; e.order = order;

@@ -244,6 +244,22 @@ for B, T, iv in ((1, 37, 100), (2, 113, 50), (1, 430, 20), (3, 64, 500), (1, 861
     lens = [max(1, T - 7 * b) for b in range(B)]
     mel = diff(feats, sampler_interval=iv, x_init=x0, lengths=lens)        # exact-ragged rows run the same fused epilogue
     h.update(mel.cpu().numpy().tobytes())
+# round 6: the other two denoisers' last projection takes the same epilogue
+from tests.helpers import CN_SMALL, TD_SMALL, convnext_sd, tfdec_sd
+for kind, cfg, sd in (("ConvNextDenoiser", CN_SMALL, convnext_sd(CN_SMALL, 5)), ("TransformerDecoderDenoiser", TD_SMALL, tfdec_sd(TD_SMALL, 6))):
+    d2 = GaussianDiffusion(dict(type=kind, **cfg), spec_min=[-5], spec_max=[0])
+    d2.denoise_fn.load_state_dict(sd, strict=True)
+    d2 = d2.to(dev).eval()
+    for B, T, iv in ((1, 37, 100), (2, 113, 334)):
+        feats, x0 = torch.randn(B, T, 256, generator=g).to(dev), torch.randn(B, 128, T, generator=g).to(dev)
+        m = torch.zeros(B, T, dtype=torch.bool, device=dev)
+        m[-1, T - T // 4:] = True
+        for masks in (None, m):
+            mel = d2(feats, sampler_interval=iv, x_init=x0, x_masks=masks, cond_masks=masks)
+            assert torch.isfinite(mel).all()
+            h.update(mel.cpu().numpy().tobytes())
+        mel = d2(feats, sampler_interval=iv, x_init=x0, lengths=[max(1, T - 7 * b) for b in range(B)])
+        h.update(mel.cpu().numpy().tobytes())
 print("DIGEST", h.hexdigest())
 '''
 
