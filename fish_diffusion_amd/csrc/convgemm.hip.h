@@ -1154,12 +1154,13 @@ __global__ __launch_bounds__(256, PRE == PRE_LN ? 2 : 1) void convgemm_kernel(FD
 // ------------------------------------------------------------------------------------------ host launch
 // Tile -> XCD map of the split-K family (small grids).  Row runs fetch the weights once chip-wide and the activation operand once per XCD: right
 // while there are more rows than columns.  With more columns than rows (ConvNext pwconv2, the transformer's linear2 / out-projections at batch 1:
-// 512 rows x 861 columns) 4 row quarters x 2 column halves halve the activation re-reads for 4 x the (smaller) weight reads.  Needs the tile counts
-// to divide; FDX_SPLITK_RECT=0 keeps row runs everywhere (A/B).  A scheduling choice only: results are bit-identical.
+// 512 rows x 861 columns) 4 row quarters x 2 column halves halve the activation re-reads for 4 x the (smaller) weight reads.  Needs the row tiles
+// to divide by 4 (an odd column-tile count pads the launch, round 6); FDX_SPLITK_RECT=0 keeps row runs everywhere (A/B).  A scheduling choice only:
+// results are bit-identical.
 inline int splitk_xcd_rect(int n_tiles_n, int n_mt, long rows, long cols) {
   static const int on = [] { const char* e = getenv("FDX_SPLITK_RECT"); return e ? atoi(e) : 1; }();
   if (!on || cols <= rows) return 0;
-  return ((n_mt & 3) == 0 && (n_tiles_n & 1) == 0 && (long)n_tiles_n * n_mt >= 64) ? 2 : 0;
+  return ((n_mt & 3) == 0 && n_tiles_n >= 2 && (long)n_tiles_n * n_mt >= 64) ? 2 : 0;   // (odd column-tile counts: padded launch, conv_rect_grid)
 }
 
 struct ConvGeom {   // everything the launcher needs besides pointers

@@ -71,7 +71,7 @@ void td_layout(const fdx_tfdec_desc& d, TdLayout& l) {
   for (auto& y : l.layers) plan_declayer(cur, y, D, H, l.folded);
   l.out0 = plan32(cur, D, D);
   if (l.folded) { l.out0_R = cur; cur += (size_t)round_up(D, 64); }
-  l.out2 = plan64(cur, d.mel_channels, D);
+  l.out2 = plan32(cur, d.mel_channels, D);     // (28 workgroups of 64 rows spend 16 k cycles in their K loop: 16 us for 0.1 GFLOP; 56 of 32 rows half that)
   l.total_floats = cur;
 }
 

@@ -7,6 +7,8 @@ few hundred dispatches instead of 45 k: a 4-step UniPC run, eager (no hipGraph),
     python tools/pmc_traffic.py <fetch_db> <write_db> tfdec > profiles/r05_tfdec_pmc_traffic.json
 
   tfdec    TransformerDecoderDenoiser (dim 512 x 12 layers), batch 1 x 861 frames               = bench.py --config tfdec
+  convnext ConvNextDenoiser (dim 512 x 20 blocks), batch 1 x 861 frames                          = bench.py --config convnext  (round 6: the PMC
+           passes over the full command die as well since its graph grew past ~10 k dispatches per run)
   sharded  WaveNet (C = 512 x 20 layers), one exact-ragged micro-batch of 8 utterances, longest 861 frames  = a micro-batch of --config sharded
 """
 import os
@@ -22,12 +24,10 @@ from fish_diffusion_amd import GaussianDiffusion  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "tfdec"
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(4)
-if cfg == "tfdec":
-    from oracle import tfdec_ref  # (seeded weights only)
-    c = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_layers=12)
-    diff = GaussianDiffusion(dict(type="TransformerDecoderDenoiser", **c), spec_min=[-5], spec_max=[0])
-    diff.denoise_fn.load_state_dict(tfdec_ref.seeded_state(1, **c))
-    diff = diff.to(dev).eval()
+if cfg in ("tfdec", "convnext"):
+    from benchkit.flops import CN_CFG, TD_CFG
+    from benchkit.workloads import seeded_denoiser      # the bench's own random-init modules (no oracle import)
+    diff = (seeded_denoiser("TransformerDecoderDenoiser", TD_CFG) if cfg == "tfdec" else seeded_denoiser("ConvNextDenoiser", CN_CFG)).to(dev).eval()
     feats = torch.randn(1, 861, 256, generator=g).to(dev)
     run = lambda: diff(feats, sampler_interval=250)   # noqa: E731
 elif cfg == "sharded":

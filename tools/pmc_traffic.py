@@ -27,7 +27,8 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     cfg = sys.argv[3] if len(sys.argv) > 3 else "headline"
     workloads = {"headline": {"config": "headline", "batch": 1, "frames": 861}, "vocoder": {"config": "vocoder", "batch": 32, "frames": 1722},
-                 "sharded": {"config": "sharded", "batch": 8, "frames": 858},   # rank 0's micro-batch of 8: longest member 858 frames (bench.py's seeded lengths) "ddpm1000": {"config": "ddpm1000", "batch": 16, "frames": 861},
+                 "sharded": {"config": "sharded", "batch": 8, "frames": 858},   # rank 0's micro-batch of 8: longest member 858 frames (bench.py's seeded lengths)
+                 "ddpm1000": {"config": "ddpm1000", "batch": 16, "frames": 861},
                  "ddpm1000_bf16": {"config": "ddpm1000_bf16", "batch": 16, "frames": 861},
                  "ddpm1000_fp16x3": {"config": "ddpm1000_fp16x3", "batch": 16, "frames": 861},
                  "headline_fp16x3": {"config": "headline_fp16x3", "batch": 1, "frames": 861},
