@@ -399,11 +399,22 @@ extern "C" int fdx_refinegan_forward(fdx_handle h, const float* mel, const float
     }
     const dim3 g_ad((len + 255) / 256, B * u.cout), blk(256);
     const size_t cnt = (size_t)B * u.cout * len;
+    // AdaIN noise: injected tensors, or (device-Philox mode) drawn inside the kernel from the same counters k_randn would have used for draw
+    // number `noise_idx` -- no scratch fill, no read-back.  (Needs len % 4 == 0 -- T x a product of the upsampling rates: true for every shipped config; otherwise the scratch path.)
+    const bool inline_rng = !noises && (len & 3) == 0;
+    const dim3 g_ad4((len / 4 + 255) / 256, B * u.cout);
+    auto adain = [&](float* out, const View& xin, const float* wv, int mode) {
+      if (inline_rng) {
+        const int idx = noise_idx++;
+        hipLaunchKernelGGL(k_adain_rng, g_ad4, blk, 0, s, out, xin.p, xin.bs, xin.ld, seed, (uint64_t)idx << 40, wv, u.cout, len, slope, mode, 3.f);
+      } else {
+        hipLaunchKernelGGL(k_adain, g_ad, blk, 0, s, out, xin.p, xin.bs, xin.ld, next_noise(cnt), wv, u.cout, len, slope, mode, 3.f);
+      }
+    };
     for (int br = 0; br < 3; ++br) {
-      hipLaunchKernelGGL(k_adain, g_ad, blk, 0, s, a1.p, xi.p, xi.bs, xi.ld, next_noise(cnt), A + u.ad0[br], u.cout, len, slope, 0, 1.f);
+      adain(a1.p, xi, A + u.ad0[br], 0);
       if (int rc = resblock(h, A, u.res[br], kBranchK[br], u.cout, /*same=*/true, B, len, a1, ra, tm, slope, s)) return rc;
-      hipLaunchKernelGGL(k_adain, g_ad, blk, 0, s, xm.p, ra.p, ra.bs, ra.ld, next_noise(cnt), A + u.ad2[br], u.cout, len, slope,
-                         br == 0 ? 0 : (br == 2 ? 2 : 1), 3.f);
+      adain(xm.p, ra, A + u.ad2[br], br == 0 ? 0 : (br == 2 ? 2 : 1));
     }
     x = xm; x_len = len;
   }

@@ -149,4 +149,39 @@ static __global__ void k_adain(float* __restrict__ out, const float* __restrict_
   out[o] = v;
 }
 
+// The same with the noise drawn IN the kernel (device-Philox mode, no injected tensors): round 5 filled a scratch buffer with k_randn and read it back
+// here -- 96 extra launches and a third of this kernel's traffic per generator pass (k_randn + k_adain = 10 % of the HiFiSinger line).  A thread owns
+// four consecutive frames of one (item, channel) row = exactly one Philox counter of k_randn's stream for this draw (element e = row * L + n, counter
+// offset + e / 4; L is a multiple of 4: every stage length is T x a product of the upsampling rates), so the values are k_randn's, bit for bit
+// (test: the run equals the one with fdx_randn's tensors injected).
+static __global__ void k_adain_rng(float* __restrict__ out, const float* __restrict__ x, long bs, int ld, uint64_t seed, uint64_t offset,
+                                   const float* __restrict__ w, int C, int L, float slope, int mode, float div) {
+  const int n0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (n0 >= L) return;
+  const int b = blockIdx.y / C, c = blockIdx.y - b * C;
+  const long o = b * bs + (long)c * ld + n0;
+  const uint64_t ctr = offset + (((uint64_t)b * C + c) * (uint64_t)L + n0) / 4;
+  uint32_t k[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x66697368u, 0x64782121u};
+  philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float r0 = sqrtf(-2.f * logf(u01(k[0]))), r1 = sqrtf(-2.f * logf(u01(k[2])));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u01(k[1]), &s0, &c0);
+  sincosf(6.283185307179586f * u01(k[3]), &s1, &c1);
+  const float nz[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+  const float4 xv = *reinterpret_cast<const float4*>(x + o);
+  float4 ov = mode ? *reinterpret_cast<const float4*>(out + o) : float4{0.f, 0.f, 0.f, 0.f};
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  float os[4] = {ov.x, ov.y, ov.z, ov.w};
+  const float wc = w[c];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = xs[j] + nz[j] * wc;
+    v = v > 0.f ? v : v * slope;
+    if (mode == 1) v = os[j] + v;
+    else if (mode == 2) v = (os[j] + v) / div;
+    os[j] = v;
+  }
+  *reinterpret_cast<float4*>(out + o) = float4{os[0], os[1], os[2], os[3]};
+}
+
 }  // namespace fdx

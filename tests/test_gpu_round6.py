@@ -206,3 +206,44 @@ def test_ragged_run_of_an_attention_denoiser_needs_the_item_layout(dev):
     assert torch.equal(again, ok)
     dense = diff(feats[:1], sampler_interval=250, x_init=x0[:1])
     assert torch.isfinite(dense).all()
+
+
+# ------------------------------------------------------------------------------------------------ RefineGAN: AdaIN noise drawn inside the kernel
+def test_refinegan_inline_philox_noise_equals_injected_fdx_randn_tensors(dev):
+    """Device-Philox mode of the RefineGAN generator (what `svc_hifisinger_v2`'s bench line runs): since round 6 the AdaIN kernels draw their noise
+    in place from the counters `k_randn` would have used (draw number i at offset i << 40) instead of reading a scratch buffer `k_randn` filled.
+    The waveform must equal, bit for bit, the run with exactly those tensors injected (`fdx_randn`, same seed / offsets)."""
+    import json
+    from fish_diffusion_amd import RefineGANGenerator, _lib
+    from oracle import refinegan_ref
+    g = load("refinegan_small") if "refinegan_small" in _fixtures() else None
+    cfg = json.loads(str(g["config"])) if g is not None else dict(sampling_rate=44100, hop_length=256, downsample_rates=[2, 2, 8, 8], upsample_rates=[8, 8, 2, 2],
+                                                                  leaky_relu_slope=0.2, num_mels=64, start_channels=8)
+    cfg.pop("template_generator", None)                 # comb template: draw 0 is its noise, then two AdaIN draws per (stage, branch)
+    gen = RefineGANGenerator(**cfg)
+    gen.load_folded_state(refinegan_ref.seeded_state(17, cfg))
+    gen = gen.to(dev).eval()
+    B, T = 2, 24
+    gg = torch.Generator().manual_seed(3)
+    mel = (torch.randn(B, cfg["num_mels"], T, generator=gg) * 0.5 - 2.0).to(dev)
+    f0 = synth_f0(T, cfg["sampling_rate"] / cfg["hop_length"])[None].repeat(B, 1).to(dev)
+    gen.rng = "philox"
+    torch.manual_seed(77)
+    a = gen(mel, f0)
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # the wrapper's own draw (refinegan.py: seed of the device generator)
+    eng = gen.engine(dev)
+    noises = []
+    for i, shape in enumerate(gen.noise_shapes(B, T)):
+        t = torch.empty(shape, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().fdx_randn(eng.h, _lib.ptr(t), t.numel(), C.c_uint64(seed), C.c_uint64(i << 40), _lib.stream_ptr(dev)), eng.h)
+        noises.append(t)
+    b = gen(mel, f0, noises=noises)
+    assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
+    assert torch.equal(a, b)
+
+
+def _fixtures():
+    import os
+    from tests.helpers import ROOT
+    return {f[:-4] for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.endswith(".npz")}
