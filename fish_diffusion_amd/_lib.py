@@ -114,6 +114,7 @@ _SIGS = {
     "fdx_mel_filterbank": (C.c_int, [C.POINTER(MelDesc), _P]),
     "fdx_mel_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P]),
     "fdx_mel_stats": (C.c_int, [_P, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)]),
+    "fdx_bcast_arena": (C.c_int, [_P, C.c_size_t, _P, C.c_int, _P]),
     "fdx_refinegan_num_weights": (C.c_int, [C.POINTER(RefineGanDesc)]),
     "fdx_refinegan_num_noises": (C.c_int, [C.POINTER(RefineGanDesc)]),
     "fdx_refinegan_packed_bytes": (C.c_int, [C.POINTER(RefineGanDesc), C.POINTER(C.c_size_t)]),

@@ -56,6 +56,40 @@ extern "C" int fdx_destroy(fdx_handle h) {
   return FDX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ weights over xGMI, without PyTorch
+// SURVEY 8(b) sketched `fdx_bcast_weights(h, rccl_comm, root, stream)`.  The Python host broadcasts the packed arenas with torch.distributed
+// (backend "nccl" = RCCL: dist.py::broadcast_model_weights); a host that is NOT PyTorch creates its own communicator (ncclCommInitRank) and
+// calls this: ONE ncclBroadcast of the arena's bytes.  RCCL is bound at call time (dlopen) -- the library neither links against it nor needs
+// it to load -- and the communicator is the caller's: nothing here owns ranks, rendez-vous or a process group.
+#include <dlfcn.h>
+extern "C" int fdx_bcast_arena(void* dev_arena, size_t bytes, void* rccl_comm, int root, fdx_stream st) {
+  if (!dev_arena || !rccl_comm || root < 0) return fail(nullptr, FDX_E_ARG, "fdx_bcast_arena: null arena / communicator or negative root");
+  if (bytes == 0) return FDX_OK;
+  typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);   // ncclBroadcast (rccl.h:591); ncclResult_t and ncclDataType_t are ints
+  typedef const char* (*err_fn)(int);
+  static bcast_fn bcast = nullptr;
+  static err_fn errstr = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (lib) {
+      bcast = reinterpret_cast<bcast_fn>(dlsym(lib, "ncclBroadcast"));
+      errstr = reinterpret_cast<err_fn>(dlsym(lib, "ncclGetErrorString"));
+    }
+  }
+  if (!bcast) {
+    const char* why = dlerror();
+    return fail(nullptr, FDX_E_NOIMPL, "fdx_bcast_arena: librccl.so (ncclBroadcast) could not be loaded: %s", why ? why : "symbol missing");
+  }
+  const int kNcclUint8 = 1;                                                            // rccl.h:460
+  const int rc = bcast(dev_arena, dev_arena, bytes, kNcclUint8, root, rccl_comm, as_stream(st));
+  if (rc != 0) return fail(nullptr, FDX_E_HIP, "fdx_bcast_arena: ncclBroadcast failed: %s", errstr ? errstr(rc) : "unknown RCCL error");
+  return FDX_OK;
+}
+
 extern "C" const char* fdx_last_error(fdx_handle h) {
   if (h) return h->err.c_str();
   return g_last_error.c_str();

@@ -167,6 +167,16 @@ int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, const uint8
 int fdx_tfdec_forward(fdx_handle h, const float* x, const float* t, int n_t, const uint8_t* x_mask, float* eps, fdx_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Weights over xGMI -- SURVEY 8(b)'s `fdx_bcast_weights`.  The reference's workers each load the checkpoint themselves
+ * (tools/preprocessing/extract_features.py:262-322); here rank `root` packs once (fdx_*_pack) and every rank receives the arena:
+ * ONE ncclBroadcast of `bytes` bytes, in place, on the caller's stream, over a communicator the HOST created (ncclComm_t passed as
+ * void*).  RCCL is bound at call time (dlopen("librccl.so.1")): the library does not link against it.  Every rank then calls
+ * fdx_*_attach on its copy.  (The Python host does the same with torch.distributed.broadcast: dist.py::broadcast_model_weights.)
+ * FDX_E_NOIMPL if librccl cannot be loaded, FDX_E_HIP with RCCL's message if the collective fails.
+ * ---------------------------------------------------------------------------------------------- */
+int fdx_bcast_arena(void* dev_arena, size_t bytes, void* rccl_comm, int root, fdx_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Sampler loop -- replaces GaussianDiffusion.forward's loop, diffusion.py:234-311, and the three
  * predictors (noise_predictor.py:19-222, uni_pc.py:583-818).  The per-step scalars are computed by
  * the host (fish_diffusion_amd/schedule.py mirrors the reference's fp32 arithmetic) and passed as a

@@ -243,6 +243,40 @@ def test_refinegan_inline_philox_noise_equals_injected_fdx_randn_tensors(dev):
     assert torch.equal(a, b)
 
 
+def test_bcast_arena_over_an_rccl_communicator_of_one_rank(dev):
+    """`fdx_bcast_arena`: the C-ABI way to ship rank 0's packed weights (what dist.broadcast_model_weights does through torch.distributed), for
+    a host that is not PyTorch.  One GPU here, so the communicator has one rank (ncclCommInitAll through ctypes: the HOST owns it): the call
+    must bind RCCL at run time, run the collective on the caller's stream and leave the arena's bytes what rank 0 packed; the attached denoiser
+    then runs off that arena."""
+    from fish_diffusion_amd import DENOISERS, _lib
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so.1")
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(dev.index or 0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        net = DENOISERS.build(dict(type="WaveNetDenoiser", **WN_SMALL))
+        net.load_state_dict(wavenet_sd(WN_SMALL, 101), strict=True)
+        net = net.to(dev).eval()
+        arena = net.packed_arena(dev) if hasattr(net, "packed_arena") else None
+        if arena is None:
+            net.engine(dev)
+            arena = net._arena
+        before = arena.clone()
+        _lib.check(_lib.lib().fdx_bcast_arena(_lib.ptr(arena), arena.numel() * arena.element_size(), comm, 0, _lib.stream_ptr(dev)))
+        torch.cuda.synchronize()
+        assert torch.equal(arena, before)
+        g = torch.Generator().manual_seed(2)
+        x, c, t = torch.randn(1, 128, 40, generator=g).to(dev), torch.randn(1, 256, 40, generator=g).to(dev), torch.tensor([300.0], device=dev)
+        assert torch.isfinite(net(x, t, c)).all()
+        with pytest.raises(RuntimeError, match="ncclBroadcast"):        # a root the communicator does not have: RCCL's own error comes back
+            _lib.check(_lib.lib().fdx_bcast_arena(_lib.ptr(arena), 64, comm, 5, _lib.stream_ptr(dev)))
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
 def _fixtures():
     import os
     from tests.helpers import ROOT

@@ -670,3 +670,15 @@ def test_xcd_rect_tile_map_is_a_bijection():
     for n_tiles_n, n_mt in ((14, 16), (8, 32), (7, 3)):      # the row-run map, any shape
         G = n_tiles_n * n_mt
         assert {tile_of_block(n_tiles_n, n_mt, 0, b) for b in range(G)} == {(m, n) for m in range(n_mt) for n in range(n_tiles_n)}
+
+
+def test_bcast_arena_entry_validates_without_a_gpu(lib):
+    """`fdx_bcast_arena` (SURVEY 8(b)'s fdx_bcast_weights): exported, bound to RCCL only at call time, and a null arena / communicator is an
+    argument error -- no GPU, no RCCL needed to find that out (the collective itself: tests/test_gpu_round6.py, a world-1 communicator)."""
+    import ctypes as C
+    from fish_diffusion_amd import _lib
+    with pytest.raises(ValueError, match="fdx_bcast_arena"):
+        _lib.check(_lib.lib().fdx_bcast_arena(None, 16, None, 0, None))
+    buf = (C.c_char * 16)()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().fdx_bcast_arena(C.cast(buf, C.c_void_p), 16, None, 0, None))
