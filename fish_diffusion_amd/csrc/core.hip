@@ -67,23 +67,22 @@ extern "C" int fdx_bcast_arena(void* dev_arena, size_t bytes, void* rccl_comm, i
   if (bytes == 0) return FDX_OK;
   typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);   // ncclBroadcast (rccl.h:591); ncclResult_t and ncclDataType_t are ints
   typedef const char* (*err_fn)(int);
-  static bcast_fn bcast = nullptr;
-  static err_fn errstr = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  struct Rccl { bcast_fn bcast = nullptr; err_fn errstr = nullptr; std::string why; };
+  static const Rccl rccl = [] {                 // (function-local static: bound once, thread-safe)
+    Rccl r;
     void* lib = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
       if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
     if (lib) {
-      bcast = reinterpret_cast<bcast_fn>(dlsym(lib, "ncclBroadcast"));
-      errstr = reinterpret_cast<err_fn>(dlsym(lib, "ncclGetErrorString"));
+      r.bcast = reinterpret_cast<bcast_fn>(dlsym(lib, "ncclBroadcast"));
+      r.errstr = reinterpret_cast<err_fn>(dlsym(lib, "ncclGetErrorString"));
     }
-  }
-  if (!bcast) {
-    const char* why = dlerror();
-    return fail(nullptr, FDX_E_NOIMPL, "fdx_bcast_arena: librccl.so (ncclBroadcast) could not be loaded: %s", why ? why : "symbol missing");
-  }
+    if (!r.bcast) { const char* e = dlerror(); r.why = e ? e : "symbol ncclBroadcast missing"; }
+    return r;
+  }();
+  const bcast_fn bcast = rccl.bcast;
+  const err_fn errstr = rccl.errstr;
+  if (!bcast) return fail(nullptr, FDX_E_NOIMPL, "fdx_bcast_arena: librccl.so (ncclBroadcast) could not be loaded: %s", rccl.why.c_str());
   const int kNcclUint8 = 1;                                                            // rccl.h:460
   const int rc = bcast(dev_arena, dev_arena, bytes, kNcclUint8, root, rccl_comm, as_stream(st));
   if (rc != 0) return fail(nullptr, FDX_E_HIP, "fdx_bcast_arena: ncclBroadcast failed: %s", errstr ? errstr(rc) : "unknown RCCL error");
