@@ -281,3 +281,23 @@ def _fixtures():
     import os
     from tests.helpers import ROOT
     return {f[:-4] for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.endswith(".npz")}
+
+
+# ------------------------------------------------------------------------------------------------ the A/B arms of round 6 stay correct
+@pytest.mark.parametrize("env", [dict(FDX_TD_LNFOLD="0"), dict(FDX_TD_SAIN_RB="2", FDX_TD_LIN1_RB="2"), dict(FDX_CN_LNP="0", FDX_CN_PW1_RB="2"), dict(FDX_CN_PW1_RB="2"),
+                                 dict(FDX_CN_LNP="0")],
+                         ids=["layernorm-launched", "tfdec-64-row-tiles", "convnext-round5", "convnext-lnp-64-row", "convnext-centred-32-row"])
+def test_round6_switches_hold_the_reference_goldens(dev, env):
+    """INTEGRATION.md lists the switches that bring back the round-5 forms (LayerNorm launches, 64-row tiles, ConvNext's group-centred fold): they
+    decide the arena layout, so each arm runs in its own process -- and must hold the same reference goldens as the default (forward of both
+    widening denoisers, small + full net, and the samplers over them)."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    files = [os.path.join(ROOT, "tests", f) for f in ("test_gpu_parity.py", "test_gpu_round2.py")]
+    sel = "(tfdec and golden) or tfdec_ragged" if any(k.startswith("FDX_TD") for k in env) else "convnext and golden"
+    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k", sel], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
