@@ -6,6 +6,7 @@
 #   tools/evidence.sh bench   <tag> <config|default> [VAR=val ...] [-- bench args]   one bench.py line under the given environment -> <tag>/<config>[_VAR-val].json
 #   tools/evidence.sh profile <tag> <config> [steps]          bench line + rocprofv3 kernel stats + the two PMC passes (tools/collect_profiles.sh)
 #   tools/evidence.sh pmcmini <tag> <tfdec|sharded> [VAR=val ...]   FETCH_SIZE / WRITE_SIZE passes over tools/pmc_mini.py (configs whose full bench command kills rocprofv3)
+#   tools/evidence.sh pmc     <tag> <name> "<counters>" [VAR=val ...] -- <command...>   one rocprofv3 --pmc pass (kernel trace only) over any command -> <tag>/<name>_pmc.txt
 #   tools/evidence.sh stats   <tag> <name> [VAR=val ...] -- <command...>   rocprofv3 --kernel-trace --stats of any command -> <tag>/<name>_kernel_stats.txt (+ _sequence.txt)
 #   tools/evidence.sh run     <tag> <name> [VAR=val ...] -- <command...>   any command, stdout+stderr -> <tag>/<name>.txt
 set -u
@@ -52,6 +53,12 @@ for k, v in t["kernels"].items():
     print(k[:90], v["launches"], round(v["hbm_bytes"] / 1e6, 2), "MB")
 PY
     ;;
+  pmc)
+    name=$1; counters=$2; shift 2; take_envs "$@"
+    env "${envs[@]:-FDX_NOP=1}" timeout ${FDX_PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $counters -d /tmp/pmc_${tag}_$name -o pmc -- "${rest[@]}" > $out/${name}_pmc.log 2>&1
+    python tools/prof_summary.py /tmp/pmc_${tag}_$name/pmc_results.db --pmc > $out/${name}_pmc.txt 2>&1
+    rm -rf /tmp/pmc_${tag}_$name
+    grep -E "k_attn_qs|EpiResLN|4, EpiBias|EpiGate|EpiResSkip|EpiScaleRes" $out/${name}_pmc.txt | cut -c1-150 | head -40 ;;
   stats)
     name=$1; shift; take_envs "$@"
     env "${envs[@]:-FDX_NOP=1}" timeout ${FDX_PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag}_$name -o kt -- "${rest[@]}" > $out/${name}.log 2>&1
