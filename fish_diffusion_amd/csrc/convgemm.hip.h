@@ -686,7 +686,8 @@ constexpr int PRE_NONE = 0, PRE_LRELU = 1, PRE_LN = 2, PRE_RESLN = 3, PRE_LNP = 
 // PRE_LNP ("plain"): LayerNorm over K folded into the GEMM with the B operand left as it is: result = rstd[t] (acc - mean[t] rowsum[row]);
 //   `ln_R` = [rows] row sums of the (affine-folded) weights.  One multiply-subtract per output instead of PRE_LN's 16-term group correction (which cost
 //   the transformer's consumers 2-3 us per launch, round 6); exact to rounding while |mean| is not orders of magnitude above the deviation -- a
-//   post-norm transformer's residual stream (LayerNorm output + sublayer); ConvNext's depthwise-conv output keeps the centred form.
+//   post-norm transformer's residual stream (LayerNorm output + sublayer) and, since the same round, ConvNext's depthwise-conv output; measured:
+//   error ~ 5e-7 (1 + |mean| / sigma) of the normalised product (profiles/NOTES.md round 6).  FDX_CN_LNP=0 / FDX_TD_LNFOLD=0 keep the exact forms.
 // PRE_RESLN (EpiResLN only): the column statistics belong to the epilogue's RESIDUAL operand, not to the GEMM's B operand -- same combine stage,
 //   no row-sum correction; the epilogue emits the new value with its own group statistics.
 
