@@ -207,6 +207,9 @@ struct AttnArgs {
 #define FDX_ATTN_COARSE(k) FDX_ATTN_STAMP(k)
 #endif
 
+#ifndef FDX_ATTN_PF
+#define FDX_ATTN_PF 1     // fragment prefetch inside the two products (0 = round 5's loops, kept for the A/B in tools/ubench/attnqs.hip)
+#endif
 // ------------------------------------------------------------------------------------------------ attention, query-split (round 5)
 // Round 4's kernel (k_attn, removed; git history and profiles/r05_attention_ubench_*.txt hold its numbers) gave a workgroup 32 queries and let
 // its four waves split the KEY tiles: every wave streamed its own K / V tiles from global memory into registers, a workgroup read the head's whole
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
   constexpr int VLD = 65;
   constexpr int KT = KS * 128, VT = DH * VLD;          // floats per staged K / V tile (64 keys)
   constexpr int UPT = DH / 16;               // 16-byte fetch units per thread per operand tile (DH rows x 16 units / 256 threads)
+  constexpr int PB = KS >= 8 ? 4 : KS / 2;   // k-steps per prefetched fragment batch of the score product
   __shared__ float lds[2 * (KT + VT)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, n = lane & 31;
@@ -323,6 +327,42 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[rb][r] = 0.f;
+#if FDX_ATTN_PF
+    // fragment reads run ONE BATCH (PB k-steps) ahead of the MFMAs that consume them, and the order is pinned: left to itself hipcc issues a
+    // batch's ds_reads right in front of its first MFMA and the matrix pipe idles for an LDS round trip every 8 MFMAs (4.92 k cycles per
+    // product against 4096 of MFMA issue)
+    if (both) {
+      float fa[2][2 * PB];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) { fa[0][2 * i] = kb[i * 128 + lane]; fa[0][2 * i + 1] = kb[i * 128 + 64 + lane]; }
+#pragma unroll
+      for (int bt = 0; bt < KS / PB; ++bt) {
+        if (bt + 1 < KS / PB) {
+#pragma unroll
+          for (int i = 0; i < PB; ++i) {
+            fa[(bt + 1) & 1][2 * i] = kb[((bt + 1) * PB + i) * 128 + lane];
+            fa[(bt + 1) & 1][2 * i + 1] = kb[((bt + 1) * PB + i) * 128 + 64 + lane];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bt & 1][2 * i], qreg[bt * PB + i], s[0], 0, 0, 0);
+          s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bt & 1][2 * i + 1], qreg[bt * PB + i], s[1], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, PB, 0);          // the first batch's reads
+#pragma unroll
+      for (int bt = 0; bt < KS / PB; ++bt)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          if (bt + 1 < KS / PB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 ds_read2st64 of the next batch
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                         // 2 MFMAs of this one
+        }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[ks * 128 + lane], qreg[ks], s[0], 0, 0, 0);
+    }
+#else
     if (both) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -334,6 +374,7 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[ks * 128 + lane], qreg[ks], s[0], 0, 0, 0);
     }
+#endif
     FDX_ATTN_FINE(4);
     // ---- key mask + online softmax over the key axis (accumulator registers of one lane + one cross-half exchange)
     if (badm != 0ull) {
@@ -370,6 +411,72 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
     }
     const float m_use = m == NEG ? 0.f : m;      // every key so far masked: keep exp2() finite, all weights 0
     float sum = 0.f;
+#if FDX_ATTN_PF
+    // ---- weights + O^T += V P^T, interleaved.  The k-pair of step (rb, r) is the key pair the two lane halves hold in s[rb][r].  V fragments
+    // are read ONE BATCH (4 key pairs) ahead of their MFMAs; only the first 32 keys' exponentials stand in front of the product, the second
+    // 32 keys' ride in the VALU slots between its first 16 RBD MFMAs (same operations on the same values in the same order as the plain loops
+    // below: identical bits).  The order is pinned -- left alone hipcc reads each batch right in front of its first MFMA
+    {
+      float fv[2][4 * RBD];
+      auto ldv2 = [&](float* f, int bt, int i0) __attribute__((always_inline)) {     // key pairs i0, i0 + 1 of batch bt (adjacent keys: one ds_read2 per x)
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i) {
+          const int kl = (bt >> 2) * 32 + acc_row((bt & 3) * 4 + i, half);
+#pragma unroll
+          for (int x = 0; x < RBD; ++x) {
+            const int d = x * 32 + n;
+            f[i * RBD + x] = d < DH ? vb[d * VLD + kl] : 0.f;
+          }
+        }
+      };
+      auto ldv = [&](float* f, int bt) __attribute__((always_inline)) { ldv2(f, bt, 0); ldv2(f, bt, 2); };
+      ldv(fv[0], 0);                              // in flight behind the first exponentials
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[0][r] - m_use);
+        s[0][r] = p;
+        sum += p;
+      }
+      FDX_ATTN_FINE(5);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {           // half batches, fenced: 2 RBD MFMAs behind RBD reads and two keys' exponentials
+          ldv2(fv[(bt + 1) & 1], bt + 1, 2 * hb);
+#pragma unroll
+          for (int i = 2 * hb; i < 2 * hb + 2; ++i) {   // (a half tile's second 32 keys are all masked: -inf -> weight 0, as in the plain loop)
+            const float p = __builtin_amdgcn_exp2f(s[1][bt * 4 + i] - m_use);
+            s[1][bt * 4 + i] = p;
+            sum += p;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 2 * hb; i < 2 * hb + 2; ++i)
+#pragma unroll
+            for (int x = 0; x < RBD; ++x) o[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[bt & 1][i * RBD + x], s[0][bt * 4 + i], o[x], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (both) {
+#pragma unroll
+        for (int bt = 4; bt < 8; ++bt) {
+          if (bt + 1 < 8) ldv(fv[(bt + 1) & 1], bt + 1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int x = 0; x < RBD; ++x) o[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[bt & 1][i * RBD + x], s[1][(bt & 3) * 4 + i], o[x], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2 * RBD; ++i) {
+            if (bt + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+        }
+      }
+      sum += __shfl_xor(sum, 32);
+      l += sum;
+    }
+#else
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -396,6 +503,7 @@ __global__ __launch_bounds__(256) void k_attn_qs(AttnArgs a) {
         }
       }
     }
+#endif
     FDX_ATTN_FINE(6);
     if (more) {
       stage(lds + ((kt + 1) & 1) * (KT + VT), k0 + 64);
