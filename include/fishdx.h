@@ -16,11 +16,15 @@
  *     synchronises the device inside *_forward / *_run.  Buffers grow only in *_prepare / first call
  *     with a new geometry.
  *   - all arithmetic is fp32 (f32-in/f32-acc MFMA), activations are [B][C][T] with T contiguous.
- *   - multi-GPU: there is deliberately no collective in this ABI.  The packed arenas (fdx_*_pack) are plain byte blobs;
- *     rank 0 packs, `torch.distributed.broadcast` (RCCL) ships them, every rank calls fdx_*_attach
- *     (fish_diffusion_amd/dist.py).  The path itself has no exchange step.
+ *   - multi-GPU: the data path has no collective (utterances shard, nothing is exchanged).  The packed arenas
+ *     (fdx_*_pack) are plain byte blobs; rank 0 packs, every rank calls fdx_*_attach.  Shipping them is the host's business:
+ *     `torch.distributed.broadcast` (RCCL) in fish_diffusion_amd/dist.py, or -- for a host that is not PyTorch --
+ *     fdx_bcast_arena below, ONE ncclBroadcast over a communicator the host created.
  *   - a handle is NOT re-entrant: one in-flight call per handle (the Python wrapper holds a lock;
  *     the reference's flask_api.py:86 can call forward from several threads).
+ *   - a handle's workspaces and cached tables are reused from call to call and are ordered by the STREAM the calls are enqueued
+ *     on: consecutive calls on one handle that use different streams must be ordered by the caller (event / stream wait), as
+ *     for any buffer shared between streams.  Independent streams want independent handles (pipeline.py's vocoder lanes).
  */
 #ifndef FISHDX_H_
 #define FISHDX_H_
