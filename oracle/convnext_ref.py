@@ -3,9 +3,9 @@
 Functional restatement (state-dict in, tensor out) of fish_diffusion/modules/convnext.py:
   ``ConvNeXtBlock.forward`` :56-92, ``CrossAttentionBlock.forward`` :127-152 and ``ConvNext.forward`` :211-262, registered as
   DENOISERS "ConvNextDenoiser" (archs/diffsinger/diffusions/builder.py:12).  Same call contract as the WaveNet denoiser.
-Pinned against the real module by oracle/make_golden.py: bit-exact for ``cross_attention=False``; with cross-attention to the
-same 3e-6 abs as oracle/tfdec_ref.py (torch's fused CPU attention groups its sums differently from the plain formula; the
-goldens hold the REAL module's outputs).
+Pinned against the real module by oracle/make_golden.py: bit-exact with and without ``cross_attention`` (since round 6 the
+attention of a CrossAttentionBlock is evaluated in torch's own operation order, oracle/tfdec_ref.py::mha; the goldens hold the
+REAL module's outputs).
 """
 from __future__ import annotations
 

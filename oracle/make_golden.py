@@ -57,6 +57,19 @@ FIXTURE_SECTIONS = (("convnext_cross", "convnext_cross"), ("convnext", "convnext
                     ("nsf_rb2_", "round5"), ("mel_filterbank_hf", "round5"), ("sharded_c3_microbatch", "round6"))
 
 
+def host_signature():
+    """What fp32 CPU bits depend on besides the torch build: the CPU model (the BLAS picks its kernels by ISA) and the thread count.  Tests that
+    assert BIT equality of an oracle against a fixture run only where this matches (tests/test_oracle_golden.py); everywhere else they hold
+    the tolerance."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"cpu": model, "threads": torch.get_num_threads()}
+
+
 def write_manifest():
     """tests/golden/MANIFEST.json: every fixture with its generating section, byte size, SHA-256 and array shapes -- checked by
     tests/test_oracle_golden.py::test_golden_manifest_lists_every_fixture, so a fixture cannot change or appear unrecorded."""
@@ -74,7 +87,7 @@ def write_manifest():
         entries[name] = {"section": f"python -m oracle.make_golden{'' if section == 'main' else ' ' + section}", "bytes": len(blob),
                          "sha256": hashlib.sha256(blob).hexdigest(), "arrays": arrays}
     manifest = {"generator": "oracle/make_golden.py (runs the REAL reference from /root/reference on seeded inputs; asserts oracle == reference)",
-                "torch": torch.__version__, "numpy": np.__version__, "fixtures": entries}
+                "torch": torch.__version__, "numpy": np.__version__, "host": host_signature(), "fixtures": entries}
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print(f"  wrote MANIFEST.json ({len(entries)} fixtures)")
@@ -315,9 +328,10 @@ TD_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_l
 @torch.no_grad()
 def golden_tfdec(R):
     """TransformerDecoderDenoiser: forward + the sampler loop driving it, outputs from the real reference
-    classes.  The restatement is asserted CLOSE (3e-6 abs), not equal: torch's fused attention groups its sums differently."""
+    classes.  The restatement is asserted EQUAL since round 6: oracle/tfdec_ref.py::mha evaluates attention in the operation order torch's
+    own MultiheadAttention takes (native fast path for self-attention, multi_head_attention_forward -> sdpa for cross-attention)."""
     print("transformer-decoder denoiser")
-    close = lambda a, b: float((a - b).abs().max()) <= 3e-6 * max(1.0, float(b.abs().max()))
+    close = torch.equal
 
     def oracle_den(sd, cfg):
         return lambda x, t, c, xm, cm: tfdec_ref.tfdec_forward(sd, x, t, c, xm, cm, num_layers=cfg["num_layers"])
@@ -338,6 +352,7 @@ def golden_tfdec(R):
         den = oracle_den(sd, cfg)
         assert close(den(x, t, cond, None, None), eps), "oracle TransformerDecoderDenoiser != reference"
         assert close(den(x, t, cond, masks, masks), eps_masked), "oracle TransformerDecoderDenoiser (masked) != reference"
+        assert close(den(x, torch.tensor([400], dtype=torch.long), cond, None, None), eps_long), "oracle TransformerDecoderDenoiser (long t) != reference"
         # (the sin/cos table is recomputed by whoever regenerates the weights: a different host CPU's vectorised sin / cos may
         # differ in the last bit, so it is left out of the fingerprint)
         arrays = dict(x=x, cond=cond, t=t, masks=masks, eps=eps, eps_masked=eps_masked, eps_long=eps_long, seed=np.int64(seed),
@@ -363,7 +378,7 @@ def golden_tfdec(R):
         step_noise = torch.stack([torch.randn(B, 128, T) for _ in range(n)]) if pred == "naive" else torch.zeros(0)
         mine = sampler_ref.diffusion_sample(den, feats, x_init=x_init, sampler_interval=interval, predictor=pred,
                                             step_noise=step_noise, x_masks=masks, cond_masks=masks)
-        assert float((mine - ref).abs().max()) < 1e-3 * float(ref.abs().max()), f"oracle sampler over tfdec {pred} != reference"
+        assert torch.equal(mine, ref), f"oracle sampler over tfdec {pred} != reference"
         save(f"tfdec_sampler_small_{pred}_i{interval}", features=feats, masks=masks, x_init=x_init, step_noise=step_noise, mel=ref,
              interval=np.int64(interval))
 
@@ -376,7 +391,7 @@ CNX_FULL = dict(mel_channels=128, dim=512, mlp_factor=4, condition_dim=256, num_
 def golden_convnext_cross(R):
     """ConvNext(cross_attention=True) (convnext.py:95-152,186-193,246-250): forward (small / full-size, masked, long t) and the
     reference's sampler loop driving it (UniPC / PLMS with masks: PLMS's one unmasked call sees the unmasked condition as the
-    attention memory).  Outputs from the real classes; the oracle restatement is pinned to 3e-6 abs (attention, see tfdec)."""
+    attention memory).  Outputs from the real classes; the oracle restatement is asserted EQUAL (attention evaluated as torch does, see tfdec)."""
     print("convnext, cross-attention variant")
     EVERY = 5
 
@@ -387,8 +402,7 @@ def golden_convnext_cross(R):
     def shapes_kw(cfg):
         return dict({k: v for k, v in cfg.items() if k != "dilation_cycle"}, cross_every=EVERY)
 
-    def close(a, b, tol=5e-6):
-        return float((a - b).abs().max()) < tol
+    close = torch.equal
 
     for tag, cfg, seed, (B, T) in (("small", CNX_SMALL, 311, (2, 50)), ("full", CNX_FULL, 4331, (2, 96))):
         sd = convnext_ref.seeded_state(seed, **shapes_kw(cfg))
@@ -427,7 +441,7 @@ def golden_convnext_cross(R):
         torch.manual_seed(seed)
         x_init = torch.randn(B, 128, T)
         mine = sampler_ref.diffusion_sample(den, feats, x_init=x_init, sampler_interval=interval, predictor=pred, x_masks=masks, cond_masks=masks)
-        assert rel(mine, ref) < 1e-4, f"oracle sampler over ConvNext(cross) {pred}/{interval} != reference: {rel(mine, ref)}"
+        assert torch.equal(mine, ref), f"oracle sampler over ConvNext(cross) {pred}/{interval} != reference: {rel(mine, ref)}"
         save(f"convnext_cross_sampler_small_{pred}_i{interval}", features=feats, masks=masks, x_init=x_init, mel=ref, interval=np.int64(interval))
 
 

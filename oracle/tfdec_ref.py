@@ -7,9 +7,10 @@ registered as DENOISERS "TransformerDecoderDenoiser" (archs/diffsinger/diffusion
     x = norm1(x + self_attn(x, x, x, key_padding_mask=tgt_kpm));  x = norm2(x + mha(x, mem, mem, key_padding_mask=mem_kpm));
     x = norm3(x + linear2(gelu(linear1(x))))          (eval mode: every dropout is the identity)
 with multi-head attention = softmax(q k^T / sqrt(d_head) + (-inf at masked keys)) v per head, packed in_proj.
-Pinned against the real module (real nn.TransformerDecoderLayer instances) by oracle/make_golden.py -- to within 3e-6 abs
-(1e-6 rel), not bit-for-bit: torch's fused CPU attention kernel groups the softmax / value sums differently from the plain
-formula above.  The golden fixtures hold the REAL module's outputs.
+Pinned against the real module (real nn.TransformerDecoderLayer instances) by oracle/make_golden.py -- BIT FOR BIT since round 6
+(rounds 1-5: 3e-6 abs): `mha` below evaluates the formula above in the operation order torch's MultiheadAttention itself takes
+(matmul-then-bias projections, pre-scaled q, the fused masked softmax, sdpa for cross-attention), forwards and 50-100-step sampler
+runs alike.  The golden fixtures hold the REAL module's outputs.
 """
 from __future__ import annotations
 
@@ -77,24 +78,45 @@ def seeded_state(seed: int, **cfg) -> SD:
 
 
 def mha(sd: SD, p: str, q_in, kv_in, key_padding_mask: Optional[torch.Tensor]):
-    """nn.MultiheadAttention(batch_first=True, packed in_proj), eval: q_in [B, Tq, D], kv_in [B, Tk, D]."""
+    """nn.MultiheadAttention(batch_first=True, packed in_proj), eval, no grad: q_in [B, Tq, D], kv_in [B, Tk, D].
+
+    Restated operation by operation in the form torch itself evaluates it (torch/nn/modules/activation.py MultiheadAttention.forward and
+    torch/nn/functional.py multi_head_attention_forward; the golden run is under no_grad), because fp32 results depend on it:
+      * self-attention (query is key is value) takes the native fast path (`torch._native_multi_head_attention`): ONE packed projection as
+        matmul-then-bias, q scaled by 1 / sqrt(d_head) BEFORE the product, softmax over the keys -- through `torch._masked_softmax`
+        (mask_type 1 = key padding) when a padding mask is given: that kernel sums a row sequentially in double, `softmax(masked_fill(-inf))`
+        sums in vector lanes -- then attn @ v and the out-projection as addmm;
+      * cross-attention goes through `F.multi_head_attention_forward`: inputs transposed to [T, B, D] views, q and the packed (k, v)
+        projections again matmul-then-bias (what `F.linear` does for a non-contiguous 3-D input and a parameter), the padding mask as an
+        additive float mask into `F.scaled_dot_product_attention`, out-projection as addmm on [Tq * B, D].
+    (`addmm` and matmul-then-bias round differently; so do the fused and the plain softmax.)  In this form the restatement equals the real
+    module BIT FOR BIT on the torch build the fixtures were made with -- oracle/make_golden.py asserts it, tests/test_oracle_golden.py re-checks
+    equality on that build and 1e-5 rel on any other."""
     D = q_in.shape[-1]
     W, b = sd[p + "in_proj_weight"], sd[p + "in_proj_bias"]
-    q = F.linear(q_in, W[:D], b[:D])
-    k = F.linear(kv_in, W[D:2 * D], b[D:2 * D])
-    v = F.linear(kv_in, W[2 * D:], b[2 * D:])
-    B, Tq, _ = q.shape
-    Tk = k.shape[1]
+    B, Tq, _ = q_in.shape
+    Tk = kv_in.shape[1]
     dh = D // NHEAD
-    q = q.view(B, Tq, NHEAD, dh).transpose(1, 2)
-    k = k.view(B, Tk, NHEAD, dh).transpose(1, 2)
-    v = v.view(B, Tk, NHEAD, dh).transpose(1, 2)
-    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    if q_in is kv_in:
+        qkv = (q_in.reshape(B * Tq, D) @ W.t()).view(B, Tq, 3 * D) + b
+        q, k, v = (c.reshape(B, Tq, NHEAD, dh).transpose(1, 2) for c in qkv.chunk(3, dim=-1))
+        s = (q * (1.0 / math.sqrt(dh))) @ k.transpose(-1, -2)
+        a = torch.softmax(s, dim=-1) if key_padding_mask is None else torch._masked_softmax(s, key_padding_mask, 3, 1)
+        o = (a @ v).transpose(1, 2).reshape(B, Tq, D)
+        return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+    qt, kt = q_in.transpose(1, 0), kv_in.transpose(1, 0)
+    q = (qt.reshape(Tq * B, D) @ W[:D].t()).view(Tq, B, D) + b[:D]
+    kv = (kt.reshape(Tk * B, D) @ W[D:].t()).view(Tk, B, 2 * D) + b[D:]
+    kv = kv.unflatten(-1, (2, D)).unsqueeze(0).transpose(0, -2).squeeze(-2).contiguous()
+    q = q.view(Tq, B * NHEAD, dh).transpose(0, 1).view(B, NHEAD, Tq, dh)
+    k = kv[0].view(Tk, B * NHEAD, dh).transpose(0, 1).view(B, NHEAD, Tk, dh)
+    v = kv[1].view(Tk, B * NHEAD, dh).transpose(0, 1).view(B, NHEAD, Tk, dh)
+    mask = None
     if key_padding_mask is not None:
-        s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
-    o = torch.softmax(s, dim=-1) @ v
-    o = o.transpose(1, 2).reshape(B, Tq, D)
-    return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+        mask = torch.zeros(B, 1, 1, Tk, dtype=q.dtype).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).expand(-1, NHEAD, -1, -1)
+    o = F.scaled_dot_product_attention(q, k, v, mask, 0.0, False)
+    o = o.permute(2, 0, 1, 3).contiguous().view(Tq * B, D)
+    return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"]).view(Tq, B, D).transpose(1, 0)
 
 
 def decoder_layer(sd: SD, i: int, x, mem, x_masks, cond_masks):
