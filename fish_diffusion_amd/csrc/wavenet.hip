@@ -868,7 +868,10 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       continue;
     }
     {  // dilated conv k = 3 + gate (wavenet.py:107-115): 64 x 64 round-1 tile, or the shape picked for this geometry
-      const ConvGeom g4{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles}, g2{B, T, l.conv[i].cin8, 3, -dil, dil, 2 * l.conv[i].n_mtiles};
+      // FDX_PROBE_TAPS=2 (TIMING PROBE, results wrong by construction): the launch walks 2 taps instead of 3 -- two thirds of the MFMAs at the operand
+      // loads a Winograd F(2, 3) K loop over the dilated axis would issue (NOTES round 6).  Never set outside tools/evidence.sh runs.
+      static const int probe_taps = [] { const char* e = getenv("FDX_PROBE_TAPS"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+      const ConvGeom g4{B, T, l.conv[i].cin8, probe_taps, -dil, dil, l.conv[i].n_mtiles}, g2{B, T, l.conv[i].cin8, probe_taps, -dil, dil, 2 * l.conv[i].n_mtiles};
       const int NRs = h->conv_shape_nr, NMs = h->conv_shape_nm;
       if (NRs == 4 && NMs == 4) {
         EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
