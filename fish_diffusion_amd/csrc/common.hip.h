@@ -163,11 +163,6 @@ struct fdx_ctx {
   fdx::DevBuf wn_nr2;                    // dilated-conv weights in the NR = 2 fragment order (convgemm16s.hip.h), derived at attach
   std::vector<size_t> wn_nr2_off;        // per layer, in floats
   int conv_shape_nr = 4, conv_shape_nm = 4;   // tile shape of the dilated conv + gate for the prepared geometry
-  // opt-in (FDX_WN_WINO=1, read at attach): the dilated conv as a Winograd F(2, 3) contraction over the dilated axis (convwino16.hip.h)
-  bool wn_wino = false;
-  fdx::DevBuf wn_wino_w;                 // the four transformed weight sets per layer, derived at attach
-  std::vector<size_t> wn_wino_off;
-  int wino_np = 4;                       // pairs per lane of the prepared geometry (tile = 32 x 32 NP)
   fdx::DevBuf wn_outp16;                 // out-projection weights in the 16x16x4 orders (NR = 4 and NR = 2), derived at attach
   std::vector<size_t> wn_outp16_off4, wn_outp16_off2, wn_outp16_off1;
   int outp_shape_nr = 4, outp_shape_nm = 4;   // tile shape of the out-projection for the prepared geometry

@@ -54,13 +54,8 @@ template <int N> __device__ __forceinline__ RawN<N> ldRaw(const float* p) {
 
 // N adjacent floats at any dword alignment (sources are the library's own padded rows: >= kTailPad floats of slack right of T)
 template <int N> __device__ __forceinline__ VecN<N> ldN(const float* p) {
-  static_assert(N == 2 || (N >= 4 && N <= 8), "2 (convwino16.hip.h) or 4..8 columns per lane");
+  static_assert(N >= 4 && N <= 8, "4..8 columns per lane");
   VecN<N> r;
-  if constexpr (N == 2) {
-    const f2u b = *reinterpret_cast<const f2u*>(p);
-    r.v[0] = b.x; r.v[1] = b.y;
-    return r;
-  } else {
   const f4u a = *reinterpret_cast<const f4u*>(p);
   r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
   if constexpr (N == 5) { r.v[4] = p[4]; }
@@ -68,7 +63,6 @@ template <int N> __device__ __forceinline__ VecN<N> ldN(const float* p) {
   if constexpr (N == 7) { const f3u b = *reinterpret_cast<const f3u*>(p + 4); r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; }
   if constexpr (N == 8) { const f4u b = *reinterpret_cast<const f4u*>(p + 4); r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w; }
   return r;
-  }
 }
 // store into a padded row: columns >= T (at most N-1, inside the right pad) receive 0 -- what the pad must hold anyway.
 // NT: non-temporal (tiles read next by other XCDs), else normal caching (tiles the same workgroup re-reads next layer).
@@ -83,10 +77,7 @@ template <int N, bool NT> __device__ __forceinline__ void stNp(float* p, VecN<N>
 #else
   constexpr bool kNT = NT;
 #endif
-  if constexpr (N == 2) {
-    if constexpr (kNT) __builtin_nontemporal_store(f2nt{v.v[0], v.v[1]}, reinterpret_cast<f2nt*>(p));
-    else { f2u b; b.x = v.v[0]; b.y = v.v[1]; *reinterpret_cast<f2u*>(p) = b; }
-  } else if constexpr (kNT) {
+  if constexpr (kNT) {
     __builtin_nontemporal_store(f4nt{v.v[0], v.v[1], v.v[2], v.v[3]}, reinterpret_cast<f4nt*>(p));
     if constexpr (N == 5) __builtin_nontemporal_store(v.v[4], p + 4);
     if constexpr (N == 6) __builtin_nontemporal_store(f2nt{v.v[4], v.v[5]}, reinterpret_cast<f2nt*>(p + 4));

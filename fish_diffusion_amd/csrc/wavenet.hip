@@ -15,7 +15,6 @@
 #include "common.hip.h"
 #include "elementwise.hip.h"
 #include "convgemm16s.hip.h"
-#include "convwino16.hip.h"
 #include "bf16lds.hip.h"
 #include "f16s64.hip.h"
 
@@ -30,17 +29,6 @@ using namespace fdx;
 // 128-row MT = 2 tiles behind FDX_MT2_MIN_TILES: measured slower, removed in round 4 -- profiles/NOTES.md.)
 // Shape-adaptive tiles for the dilated conv + gate (convgemm16s.hip.h).  FDX_CONV_SHAPE=<NR><NM> (e.g. 27; 44 = the round-1 64 x 64 tile) forces
 // one shape: the tile-shape bit-identity test runs every shape in its own process.
-// FDX_WN_WINO=1 (opt-in, round 6): the dilated conv + gate of the fp32 path runs as a Winograd F(2, 3) contraction (convwino16.hip.h): two thirds
-// of the MFMAs, fp32 throughout, different rounding from the direct sum (every parity bar holds; results are bit-identical across its own tile
-// shapes and between an exact-ragged item and its batch-1 run when items start at multiples of 32 frames).  FDX_WINO_NP=2|4 forces a tile width.
-static bool wino_env() {
-  static const bool v = [] { const char* e = getenv("FDX_WN_WINO"); return e && atoi(e) != 0; }();
-  return v;
-}
-static int wino_np_env() {
-  static const int v = [] { const char* e = getenv("FDX_WINO_NP"); return e ? atoi(e) : 0; }();
-  return v;
-}
 static int conv_shape_env() {
   static const int v = [] { const char* e = getenv("FDX_CONV_SHAPE"); return e ? atoi(e) : -1; }();
   return v;
@@ -226,25 +214,6 @@ extern "C" int fdx_wavenet_attach(fdx_handle h, const fdx_wavenet_desc* d, const
       hipLaunchKernelGGL(k_repack16_nr2, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, nullptr, reinterpret_cast<float2*>(h->wn_nr2.f() + cur),
                          reinterpret_cast<const float4*>(h->wn_arena + p.w_off), n_src, p.cin8 * p.taps, 1);
       cur += n_src * 4;
-    }
-    // opt-in Winograd form of the dilated conv (convwino16.hip.h): U0 .. U3 from the NR = 2 order just written
-    h->wn_wino = wino_env();
-    if (h->wn_wino) {
-      for (const auto& p : l.conv)
-        if (p.taps != 3) return fail(h, FDX_E_ARG, "FDX_WN_WINO=1 needs kernel_size 3");
-      size_t tot = 0;
-      for (const auto& p : l.conv) tot += wino_floats(2 * p.n_mtiles, p.cin8);
-      FDX_HIP(h, h->wn_wino_w.ensure(tot * sizeof(float), false, nullptr));
-      h->wn_wino_off.clear();
-      size_t c = 0;
-      for (size_t i = 0; i < l.conv.size(); ++i) {
-        const auto& p = l.conv[i];
-        const size_t n_slots = (size_t)2 * p.n_mtiles * p.cin8 * 2 * 64;
-        h->wn_wino_off.push_back(c);
-        hipLaunchKernelGGL(k_repack_wino, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, nullptr, h->wn_wino_w.f() + c,
-                           reinterpret_cast<const float2*>(h->wn_nr2.f() + h->wn_nr2_off[i]), n_slots, p.cin8);
-        c += n_slots * 8;
-      }
     }
     // the out-projection (packed in the generic 32x32x2 order) in the three 16x16x4 orders
     {
@@ -673,11 +642,6 @@ static int wn_alloc(fdx_ctx* h, int B, int T, hipStream_t s) {
     if (forced > 0) sh = Shape16{forced / 10, forced % 10};
     if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8) sh = Shape16{4, 4};
     h->conv_shape_nr = sh.NR; h->conv_shape_nm = sh.NM;
-    if (h->wn_wino) {   // 32 x 128 tiles when they give a round of the chip something to do on every CU's worth of rows, else 32 x 64
-      const long wg128 = (long)(rows16 / 2) * B * ((T + 127) / 128);
-      h->wino_np = wg128 >= 200 ? 4 : 2;
-      if (wino_np_env() == 2 || wino_np_env() == 4) h->wino_np = wino_np_env();
-    }
     // the out-projection (rows = 2C, K = C: 16 iterations per K-splitting wave) runs on the same 16x16x4 family for EVERY geometry,
     // so that an item's result does not depend on the batch it rode in
     Shape16 so{4, 4};
@@ -838,9 +802,6 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
         h->prof.note(PROF_WN_CONVGATE, "convgemm16s_kernel<EpiGate16S<%d>, %d, %d> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, %ld workgroups)",
                      h->conv_shape_nm, h->conv_shape_nr, h->conv_shape_nm, 16 * h->conv_shape_nr, 16 * h->conv_shape_nm,
                      (long)B * ((T + 16 * h->conv_shape_nm - 1) / (16 * h->conv_shape_nm)) * (2 * C / (16 * h->conv_shape_nr)));
-      if (h->wn_wino)
-        h->prof.note(PROF_WN_CONVGATE, "convwino16_kernel<EpiGate16S<%d>, %d> (Winograd F(2,3) over the dilated axis on v_mfma_f32_16x16x4_f32; 32 x %d split-K workgroup tile, %ld workgroups)",
-                     h->wino_np, h->wino_np, 32 * h->wino_np, (long)B * ((T + 32 * h->wino_np - 1) / (32 * h->wino_np)) * (2 * C / 32));
       h->prof.note(PROF_WN_OUTPROJ, "convgemm16s_kernel<EpiResSkip16S<%d>, %d, %d> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, %ld workgroups)",
                    h->outp_shape_nm, h->outp_shape_nr, h->outp_shape_nm, 16 * h->outp_shape_nr, 16 * h->outp_shape_nm,
                    (long)B * ((T + 16 * h->outp_shape_nm - 1) / (16 * h->outp_shape_nm)) * (2 * C / (16 * h->outp_shape_nr)));
@@ -907,22 +868,9 @@ static int wn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, co
       continue;
     }
     {  // dilated conv k = 3 + gate (wavenet.py:107-115): 64 x 64 round-1 tile, or the shape picked for this geometry
-      // FDX_PROBE_TAPS=2 (TIMING PROBE, results wrong by construction): the launch walks 2 taps instead of 3 -- two thirds of the MFMAs at the operand
-      // loads a Winograd F(2, 3) K loop over the dilated axis would issue (NOTES round 6).  Never set outside tools/evidence.sh runs.
-      static const int probe_taps = [] { const char* e = getenv("FDX_PROBE_TAPS"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
-      const ConvGeom g4{B, T, l.conv[i].cin8, probe_taps, -dil, dil, l.conv[i].n_mtiles}, g2{B, T, l.conv[i].cin8, probe_taps, -dil, dil, 2 * l.conv[i].n_mtiles};
+      const ConvGeom g4{B, T, l.conv[i].cin8, 3, -dil, dil, l.conv[i].n_mtiles}, g2{B, T, l.conv[i].cin8, 3, -dil, dil, 2 * l.conv[i].n_mtiles};
       const int NRs = h->conv_shape_nr, NMs = h->conv_shape_nm;
-      if (h->wn_wino) {
-        const ConvGeom gw{B, T, l.conv[i].cin8, 1, -dil, dil, 2 * l.conv[i].n_mtiles};
-        const void* U = h->wn_wino_w.f() + h->wn_wino_off[i];
-        if (h->wino_np == 4 && (dil <= 2 || dil % 4 == 0)) {
-          const EpiGate16S<4> gs{Z, bsC, ld, Pl, p_bs, ld, C};
-          FDX_HIP(h, (launch_convwino16<EpiGate16S, 4>(gw, U, Y, bsC, ld, gs, s, ev0, ev1)));
-        } else {
-          const EpiGate16S<2> gs{Z, bsC, ld, Pl, p_bs, ld, C};
-          FDX_HIP(h, (launch_convwino16<EpiGate16S, 2>(gw, U, Y, bsC, ld, gs, s, ev0, ev1)));
-        }
-      } else if (NRs == 4 && NMs == 4) {
+      if (NRs == 4 && NMs == 4) {
         EpiGate16 g{Z, bsC, ld, Pl, p_bs, ld, C};
         FDX_HIP(h, launch_convgemm16(g4, reinterpret_cast<const float4*>(A + l.conv[i].w_off), Y, bsC, ld, g, s, ev0, ev1));
       } else {
