@@ -175,19 +175,48 @@ template <int NM> struct EpiResSkip16S {  // wavenet.py:117-120 + the skip sum o
   }
 };
 
+// out = act(acc + bias[row]) for NM adjacent columns (EpiBias of convgemm.hip.h, the part the K = 512 GEMMs of the widening denoisers use: no
+// mask, no second output).  The result is the next GEMM's B operand, read by every XCD: non-temporal stores.
+template <int NM> struct EpiBiasAct16S {
+  static constexpr bool kPaired = false;
+  float* out; long o_bs; int ldo;
+  const float* bias;
+  int act;
+  struct Pre { float bias; };
+  __device__ __forceinline__ Pre load(int /*b*/, int row, int /*t*/) const { return Pre{bias[row]}; }
+  __device__ __forceinline__ void store(int b, int row, int t, int nvalid, VecN<NM> v, const Pre& p) const {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      float y = v.v[m] + p.bias;
+      if (act == ACT_RELU) y = fmaxf(y, 0.f);
+      else if (act == ACT_MISH) y = mish_f(y);
+      else if (act == ACT_GELU) y = gelu_f(y);
+      v.v[m] = y;
+    }
+    stNp<NM, true>(out + b * o_bs + (long)row * ldo + t, v, nvalid);
+  }
+};
+
 // ------------------------------------------------------------------------------------------ kernel
 // Packed A: NR = 4: [m64-tile][it][h][lane] float4 (pack_convgemm16);  NR = 2: [m32-tile][it][h][lane] float2 (k_repack16_nr2);
 // NR = 1 (out-projection only): [m16-tile][it][h][lane] float (k_repack16_from32<1>) -- 16 x (16 NM) tiles, twice the workgroups of NR = 2.
 // Paired epilogues: blocks 0 .. NR/2-1 hold the tile's gate rows (16 channels each), blocks NR/2 .. NR-1 the matching filter rows.
 // (An LDS-staged operand path for this K loop -- per-wave LDS-DMA rings, asm-sequenced MFMA / ds_read stream -- was built and measured in
 // round 3: bit-identical, fewer cycles per wave, LONGER launches (26.6 vs 25.2 us); removed in round 4, see profiles/NOTES.md and commit 7078c9b.)
-template <class Epi, int NR, int NM>
+// PRE = PRE_LNP (round 6, second session: the K = 512 GEMMs of the ConvNext block on this family): LayerNorm over K folded in with the B operand
+// left as it is -- result = rstd[t] (acc - mean[t] rowsum[row]) in front of the epilogue, exactly convgemm.hip.h's PRE_LNP: a.col_stats =
+// [item][T][2][16] group means / M2s (combined per column ONCE per workgroup, same arithmetic), a.ln_R = [rows] row sums of the folded weights.
+template <class Epi, int NR, int NM, int PRE = PRE_NONE>
 __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, ConvArgsCold cold, Epi epi) {
   FDX_CONV_ARGS_FROM_HOT(cold);
   static_assert(NR == 2 || NR == 4 || (NR == 1 && !Epi::kPaired), "1 (unpaired epilogues only), 2 or 4 row blocks");
+  static_assert(PRE == PRE_NONE || (PRE == PRE_LNP && !Epi::kPaired), "plain, or PRE_LNP with an unpaired epilogue");
   constexpr int NW = 4, COLS = 16 * NM, STR = NM <= 4 ? 4 : 8;      // LDS stride (floats) of a lane's NM partial sums
   a.tiles_per_item = (a.T + COLS - 1) / COLS;
   __shared__ float red[NW * NR * 4 * kWave * STR];                  // [wave][x*4 + reg][lane][m]
+  constexpr bool kLnp = PRE == PRE_LNP;
+  constexpr int LNPASS = (COLS + 63) / 64;                          // 4 threads per column, 64 columns per pass
+  __shared__ float ln_cols[kLnp ? COLS * 2 : 1];                    // per column of the tile: mean, rstd
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -212,10 +241,51 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
   static_assert(NS >= 1, "at least one site per wave");
   auto site_row = [&](int sidx) { return row_base + (sidx >> 2) * 16 + lk * 4 + (sidx & 3); };
   typename Epi::Pre pre[NS];
+  float ln_rsum[kLnp ? NS : 1];
+  float4 sq_mean[kLnp ? LNPASS : 1], sq_m2[kLnp ? LNPASS : 1];
   auto prefetch_epilogue = [&]() {
     if (nvalid > 0) {
 #pragma unroll
       for (int i = 0; i < NS; ++i) pre[i] = epi.load(item, site_row(wave * NS + i), tc);
+    }
+    if constexpr (kLnp) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) ln_rsum[i] = a.ln_R[site_row(wave * NS + i)];
+#pragma unroll
+      for (int ps = 0; ps < LNPASS; ++ps) {
+        const int c = ps * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+        const float4* p = reinterpret_cast<const float4*>(a.col_stats + ((long)item * a.T + min(t0 + min(c, COLS - 1), a.T - 1)) * 32);
+        sq_mean[ps] = p[q];
+        sq_m2[ps] = p[4 + q];
+      }
+    }
+  };
+  auto ln_publish = [&]() {   // after the K loop, before the reduction's barrier (convgemm.hip.h ln_publish, kColMean form)
+    if constexpr (kLnp) {
+#pragma unroll
+      for (int ps = 0; ps < LNPASS; ++ps) {
+        const int c = ps * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+        const float mg[4] = {sq_mean[ps].x, sq_mean[ps].y, sq_mean[ps].z, sq_mean[ps].w};
+        const float m2g[4] = {sq_m2[ps].x, sq_m2[ps].y, sq_m2[ps].z, sq_m2[ps].w};
+        float msum = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * q + k < a.n_groups) { msum += mg[k]; m2 += m2g[k]; }
+        msum += __shfl_xor(msum, 1); msum += __shfl_xor(msum, 2);
+        m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2);
+        const float mean = msum / (float)a.n_groups;
+        float dev2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d = 4 * q + k < a.n_groups ? mg[k] - mean : 0.f;
+          dev2 += d * d;
+        }
+        dev2 += __shfl_xor(dev2, 1); dev2 += __shfl_xor(dev2, 2);
+        if (q == 0 && c < COLS) {
+          ln_cols[c * 2] = mean;
+          ln_cols[c * 2 + 1] = 1.f / sqrtf((m2 + 32.f * dev2) / (float)(32 * a.n_groups) + a.ln_eps);
+        }
+      }
     }
   };
 
@@ -310,6 +380,7 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
     prefetch_epilogue();
   }
   FDX_STAMP(2);
+  ln_publish();
 
   // ---- cross-wave K reduction through LDS, fixed order w0 + w1 + w2 + w3
   f4* redv = reinterpret_cast<f4*>(red);
@@ -357,18 +428,29 @@ __global__ __launch_bounds__(256) void convgemm16s_kernel(FDX_CONV_HOT_PARAMS, C
     for (int m = 4; m < NM; ++m) out.v[m] = hi[m - 4];
     return out;
   };
+  float ln_mean[kLnp ? NM : 1], ln_rstd[kLnp ? NM : 1];
+  if constexpr (kLnp) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) { ln_mean[m] = ln_cols[(NM * lj + m) * 2]; ln_rstd[m] = ln_cols[(NM * lj + m) * 2 + 1]; }
+  }
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int sidx = wave * NS + i;
     if constexpr (Epi::kPaired) epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), rsum(sidx + NR * 2), pre[i]);
-    else epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), pre[i]);
+    else if constexpr (kLnp) {
+      VecN<NM> v = rsum(sidx);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) v.v[m] = (v.v[m] - ln_mean[m] * ln_rsum[i]) * ln_rstd[m];
+      epi.store(item, site_row(sidx), tc, nvalid, v, pre[i]);
+    } else epi.store(item, site_row(sidx), tc, nvalid, rsum(sidx), pre[i]);
   }
   FDX_STAMP_END();
 }
 
-template <class Epi, int NR, int NM>
+template <class Epi, int NR, int NM, int PRE = PRE_NONE>
 inline hipError_t launch_convgemm16s(const ConvGeom& g, const void* Wp, const float* X, long x_bstride, int ldx, const Epi& epi,
-                                     hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                                     hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const float* col_stats = nullptr,
+                                     const float* ln_R = nullptr, int n_groups = 0, float ln_eps = 0.f) {
   ConvArgs a;
   a.Wp = static_cast<const float4*>(Wp); a.X = X; a.x_bstride = x_bstride; a.ldx = ldx;
   a.n_it = g.cin8 * g.taps; a.taps = g.taps; a.shift0 = g.shift0; a.dshift = g.dshift;
@@ -378,7 +460,7 @@ inline hipError_t launch_convgemm16s(const ConvGeom& g, const void* Wp, const fl
   a.n_mtiles = g.n_mtiles;             // tiles of NR 16-row blocks
   a.xcd_rect = use_xcd_rect(a.n_tiles_n, a.n_mtiles, a.taps);
   a.in_slope = 1.f;
-  a.col_stats = nullptr; a.ln_R = nullptr; a.n_groups = 0; a.ln_eps = 0.f;
+  a.col_stats = col_stats; a.ln_R = ln_R; a.n_groups = n_groups; a.ln_eps = ln_eps;
   const int grid = conv_rect_grid(a.n_tiles_n, a.n_mtiles, a.xcd_rect);
   if (grid <= 0) return hipSuccess;
 #ifdef FDX_KTRACE
@@ -387,9 +469,9 @@ inline hipError_t launch_convgemm16s(const ConvGeom& g, const void* Wp, const fl
     a.trace = g_trace.buf + (size_t)(g_trace.n++) * g_trace.blocks_cap * 32;
 #endif
   if (ev_start)
-    hipExtLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipExtLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM, PRE>), dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   else
-    hipLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
+    hipLaunchKernelGGL((convgemm16s_kernel<Epi, NR, NM, PRE>), dim3(grid), dim3(256), 0, s, FDX_CONV_HOT_ARGS(a), conv_cold_of(a), epi);
   return hipGetLastError();
 }
 
@@ -441,6 +523,25 @@ static __global__ void k_repack16_nr2(float2* __restrict__ dst, const float4* __
 // 16x16x4 fragment order (NR = 4: one float4 per lane, NR = 2: one float2) of a plain [rows][K] GEMM weight, derived on the device from
 // the 32x32x2 order pack_convgemm(RB = 2) wrote into the arena: src[(((mt*n_it + it)*2 + rb)*64 + hi*32 + r32)*4 + j] =
 // w(row = mt*64 + rb*32 + r32, c = it*8 + hi*4 + j).  One thread per destination lane slot.
+// ... and from the RB = 1 (32-row tiles) 32x32x2 order: src[((mt32 * n_it + it) * 64 + hi * 32 + r32) * 4 + j] = w(row = mt32 * 32 + r32, c = it*8 + hi*4 + j);
+// n_mt32 = 32-row tiles of the source (rows = 32 n_mt32, a multiple of 16 NR)
+template <int NR>
+static __global__ void k_repack16_from32rb1(float* __restrict__ dst, const float* __restrict__ src, int n_mt32, int n_it) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // ((mt' * n_it + it) * 2 + h) * 64 + lane, mt' = tile of NR 16-row blocks
+  const size_t n_dst = (size_t)n_mt32 * 32 / (16 * NR) * n_it * 128;
+  if (i >= n_dst) return;
+  const int lane = (int)(i & 63), h = (int)((i >> 6) & 1);
+  const size_t q = i >> 7;
+  const int it = (int)(q % n_it), mtp = (int)(q / n_it);
+  const int c = it * 8 + h * 4 + (lane >> 4);
+#pragma unroll
+  for (int x = 0; x < NR; ++x) {
+    const int row = mtp * (16 * NR) + x * 16 + (lane & 15);
+    const int mt = row >> 5, r32 = row & 31, hi = (c & 7) >> 2, j = c & 3;
+    dst[i * NR + x] = src[(((size_t)mt * n_it + (c >> 3)) * 64 + hi * 32 + r32) * 4 + j];
+  }
+}
+
 template <int NR>
 static __global__ void k_repack16_from32(float* __restrict__ dst, const float* __restrict__ src, int n_mt64, int n_it) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // ((mt'*n_it + it)*2 + h)*64 + lane, mt' = tile of NR blocks

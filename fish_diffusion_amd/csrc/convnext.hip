@@ -23,6 +23,7 @@
 #include "gemmplan.hip.h"
 #include "elementwise.hip.h"
 #include "declayer.hip.h"
+#include "convgemm16s.hip.h"
 
 #include <cmath>
 
@@ -52,6 +53,10 @@ constexpr int kCrossTensors = 3 + 18 + 2;
 //   PRE_LNP with 32-row tiles (896 workgroups, four co-resident per CU instead of 448 at 1.75 per CU)            1001 | 5783   <- default
 // A/B switches (decide the arena layout / the operand form: read once per process): FDX_CN_PW1_RB=2 (64-row tiles), FDX_CN_LNP=0 (centred form).
 int cn_pw1_rb() { static const int v = [] { const char* e = getenv("FDX_CN_PW1_RB"); const int k = e ? atoi(e) : 0; return k == 2 ? 2 : 1; }(); return v; }
+// pwconv1 on the shape-adaptive split-K 16x16x4 family of the residual-block GEMMs (convgemm16s.hip.h, PRE_LNP + bias + GELU): at batch 1 x 861
+// frames 256 workgroups of 64 x 112 (one per CU) instead of 896 of 32 x 64 -- 24.3 -> ~19.6 us per launch; FDX_CN_PW1_16S=0 keeps the 32x32x2 kernel.
+// Taken for EVERY geometry when on (an item's result must not depend on the batch it rode in).  Needs the PRE_LNP form and 32-row packed weights.
+bool cn_pw1_16s() { static const bool v = [] { const char* e = getenv("FDX_CN_PW1_16S"); return !e || atoi(e) != 0; }(); return v; }
 bool cn_lnp() { static const bool v = [] { const char* e = getenv("FDX_CN_LNP"); return !e || atoi(e) != 0; }(); return v; }
 int cn_n_cross(const fdx_convnext_desc& d) { return d.cross_attention > 0 ? (d.num_layers + d.cross_attention - 1) / d.cross_attention : 0; }
 
@@ -252,6 +257,11 @@ struct fdx_cn_state {
   CnLayout l;
   const float* arena = nullptr;
   CnBufs b;
+  // pwconv1's weights once more in the 16x16x4 fragment orders (NR = 4 and NR = 2), derived on the device at attach (cn_pw1_16s)
+  DevBuf pw1_16;
+  std::vector<size_t> pw1_off4, pw1_off2;
+  bool pw1_16_ok = false;
+  int pw1_nr = 4, pw1_nm = 4;     // tile shape for the prepared geometry
 };
 
 static fdx_cn_state* cn(fdx_ctx* h) {
@@ -354,6 +364,26 @@ extern "C" int fdx_convnext_attach(fdx_handle h, const fdx_convnext_desc* d, con
   S->d = *d; S->arena = static_cast<const float*>(dev); S->ok = true;
   ++h->alloc_gen;   // cached sampler graphs bake the arena address in
   h->prepared = false;
+  S->pw1_16_ok = false;
+  if (cn_pw1_16s() && cn_lnp() && !S->l.pw1.empty() && S->l.pw1[0].RB == 1 && (d->dim * d->mlp_factor) % 64 == 0) {
+    // one-off at model load: default stream, synchronous (like the WaveNet's derived orders)
+    FDX_HIP(h, hipSetDevice(h->device));
+    size_t tot = 0;
+    for (const auto& p : S->l.pw1) tot += 2 * packed_floats(p.n_mtiles, 1, p.cin8, 1);
+    FDX_HIP(h, S->pw1_16.ensure(tot * sizeof(float), false, nullptr));
+    S->pw1_off4.clear(); S->pw1_off2.clear();
+    size_t c = 0;
+    for (const auto& p : S->l.pw1) {
+      const size_t nf = packed_floats(p.n_mtiles, 1, p.cin8, 1);
+      S->pw1_off4.push_back(c); S->pw1_off2.push_back(c + nf);
+      const size_t n4 = nf / 4, n2 = nf / 2;
+      hipLaunchKernelGGL(k_repack16_from32rb1<4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, nullptr, S->pw1_16.f() + c, S->arena + p.w_off, p.n_mtiles, p.cin8);
+      hipLaunchKernelGGL(k_repack16_from32rb1<2>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, nullptr, S->pw1_16.f() + c + nf, S->arena + p.w_off, p.n_mtiles, p.cin8);
+      c += 2 * nf;
+    }
+    FDX_HIP(h, hipDeviceSynchronize());
+    S->pw1_16_ok = true;
+  }
   return FDX_OK;
 }
 
@@ -377,7 +407,20 @@ extern "C" int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int 
   CnBufs& b = S->b;
   FDX_HIP(h, h->xin.ensure(sz(M), geom, s));
   FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
-  FDX_HIP(h, b.X.ensure(sz(D), geom, s)); FDX_HIP(h, b.N.ensure(sz(D), geom, s)); FDX_HIP(h, b.H2.ensure(sz(D), geom, s));
+  // (N is pwconv1's B operand: the 16x16x4 family's 16 NM-column tiles may read up to 127 columns past T in the last row -- values unused, memory owned)
+  FDX_HIP(h, b.X.ensure(sz(D), geom, s)); FDX_HIP(h, b.N.ensure(sz(D) + kTailPad * sizeof(float), geom, s)); FDX_HIP(h, b.H2.ensure(sz(D), geom, s));
+  if (S->pw1_16_ok) {
+    const int rows16 = H / 16;
+    Shape16 sh{4, 4};
+    const long wg44 = (long)(rows16 / 4) * B * ((T + 63) / 64);
+    if (wg44 < 2 * 256) sh = pick_shape16(rows16, B, T, 12000.0 / (32.0 * ((D / 8 + 3) / 4)));
+    static const int forced = [] { const char* e = getenv("FDX_CN_PW1_SHAPE"); return e ? atoi(e) : -1; }();
+    if (forced > 0) sh = Shape16{forced / 10, forced % 10};
+    else if (sh.NR == 4 && (long)(rows16 / 2) * B * ((T + 16 * sh.NM - 1) / (16 * sh.NM)) <= 512)
+      sh.NR = 2;   // two co-resident 32-row workgroups per CU cover each other's GELU epilogue (batch 1 x 861: 32 x 112 105.2x, 64 x 112 102.9x; `r06_convnext_pw1_16s_shapes.txt`)
+    if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8) sh = Shape16{4, 4};
+    S->pw1_nr = sh.NR; S->pw1_nm = sh.NM;
+  }
   FDX_HIP(h, b.G.ensure(sz(H), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s)); FDX_HIP(h, b.c2.ensure(sz(D), geom, s));
   FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.CP.ensure(sz(L * D), geom, s));
   FDX_HIP(h, b.ST.ensure((size_t)B * T * 32 * sizeof(float), false, s));
@@ -524,12 +567,32 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
       const PackedW& p = l.pw1[i];
       ConvGeom gg{B, T, p.cin8, 1, 0, 0, p.n_mtiles};
       hipEvent_t ev0 = nullptr, ev1 = nullptr;   // fdx_prof_*: the denoiser's dominant kernel
-      h->prof.note(PROF_CN_PWCONV1, "convgemm_kernel<%d, true, %s, EpiBias> (v_mfma_f32_32x32x2_f32; %d x 64 split-K workgroup tile, LayerNorm folded in, GELU epilogue; %ld workgroups)",
-                   p.RB, cn_lnp() ? "PRE_LNP" : "PRE_LN", 32 * p.RB, (long)B * ((T + 63) / 64) * p.n_mtiles);
+      if (S->pw1_16_ok)
+        h->prof.note(PROF_CN_PWCONV1, "convgemm16s_kernel<EpiBiasAct16S<%d>, %d, %d, PRE_LNP> (v_mfma_f32_16x16x4_f32; %d x %d split-K workgroup tile, LayerNorm folded in, GELU epilogue; %ld workgroups)",
+                     S->pw1_nm, S->pw1_nr, S->pw1_nm, 16 * S->pw1_nr, 16 * S->pw1_nm, (long)B * ((T + 16 * S->pw1_nm - 1) / (16 * S->pw1_nm)) * (H / (16 * S->pw1_nr)));
+      else
+        h->prof.note(PROF_CN_PWCONV1, "convgemm_kernel<%d, true, %s, EpiBias> (v_mfma_f32_32x32x2_f32; %d x 64 split-K workgroup tile, LayerNorm folded in, GELU epilogue; %ld workgroups)",
+                     p.RB, cn_lnp() ? "PRE_LNP" : "PRE_LN", 32 * p.RB, (long)B * ((T + 63) / 64) * p.n_mtiles);
       h->prof.take(PROF_CN_PWCONV1, 2.0 * (double)H * D * (double)B * T, ev0, ev1);
       const float4* Wp = reinterpret_cast<const float4*>(A + p.w_off);
       const EpiBias eb = bias_epi(G, bsH, ld, A + p.b_off, H, ACT_GELU);
-      if (cn_lnp()) {
+      if (S->pw1_16_ok) {
+        const int NRs = S->pw1_nr, NMs = S->pw1_nm;
+        const ConvGeom g4{B, T, p.cin8, 1, 0, 0, H / 64}, g2{B, T, p.cin8, 1, 0, 0, H / 32};
+        const void* W4 = S->pw1_16.f() + S->pw1_off4[i];
+        const void* W2 = S->pw1_16.f() + S->pw1_off2[i];
+        hipError_t e = hipErrorInvalidValue;
+#define FDX_PW1_SHAPE(NR_, NM_)                                                                                                        \
+  if (NRs == NR_ && NMs == NM_) {                                                                                                      \
+    const EpiBiasAct16S<NM_> ea{G, bsH, ld, A + p.b_off, ACT_GELU};                                                                    \
+    e = launch_convgemm16s<EpiBiasAct16S<NM_>, NR_, NM_, PRE_LNP>(NR_ == 4 ? g4 : g2, NR_ == 4 ? W4 : W2, N, bsD, ld, ea, s, ev0, ev1, \
+                                                                 b.ST.f(), A + l.lnRs[i], D / kCnCh, 1e-6f);                           \
+  }
+        FDX_PW1_SHAPE(4, 4) FDX_PW1_SHAPE(4, 5) FDX_PW1_SHAPE(4, 6) FDX_PW1_SHAPE(4, 7) FDX_PW1_SHAPE(4, 8)
+        FDX_PW1_SHAPE(2, 4) FDX_PW1_SHAPE(2, 5) FDX_PW1_SHAPE(2, 6) FDX_PW1_SHAPE(2, 7) FDX_PW1_SHAPE(2, 8)
+#undef FDX_PW1_SHAPE
+        FDX_HIP(h, e);
+      } else if (cn_lnp()) {
         if (p.RB == 1) FDX_HIP(h, (launch_convgemm<1, true, PRE_LNP, EpiBias>(gg, Wp, N, bsD, ld, 1.f, eb, s, ev0, ev1, b.ST.f(), A + l.lnRs[i], D / kCnCh, 1e-6f)));
         else FDX_HIP(h, (launch_convgemm<2, true, PRE_LNP, EpiBias>(gg, Wp, N, bsD, ld, 1.f, eb, s, ev0, ev1, b.ST.f(), A + l.lnRs[i], D / kCnCh, 1e-6f)));
       } else {

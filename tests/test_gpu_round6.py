@@ -285,8 +285,9 @@ def _fixtures():
 
 # ------------------------------------------------------------------------------------------------ the A/B arms of round 6 stay correct
 @pytest.mark.parametrize("env", [dict(FDX_TD_LNFOLD="0"), dict(FDX_TD_SAIN_RB="2", FDX_TD_LIN1_RB="2"), dict(FDX_CN_LNP="0", FDX_CN_PW1_RB="2"), dict(FDX_CN_PW1_RB="2"),
-                                 dict(FDX_CN_LNP="0")],
-                         ids=["layernorm-launched", "tfdec-64-row-tiles", "convnext-round5", "convnext-lnp-64-row", "convnext-centred-32-row"])
+                                 dict(FDX_CN_LNP="0"), dict(FDX_CN_PW1_16S="0")],
+                         ids=["layernorm-launched", "tfdec-64-row-tiles", "convnext-round5", "convnext-lnp-64-row", "convnext-centred-32-row",
+                              "convnext-pwconv1-32x32x2"])
 def test_round6_switches_hold_the_reference_goldens(dev, env):
     """INTEGRATION.md lists the switches that bring back the round-5 forms (LayerNorm launches, 64-row tiles, ConvNext's group-centred fold): they
     decide the arena layout, so each arm runs in its own process -- and must hold the same reference goldens as the default (forward of both
@@ -301,3 +302,47 @@ def test_round6_switches_hold_the_reference_goldens(dev, env):
                        timeout=900, cwd=ROOT)
     print(r.stdout[-1500:])
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ pwconv1 on the 16x16x4 family: tile shapes
+def test_convnext_pwconv1_tile_shapes_are_bit_identical(dev):
+    """Second session of round 6: ConvNext's pwconv1 (LayerNorm folded in, GELU epilogue) runs on the shape-adaptive split-K family of the
+    residual-block GEMMs (convgemm16s.hip.h, PRE_LNP).  The tile shape is a scheduling choice there -- every output is the same k-ordered fp32 chain
+    over the same four K ranges, the column statistics are combined per column -- so every forced shape (FDX_CN_PW1_SHAPE=<NR><NM>, own process)
+    must reproduce the automatic choice BIT FOR BIT on overhanging / tiny / batched / masked geometries: what makes an exact-ragged item equal its
+    batch-1 run whatever tile its row was cut into."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    code = r'''
+import os, sys, hashlib, torch
+sys.path.insert(0, %r)
+from fish_diffusion_amd import DENOISERS
+from tests.helpers import CN_SMALL, convnext_sd
+dev = torch.device("cuda", 0)
+net = DENOISERS.build(dict(type="ConvNextDenoiser", **CN_SMALL))
+net.load_state_dict(convnext_sd(CN_SMALL, 77), strict=True)
+net = net.to(dev).eval()
+h = hashlib.sha1()
+g = torch.Generator().manual_seed(3)
+for B, T in ((1, 1), (1, 37), (2, 113), (1, 257), (3, 430), (1, 861)):
+    x, c, t = torch.randn(B, 128, T, generator=g).to(dev), torch.randn(B, 256, T, generator=g).to(dev), (torch.rand(B, generator=g) * 999).to(dev)
+    m = torch.zeros(B, T, dtype=torch.bool, device=dev)
+    m[-1, T - T // 5:] = True
+    for masks in (None, m):
+        y = net(x, t, c, x_masks=masks, cond_masks=masks)
+        assert torch.isfinite(y).all()
+        h.update(y.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+''' % ROOT
+    digests = {}
+    for shape in ("auto", "44", "47", "48", "24", "27", "28", "45"):
+        env = dict(os.environ)
+        env.pop("FDX_CN_PW1_SHAPE", None)
+        if shape != "auto":
+            env["FDX_CN_PW1_SHAPE"] = shape
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DIGEST" in r.stdout, shape + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+        digests[shape] = r.stdout.split("DIGEST")[1].split()[0]
+    assert len(set(digests.values())) == 1, digests
