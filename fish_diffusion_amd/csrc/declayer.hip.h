@@ -6,6 +6,7 @@
 // softmax axis runs over the accumulator registers of one lane; P^T feeds the second product in place; see tfdec.hip's header).
 #pragma once
 #include "common.hip.h"
+#include "convgemm16s.hip.h"
 #include "elementwise.hip.h"
 #include "gemmplan.hip.h"
 
@@ -744,9 +745,14 @@ inline hipError_t gemm_ln(const float* A, const PackedW& p, size_t R_off, int B,
   return launch_convgemm<2, true, PRE_LNP, Epi>(g, Wp, X, x_bs, ldx, 1.f, e, s, nullptr, nullptr, ln.st[ln.cur], A + R_off, D / 32, 1e-5f);
 }
 
+// linear1 (dim -> mlp_factor dim, GELU, pending norm folded in) on the shape-adaptive split-K 16x16x4 family (convgemm16s.hip.h PRE_LNP; second session of
+// round 6, after ConvNext's pwconv1 -- the same [2048 x 512] GEMM): its weights in the NR = 4 / NR = 2 fragment orders, derived at attach (tfdec.hip)
+struct Lin1On16 { const float* w4 = nullptr; const float* w2 = nullptr; int nr = 4, nm = 4; };
+
 inline hipError_t run_declayer_ln(const float* A, const TdLayer& y, int B, int T, int D, int H, int ld, float* X, const float* KV, long kv_bs,
                                   const DecScratch& sc, const uint8_t* tgt_kpm, const uint8_t* mem_kpm, hipStream_t s, ProfEvents* prof,
-                                  const float* ca_bias, int ca_bias_ld, int ca_bias_bs, const AttnItems& items, LnStream& ln) {
+                                  const float* ca_bias, int ca_bias_ld, int ca_bias_bs, const AttnItems& items, LnStream& ln,
+                                  const Lin1On16* l16 = nullptr) {
   const long bsD = (long)D * ld, bsH = (long)H * ld;
   const int DH = D / kHeads;
   // X = LN_pending(X) + W in + b, un-normalised and centred, statistics to the other buffer; `nw / nb` = the norm that follows this sublayer
@@ -780,7 +786,20 @@ inline hipError_t run_declayer_ln(const float* A, const TdLayer& y, int B, int T
   if ((e = launch_attn(DH, at, B, s, prof, items)) != hipSuccess) return e;
   if ((e = residual(y.ca_out, sc.O, bsD, A + y.n2w, A + y.n2b, ca_bias, ca_bias_ld, ca_bias_bs)) != hipSuccess) return e;
   // ---- feed-forward block
-  if ((e = gemm_ln(A, y.lin1, y.lin1_R, B, T, D, X, bsD, ld, ln, bias_epi(sc.G, bsH, ld, A + y.lin1.b_off, H, ACT_GELU), s)) != hipSuccess) return e;
+  if (l16 && ln.pw) {
+    const ConvGeom g4{B, T, y.lin1.cin8, 1, 0, 0, H / 64}, g2{B, T, y.lin1.cin8, 1, 0, 0, H / 32};
+    e = hipErrorInvalidValue;
+#define FDX_LIN1_SHAPE(NR_, NM_)                                                                                                            \
+  if (l16->nr == NR_ && l16->nm == NM_) {                                                                                                  \
+    const EpiBiasAct16S<NM_> ea{sc.G, bsH, ld, A + y.lin1.b_off, ACT_GELU};                                                                 \
+    e = launch_convgemm16s<EpiBiasAct16S<NM_>, NR_, NM_, PRE_LNP>(NR_ == 4 ? g4 : g2, NR_ == 4 ? l16->w4 : l16->w2, X, bsD, ld, ea, s, nullptr, \
+                                                                 nullptr, ln.st[ln.cur], A + y.lin1_R, D / 32, 1e-5f);                       \
+  }
+    FDX_LIN1_SHAPE(4, 4) FDX_LIN1_SHAPE(4, 5) FDX_LIN1_SHAPE(4, 6) FDX_LIN1_SHAPE(4, 7) FDX_LIN1_SHAPE(4, 8)
+    FDX_LIN1_SHAPE(2, 4) FDX_LIN1_SHAPE(2, 5) FDX_LIN1_SHAPE(2, 6) FDX_LIN1_SHAPE(2, 7) FDX_LIN1_SHAPE(2, 8)
+#undef FDX_LIN1_SHAPE
+    if (e != hipSuccess) return e;
+  } else if ((e = gemm_ln(A, y.lin1, y.lin1_R, B, T, D, X, bsD, ld, ln, bias_epi(sc.G, bsH, ld, A + y.lin1.b_off, H, ACT_GELU), s)) != hipSuccess) return e;
   if ((e = residual(y.lin2, sc.G, bsH, A + y.n3w, A + y.n3b)) != hipSuccess) return e;
   return hipGetLastError();
 }

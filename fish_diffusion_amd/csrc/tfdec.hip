@@ -92,7 +92,13 @@ struct fdx_td_state {
   TdLayout l;
   const float* arena = nullptr;
   TdBufs b;
+  // linear1 of every layer once more in the 16x16x4 fragment orders (declayer.hip.h Lin1On16), derived on the device at attach; FDX_TD_LIN1_16S=0: off
+  DevBuf lin1_16;
+  std::vector<size_t> lin1_off4, lin1_off2;
+  bool lin1_16_ok = false;
+  int lin1_nr = 4, lin1_nm = 4;
 };
+static bool td_lin1_16s() { static const bool v = [] { const char* e = getenv("FDX_TD_LIN1_16S"); return !e || atoi(e) != 0; }(); return v; }
 
 static fdx_td_state* td(fdx_ctx* h) {
   if (!h->td) h->td = new fdx_td_state();
@@ -158,6 +164,25 @@ extern "C" int fdx_tfdec_attach(fdx_handle h, const fdx_tfdec_desc* d, const voi
   S->d = *d; S->arena = static_cast<const float*>(dev); S->ok = true;
   ++h->alloc_gen;   // cached sampler graphs bake the arena address in
   h->prepared = false;
+  S->lin1_16_ok = false;
+  if (td_lin1_16s() && S->l.folded && !S->l.layers.empty() && S->l.layers[0].lin1.RB == 1 && (d->dim * d->mlp_factor) % 64 == 0) {
+    FDX_HIP(h, hipSetDevice(h->device));     // one-off at model load: default stream, synchronous
+    size_t tot = 0;
+    for (const auto& y : S->l.layers) tot += 2 * packed_floats(y.lin1.n_mtiles, 1, y.lin1.cin8, 1);
+    FDX_HIP(h, S->lin1_16.ensure(tot * sizeof(float), false, nullptr));
+    S->lin1_off4.clear(); S->lin1_off2.clear();
+    size_t c = 0;
+    for (const auto& y : S->l.layers) {
+      const PackedW& p = y.lin1;
+      const size_t nf = packed_floats(p.n_mtiles, 1, p.cin8, 1);
+      S->lin1_off4.push_back(c); S->lin1_off2.push_back(c + nf);
+      hipLaunchKernelGGL(k_repack16_from32rb1<4>, dim3((unsigned)((nf / 4 + 255) / 256)), dim3(256), 0, nullptr, S->lin1_16.f() + c, S->arena + p.w_off, p.n_mtiles, p.cin8);
+      hipLaunchKernelGGL(k_repack16_from32rb1<2>, dim3((unsigned)((nf / 2 + 255) / 256)), dim3(256), 0, nullptr, S->lin1_16.f() + c + nf, S->arena + p.w_off, p.n_mtiles, p.cin8);
+      c += 2 * nf;
+    }
+    FDX_HIP(h, hipDeviceSynchronize());
+    S->lin1_16_ok = true;
+  }
   return FDX_OK;
 }
 
@@ -190,7 +215,19 @@ extern "C" int fdx_tfdec_prepare(fdx_handle h, const float* cond, int B, int T, 
   FDX_HIP(h, h->xin.ensure(sz(M), geom, s));
   FDX_HIP(h, h->EPS.ensure(sz(M), geom, s));
   const int L = d.num_layers;
-  FDX_HIP(h, b.X.ensure(sz(D), geom, s)); FDX_HIP(h, b.QKV.ensure(sz(3 * D), geom, s)); FDX_HIP(h, b.KVh.ensure(sz(2 * D) * L, geom, s));
+  // (X is linear1's B operand on the 16x16x4 family: its tiles may read up to 127 columns past T in the last row -- values unused, memory owned)
+  FDX_HIP(h, b.X.ensure(sz(D) + kTailPad * sizeof(float), geom, s)); FDX_HIP(h, b.QKV.ensure(sz(3 * D), geom, s)); FDX_HIP(h, b.KVh.ensure(sz(2 * D) * L, geom, s));
+  if (S->lin1_16_ok) {   // tile shape of linear1 for this geometry (ConvNext's pwconv1 rule: convnext.hip)
+    const int rows16 = H / 16;
+    Shape16 sh{4, 4};
+    const long wg44 = (long)(rows16 / 4) * B * ((T + 63) / 64);
+    if (wg44 < 2 * 256) sh = pick_shape16(rows16, B, T, 12000.0 / (32.0 * ((D / 8 + 3) / 4)));
+    static const int forced = [] { const char* e = getenv("FDX_TD_LIN1_SHAPE"); return e ? atoi(e) : -1; }();
+    if (forced > 0) sh = Shape16{forced / 10, forced % 10};
+    else if (sh.NR == 4 && (long)(rows16 / 2) * B * ((T + 16 * sh.NM - 1) / (16 * sh.NM)) <= 512) sh.NR = 2;
+    if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8) sh = Shape16{4, 4};
+    S->lin1_nr = sh.NR; S->lin1_nm = sh.NM;
+  }
   FDX_HIP(h, b.O.ensure(sz(D), geom, s)); FDX_HIP(h, b.G.ensure(sz(H), geom, s)); FDX_HIP(h, b.Hin.ensure(sz(H), geom, s));
   FDX_HIP(h, b.H2.ensure(sz(D), geom, s)); FDX_HIP(h, b.C0.ensure(sz(D), geom, s));
   FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s));
@@ -285,9 +322,12 @@ int fdx_td_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
   if (l.folded) {
     LnStream ln;
     ln.st[0] = b.ST.f(); ln.st[1] = b.ST.f() + (size_t)B * T * 32;
-    for (int i = 0; i < L; ++i)
+    for (int i = 0; i < L; ++i) {
+      Lin1On16 l16;
+      if (S->lin1_16_ok) { l16.w4 = S->lin1_16.f() + S->lin1_off4[i]; l16.w2 = S->lin1_16.f() + S->lin1_off2[i]; l16.nr = S->lin1_nr; l16.nm = S->lin1_nm; }
       FDX_HIP(h, run_declayer_ln(A, l.layers[i], B, T, D, H, ld, X, KVh + (size_t)i * 2 * D * ld, (long)L * 2 * bsD, sc, mask, cmask, s, &h->prof,
-                                 b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs, items, ln));
+                                 b.CB.f() + kHalo + (size_t)i * D * b.ldn + col0, b.ldn, sb_bs, items, ln, S->lin1_16_ok ? &l16 : nullptr));
+    }
     // output_projection.0 reads the stream through the last layer's norm3 like every other consumer
     FDX_HIP(h, gemm_ln(A, l.out0, l.out0_R, B, T, D, X, bsD, ld, ln, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
   } else {

@@ -285,9 +285,9 @@ def _fixtures():
 
 # ------------------------------------------------------------------------------------------------ the A/B arms of round 6 stay correct
 @pytest.mark.parametrize("env", [dict(FDX_TD_LNFOLD="0"), dict(FDX_TD_SAIN_RB="2", FDX_TD_LIN1_RB="2"), dict(FDX_CN_LNP="0", FDX_CN_PW1_RB="2"), dict(FDX_CN_PW1_RB="2"),
-                                 dict(FDX_CN_LNP="0"), dict(FDX_CN_PW1_16S="0")],
+                                 dict(FDX_CN_LNP="0"), dict(FDX_CN_PW1_16S="0"), dict(FDX_TD_LIN1_16S="0")],
                          ids=["layernorm-launched", "tfdec-64-row-tiles", "convnext-round5", "convnext-lnp-64-row", "convnext-centred-32-row",
-                              "convnext-pwconv1-32x32x2"])
+                              "convnext-pwconv1-32x32x2", "tfdec-linear1-32x32x2"])
 def test_round6_switches_hold_the_reference_goldens(dev, env):
     """INTEGRATION.md lists the switches that bring back the round-5 forms (LayerNorm launches, 64-row tiles, ConvNext's group-centred fold): they
     decide the arena layout, so each arm runs in its own process -- and must hold the same reference goldens as the default (forward of both
