@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 TRAFFIC_KEYS = {"convgate": ("EpiGate",), "outproj": ("EpiResSkip",), "nsf_resblock": ("2, false, 1, EpiResblock",),
-                "rg_resblock": ("2, false, 1, EpiResblock",), "cn_pwconv1": ("1, true, 4, EpiBias", "2, true, 2, EpiBias"), "td_attn": ("k_attn_qs",)}
+                "rg_resblock": ("2, false, 1, EpiResblock",), "cn_pwconv1": ("EpiBiasAct16S",), "td_attn": ("k_attn_qs",)}
 
 
 def pmc_traffic(config: str, kernel: str, expect: dict):
