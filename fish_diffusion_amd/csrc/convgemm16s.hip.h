@@ -197,32 +197,6 @@ template <int NM> struct EpiBiasAct16S {
   }
 };
 
-// x = residual + gamma * (acc + bias); masked columns -> 0, in place (EpiScaleRes of convgemm.hip.h for NM adjacent columns: ConvNext's pwconv2)
-template <int NM> struct EpiScaleRes16S {
-  static constexpr bool kPaired = false;
-  float* X; long bs; int ld;
-  const float* bias; const float* gamma;
-  const uint8_t* mask; int mask_ld;
-  struct Pre { VecN<NM> old; float bias, gamma; };
-  __device__ __forceinline__ Pre load(int b, int row, int t) const {
-    Pre p;
-    p.old = ldN<NM>(X + b * bs + (long)row * ld + t);
-    p.bias = bias[row];
-    p.gamma = *(gamma ? gamma + row : bias + row);              // gamma == null: plain residual add
-    return p;
-  }
-  __device__ __forceinline__ void store(int b, int row, int t, int nvalid, VecN<NM> v, const Pre& p) const {
-    const float gm = gamma ? p.gamma : 1.f;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      float y = p.old.v[m] + gm * (v.v[m] + p.bias);
-      if (mask && m < nvalid && mask[(long)b * mask_ld + t + m] != 0) y = 0.f;
-      v.v[m] = y;
-    }
-    stNp<NM, false>(X + b * bs + (long)row * ld + t, v, nvalid);
-  }
-};
-
 // ------------------------------------------------------------------------------------------ kernel
 // Packed A: NR = 4: [m64-tile][it][h][lane] float4 (pack_convgemm16);  NR = 2: [m32-tile][it][h][lane] float2 (k_repack16_nr2);
 // NR = 1 (out-projection only): [m16-tile][it][h][lane] float (k_repack16_from32<1>) -- 16 x (16 NM) tiles, twice the workgroups of NR = 2.

@@ -57,9 +57,6 @@ int cn_pw1_rb() { static const int v = [] { const char* e = getenv("FDX_CN_PW1_R
 // frames 256 workgroups of 64 x 112 (one per CU) instead of 896 of 32 x 64 -- 24.3 -> ~19.6 us per launch; FDX_CN_PW1_16S=0 keeps the 32x32x2 kernel.
 // Taken for EVERY geometry when on (an item's result must not depend on the batch it rode in).  Needs the PRE_LNP form and 32-row packed weights.
 bool cn_pw1_16s() { static const bool v = [] { const char* e = getenv("FDX_CN_PW1_16S"); return !e || atoi(e) != 0; }(); return v; }
-// pwconv2 ([dim x 4 dim] x [4 dim x T], scale + residual epilogue) on the same family: 16 x 112 tiles = 256 workgroups at batch 1 x 861 (was 224 of 32 x 64
-// on the 32x32x2 kernel); every geometry when on.  FDX_CN_PW2_16S=0 keeps the 32x32x2 kernels, FDX_CN_PW2_SHAPE=<NR><NM> forces a tile (NR = 1 | 2 | 4).
-bool cn_pw2_16s() { static const bool v = [] { const char* e = getenv("FDX_CN_PW2_16S"); return !e || atoi(e) != 0; }(); return v; }
 bool cn_lnp() { static const bool v = [] { const char* e = getenv("FDX_CN_LNP"); return !e || atoi(e) != 0; }(); return v; }
 int cn_n_cross(const fdx_convnext_desc& d) { return d.cross_attention > 0 ? (d.num_layers + d.cross_attention - 1) / d.cross_attention : 0; }
 
@@ -265,10 +262,6 @@ struct fdx_cn_state {
   std::vector<size_t> pw1_off4, pw1_off2;
   bool pw1_16_ok = false;
   int pw1_nr = 4, pw1_nm = 4;     // tile shape for the prepared geometry
-  DevBuf pw2_16;                  // pwconv2: NR = 4 / 2 / 1 orders
-  std::vector<size_t> pw2_off4, pw2_off2, pw2_off1;
-  bool pw2_16_ok = false;
-  int pw2_nr = 4, pw2_nm = 4;
 };
 
 static fdx_cn_state* cn(fdx_ctx* h) {
@@ -391,25 +384,6 @@ extern "C" int fdx_convnext_attach(fdx_handle h, const fdx_convnext_desc* d, con
     FDX_HIP(h, hipDeviceSynchronize());
     S->pw1_16_ok = true;
   }
-  S->pw2_16_ok = false;
-  if (cn_pw2_16s() && !S->l.pw2.empty() && S->l.pw2[0].RB == 1 && d->dim % 64 == 0) {
-    FDX_HIP(h, hipSetDevice(h->device));
-    size_t tot = 0;
-    for (const auto& p : S->l.pw2) tot += 3 * packed_floats(p.n_mtiles, 1, p.cin8, 1);
-    FDX_HIP(h, S->pw2_16.ensure(tot * sizeof(float), false, nullptr));
-    S->pw2_off4.clear(); S->pw2_off2.clear(); S->pw2_off1.clear();
-    size_t c = 0;
-    for (const auto& p : S->l.pw2) {
-      const size_t nf = packed_floats(p.n_mtiles, 1, p.cin8, 1);
-      S->pw2_off4.push_back(c); S->pw2_off2.push_back(c + nf); S->pw2_off1.push_back(c + 2 * nf);
-      hipLaunchKernelGGL(k_repack16_from32rb1<4>, dim3((unsigned)((nf / 4 + 255) / 256)), dim3(256), 0, nullptr, S->pw2_16.f() + c, S->arena + p.w_off, p.n_mtiles, p.cin8);
-      hipLaunchKernelGGL(k_repack16_from32rb1<2>, dim3((unsigned)((nf / 2 + 255) / 256)), dim3(256), 0, nullptr, S->pw2_16.f() + c + nf, S->arena + p.w_off, p.n_mtiles, p.cin8);
-      hipLaunchKernelGGL(k_repack16_from32rb1<1>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, nullptr, S->pw2_16.f() + c + 2 * nf, S->arena + p.w_off, p.n_mtiles, p.cin8);
-      c += 3 * nf;
-    }
-    FDX_HIP(h, hipDeviceSynchronize());
-    S->pw2_16_ok = true;
-  }
   return FDX_OK;
 }
 
@@ -447,27 +421,7 @@ extern "C" int fdx_convnext_prepare(fdx_handle h, const float* cond, int B, int 
     if ((sh.NR != 2 && sh.NR != 4) || sh.NM < 4 || sh.NM > 8) sh = Shape16{4, 4};
     S->pw1_nr = sh.NR; S->pw1_nm = sh.NM;
   }
-  FDX_HIP(h, b.G.ensure(sz(H) + kTailPad * sizeof(float), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s)); FDX_HIP(h, b.c2.ensure(sz(D), geom, s));
-  if (S->pw2_16_ok) {   // pwconv2's tile: the cheapest (rounds of the chip) x (MFMAs per K iteration + fixed cost) over NR in {1, 2, 4}, NM in 4 .. 8
-    const int rows16 = D / 16, n_per_wave = (H / 8 + 3) / 4;
-    Shape16 best{4, 4};
-    const long wg44 = (long)(rows16 / 4) * B * ((T + 63) / 64);
-    if (wg44 < 2 * 256) {
-      double best_cost = 1e300;
-      const double fixed = 12000.0 / (32.0 * n_per_wave);
-      for (int NR = 4; NR >= 1; NR >>= 1)
-        for (int NM = 4; NM <= 8; ++NM) {
-          if (rows16 % NR) continue;
-          const long wgs = (long)(rows16 / NR) * B * ((T + 16 * NM - 1) / (16 * NM));
-          const double cost = (double)((wgs + 255) / 256) * (2.0 * NM * NR + fixed) * (NR == 4 ? 1.0 : 1.02);
-          if (cost < best_cost - 1e-9) { best_cost = cost; best = Shape16{NR, NM}; }
-        }
-    }
-    static const int forced = [] { const char* e = getenv("FDX_CN_PW2_SHAPE"); return e ? atoi(e) : -1; }();
-    if (forced > 0) best = Shape16{forced / 10, forced % 10};
-    if ((best.NR != 1 && best.NR != 2 && best.NR != 4) || best.NM < 4 || best.NM > 8) best = Shape16{4, 4};
-    S->pw2_nr = best.NR; S->pw2_nm = best.NM;
-  }
+  FDX_HIP(h, b.G.ensure(sz(H), geom, s)); FDX_HIP(h, b.c1.ensure(sz(H), geom, s)); FDX_HIP(h, b.c2.ensure(sz(D), geom, s));
   FDX_HIP(h, b.condp.ensure(sz(E), geom, s)); FDX_HIP(h, b.CP.ensure(sz(L * D), geom, s));
   FDX_HIP(h, b.ST.ensure((size_t)B * T * 32 * sizeof(float), false, s));
   // condition = conditioner_projection(conditioner).masked_fill(cond_masks)  (convnext.py:242,247-248)
@@ -648,27 +602,7 @@ int fdx_cn_forward_core(fdx_ctx* h, const float* xin, int col0, int sb_bs, const
     }
     EpiScaleRes e{};
     e.X = X; e.bs = bsD; e.ld = ld; e.bias = A + l.pw2[i].b_off; e.gamma = A + l.gamma[i]; e.M = D; e.mask = mask; e.mask_ld = T;
-    if (S->pw2_16_ok) {
-      const PackedW& p = l.pw2[i];
-      const int NRs = S->pw2_nr, NMs = S->pw2_nm;
-      const ConvGeom g4{B, T, p.cin8, 1, 0, 0, D / 64}, g2{B, T, p.cin8, 1, 0, 0, D / 32}, g1{B, T, p.cin8, 1, 0, 0, D / 16};
-      const void* W4 = S->pw2_16.f() + S->pw2_off4[i];
-      const void* W2 = S->pw2_16.f() + S->pw2_off2[i];
-      const void* W1 = S->pw2_16.f() + S->pw2_off1[i];
-      hipError_t er = hipErrorInvalidValue;
-#define FDX_PW2_SHAPE(NR_, NM_)                                                                                                      \
-  if (NRs == NR_ && NMs == NM_) {                                                                                                    \
-    const EpiScaleRes16S<NM_> es{X, bsD, ld, A + p.b_off, A + l.gamma[i], mask, T};                                                  \
-    er = launch_convgemm16s<EpiScaleRes16S<NM_>, NR_, NM_>(NR_ == 4 ? g4 : NR_ == 2 ? g2 : g1, NR_ == 4 ? W4 : NR_ == 2 ? W2 : W1, G, bsH, ld, es, s); \
-  }
-      FDX_PW2_SHAPE(4, 4) FDX_PW2_SHAPE(4, 5) FDX_PW2_SHAPE(4, 6) FDX_PW2_SHAPE(4, 7) FDX_PW2_SHAPE(4, 8)
-      FDX_PW2_SHAPE(2, 4) FDX_PW2_SHAPE(2, 5) FDX_PW2_SHAPE(2, 6) FDX_PW2_SHAPE(2, 7) FDX_PW2_SHAPE(2, 8)
-      FDX_PW2_SHAPE(1, 4) FDX_PW2_SHAPE(1, 5) FDX_PW2_SHAPE(1, 6) FDX_PW2_SHAPE(1, 7) FDX_PW2_SHAPE(1, 8)
-#undef FDX_PW2_SHAPE
-      FDX_HIP(h, er);
-    } else {
-      FDX_HIP(h, gemm(A, wide_pw2 ? l.pw2w[i] : l.pw2[i], B, T, G, bsH, ld, e, s));
-    }
+    FDX_HIP(h, gemm(A, wide_pw2 ? l.pw2w[i] : l.pw2[i], B, T, G, bsH, ld, e, s));
   }
   FDX_HIP(h, gemm(A, l.out0, B, T, X, bsD, ld, bias_epi(H2, bsD, ld, A + l.out0.b_off, D, ACT_GELU), s));
   if (fuse) {   // UniPC: eps is consumed in the epilogue (corrector + the next step's predictor), bit-identical to the separate launch

@@ -285,9 +285,9 @@ def _fixtures():
 
 # ------------------------------------------------------------------------------------------------ the A/B arms of round 6 stay correct
 @pytest.mark.parametrize("env", [dict(FDX_TD_LNFOLD="0"), dict(FDX_TD_SAIN_RB="2", FDX_TD_LIN1_RB="2"), dict(FDX_CN_LNP="0", FDX_CN_PW1_RB="2"), dict(FDX_CN_PW1_RB="2"),
-                                 dict(FDX_CN_LNP="0"), dict(FDX_CN_PW1_16S="0", FDX_CN_PW2_16S="0"), dict(FDX_TD_LIN1_16S="0")],
+                                 dict(FDX_CN_LNP="0"), dict(FDX_CN_PW1_16S="0"), dict(FDX_TD_LIN1_16S="0")],
                          ids=["layernorm-launched", "tfdec-64-row-tiles", "convnext-round5", "convnext-lnp-64-row", "convnext-centred-32-row",
-                              "convnext-pointwise-32x32x2", "tfdec-linear1-32x32x2"])
+                              "convnext-pwconv1-32x32x2", "tfdec-linear1-32x32x2"])
 def test_round6_switches_hold_the_reference_goldens(dev, env):
     """INTEGRATION.md lists the switches that bring back the round-5 forms (LayerNorm launches, 64-row tiles, ConvNext's group-centred fold): they
     decide the arena layout, so each arm runs in its own process -- and must hold the same reference goldens as the default (forward of both
@@ -305,7 +305,7 @@ def test_round6_switches_hold_the_reference_goldens(dev, env):
 
 
 # ------------------------------------------------------------------------------------------------ pwconv1 on the 16x16x4 family: tile shapes
-def test_convnext_pointwise_tile_shapes_are_bit_identical(dev):
+def test_convnext_pwconv1_tile_shapes_are_bit_identical(dev):
     """Second session of round 6: ConvNext's pwconv1 (LayerNorm folded in, GELU epilogue) runs on the shape-adaptive split-K family of the
     residual-block GEMMs (convgemm16s.hip.h, PRE_LNP).  The tile shape is a scheduling choice there -- every output is the same k-ordered fp32 chain
     over the same four K ranges, the column statistics are combined per column -- so every forced shape (FDX_CN_PW1_SHAPE=<NR><NM>, own process)
@@ -337,14 +337,11 @@ for B, T in ((1, 1), (1, 37), (2, 113), (1, 257), (3, 430), (1, 861)):
 print("DIGEST", h.hexdigest())
 ''' % ROOT
     digests = {}
-    pw2 = {"auto": None, "44": "14", "47": "17", "48": "28", "24": "24", "27": "47", "28": "18", "45": "15"}      # pwconv2's tile forced alongside (NR = 1 only it has)
     for shape in ("auto", "44", "47", "48", "24", "27", "28", "45"):
         env = dict(os.environ)
         env.pop("FDX_CN_PW1_SHAPE", None)
-        env.pop("FDX_CN_PW2_SHAPE", None)
         if shape != "auto":
             env["FDX_CN_PW1_SHAPE"] = shape
-            env["FDX_CN_PW2_SHAPE"] = pw2[shape]
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "DIGEST" in r.stdout, shape + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
         digests[shape] = r.stdout.split("DIGEST")[1].split()[0]
